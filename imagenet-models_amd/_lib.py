@@ -1,0 +1,137 @@
+"""ctypes binding of csrc/libgaext.so (C ABI declared in include/gaext.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libgaext.so')
+
+GA_F32, GA_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+A_PLAIN, A_PATCH2, A_STEM4_NCHW, A_CONV3 = 0, 1, 2, 3
+C_PLAIN, C_UNPATCH2 = 0, 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ('M', i32), ('N', i32), ('K', i32), ('batch', i32), ('dtype', i32),
+        ('A', vp), ('lda', i64), ('strideA', i64), ('a_batch_mod', i32), ('a_kind', i32),
+        ('a_H', i32), ('a_W', i32), ('a_C', i32), ('a_act', i32),
+        ('B', vp), ('ldb', i64), ('strideB', i64),
+        ('C', vp), ('ldc', i64), ('strideC', i64), ('c_kind', i32),
+        ('c_H', i32), ('c_W', i32), ('c_C', i32), ('c_f32', i32),
+        ('alpha', f32), ('bias', vp), ('strideBias', i64), ('act', i32),
+        ('H', vp), ('ldh', i64), ('strideH', i64),
+        ('rowscale', vp), ('rows_per_scale', i32),
+        ('R', vp), ('ldr', i64), ('strideR', i64), ('relu_after', i32),
+        ('colsum', vp), ('colsumsq', vp), ('strideCol', i64),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ('M', i32), ('N', i32), ('K', i32), ('batch', i32), ('dtype', i32),
+        ('Y', vp), ('ldy', i64), ('strideY', i64),
+        ('X', vp), ('ldx', i64), ('strideX', i64), ('x_kind', i32),
+        ('x_H', i32), ('x_W', i32), ('x_C', i32), ('x_act', i32),
+        ('dW', vp), ('ldw', i64), ('strideW', i64),
+        ('dbias', vp), ('strideDbias', i64),
+        ('alpha', f32), ('split_m', i32), ('accumulate', i32),
+    ]
+
+
+class WprepDesc(C.Structure):
+    _fields_ = [
+        ('w', vp), ('G', i32), ('Co', i32), ('Ci', i32), ('KH', i32), ('KW', i32),
+        ('rs', vp), ('cs', vp), ('dtype', i32),
+        ('out', vp), ('ldo', i64), ('outT', vp), ('ldt', i64), ('flip', i32), ('stem', i32),
+    ]
+
+
+class WunfoldDesc(C.Structure):
+    _fields_ = [
+        ('G', vp), ('ldg', i64), ('gb', vp), ('W', vp), ('b', vp), ('rs', vp), ('cs', vp), ('v', vp),
+        ('N', i32), ('Ci', i32), ('KH', i32), ('KW', i32), ('stem', i32),
+        ('dW', vp), ('db', vp), ('d_rs', vp), ('d_cs', vp), ('d_v', vp),
+    ]
+
+
+_SIGS = {
+    'ga_version': ([], i32),
+    'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
+    'ga_device_info': ([C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    'ga_gemm': ([C.POINTER(GemmDesc), vp], i32),
+    'ga_wgrad': ([C.POINTER(WgradDesc), vp], i32),
+    'ga_weight_prep': ([C.POINTER(WprepDesc), vp], i32),
+    'ga_bias_fold': ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    'ga_weight_unfold': ([C.POINTER(WunfoldDesc), vp], i32),
+    'ga_dwconv7_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwconv7_bwd_data': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwconv7_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
+    'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    'ga_bn_finalize': ([vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    'ga_affine_act': ([vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),
+    'ga_bn_bwd_apply': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp], i32),
+    'ga_pool_concat_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_pool_concat_bwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_spatial_sum': ([vp, vp, vp, i32, i32, i32, f32, i32, vp], i32),
+    'ga_se_mlp_fwd': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    'ga_se_mlp_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    'ga_chan_scale': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_gram_pack_fwd': ([vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_gram_pack_bwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_token_cat': ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_token_split': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_class_attn_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_bwd': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_loss_fwd_bwd': ([vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, i32, vp], i32),
+    'ga_heads_topk': ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
+    'ga_sgd_step': ([vp, vp, vp, vp, i64, i32, f32, vp], i32),
+    'ga_adamw_step': ([vp, vp, vp, vp, vp, i64, f32, vp], i32),
+    'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
+    'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
+    'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),
+    'ga_rowscale': ([vp, vp, vp, i64, i64, i32, vp], i32),
+    'ga_cast_from_f32': ([vp, vp, i64, i32, vp], i32),
+    'ga_cast_to_f32': ([vp, vp, i64, i32, vp], i32),
+}
+
+_lib = None
+
+
+def load():
+    """Load libgaext.so (built by __graft_entry__.build() / `make -C csrc`). Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f'libgaext.so not found at {LIB_PATH}: build it with `make -C {os.path.dirname(LIB_PATH)}` '
+                           f'(there is no CPU fallback for the product path)')
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().ga_last_error(buf, 512)
+    return buf.value.decode(errors='replace')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'libgaext {what} failed (code {rc}): {last_error()}')
+
+
+def exported_symbols():
+    return sorted(_SIGS)

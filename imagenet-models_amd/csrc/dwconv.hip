@@ -1,0 +1,319 @@
+// Depthwise 7x7 convolution (pad 3, stride 1), NHWC, for gfx950.  HBM/LDS-bound VALU kernels -- no MFMA:
+// 49 MAC per element, a depthwise product as a GEMM would waste 1 - 1/C of the matrix core.
+//
+//  * workgroup = (image, TH x TW output tile, slice of <=64 channels); the input tile with its 3-pixel halo is
+//    staged once in LDS ([pixel][channel], channel-contiguous so global loads are 128 B per pixel);
+//  * work item = (output row, strip of 7 output pixels, 4 channels): a 13-pixel input row segment is held in
+//    registers and reused by the 7 taps x 7 outputs of that row -> 13 LDS reads per 196 FMAs;
+//  * forward and backward-data are the same kernel (backward-data = flipped taps, + fused residual add);
+//  * backward-weight keeps the 49 x 64 partial sums of a channel slice in registers while a persistent
+//    workgroup walks over many tiles, so only nblocks x 49 x 64 fp32 atomics reach memory.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+int num_cus() {
+    static int n = [] {
+        int c = 256;
+        ga_device_info(&c, nullptr, nullptr);
+        return c;
+    }();
+    return n;
+}
+
+constexpr int kCS = 64;   // channels per slice
+constexpr int kCG = 4;    // channels per work item
+
+template <typename T> struct vec4;  // 4 channels of T
+template <> struct vec4<float> { typedef float4 type; };
+template <> struct vec4<bf16_t> { typedef uint2 type; };
+
+__device__ __forceinline__ void cvt4(const float4& v, float f[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+__device__ __forceinline__ void cvt4(const uint2& v, float f[4]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+// stage a (TH+6)x(TW+6) x cs tile (zero outside the image) of NHWC tensor `src` into LDS [pix][kCS]
+template <typename T, int TH, int TW>
+__device__ __forceinline__ void stage_halo(const T* src, T* lds, long img_base, int H, int W, int C, int y0, int x0,
+                                           int c0, int cs, int tid, int nthreads) {
+    constexpr int PW = TW + 6, PH = TH + 6;
+    const int cgs = cs / kCG;
+    for (int i = tid; i < PH * PW * cgs; i += nthreads) {
+        const int cg = i % cgs, p = i / cgs;
+        const int py = p / PW, px = p - py * PW;
+        const int y = y0 + py - 3, x = x0 + px - 3;
+        typename vec4<T>::type v;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+            v = *reinterpret_cast<const typename vec4<T>::type*>(src + (img_base + (long)y * W + x) * C + c0 + cg * kCG);
+        else
+            memset(&v, 0, sizeof(v));
+        *reinterpret_cast<typename vec4<T>::type*>(lds + p * kCS + cg * kCG) = v;
+    }
+}
+
+// y = bias + conv7x7(x, w)  [+ res];  flip selects the transposed (backward-data) taps
+template <typename T, int TH, int TW, int NT>
+__global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, const float* __restrict__ w49,
+                                                     const float* __restrict__ bias, const T* __restrict__ res,
+                                                     T* __restrict__ y, int H, int W, int C, int flip) {
+    constexpr int PW = TW + 6, PH = TH + 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* xs = reinterpret_cast<T*>(smem);                                    // [PH*PW][kCS]
+    float* ws = reinterpret_cast<float*>(smem + PH * PW * kCS * sizeof(T)); // [49][kCS]
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const long b = t / tiles_y;
+    const int c0 = blockIdx.y * kCS;
+    const int cs = min(kCS, C - c0);
+    const int y0 = ty * TH, x0 = tx * TW;
+    const long img = b * H * W;
+
+    stage_halo<T, TH, TW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
+    for (int i = tid; i < 49 * cs; i += NT) {
+        const int tap = i / cs, c = i - tap * cs;
+        ws[tap * kCS + c] = w49[(flip ? 48 - tap : tap) * C + c0 + c];
+    }
+    __syncthreads();
+
+    const int cgs = cs / kCG;
+    constexpr int XS = TW / 7;                 // strips per row
+    const int nitems = TH * XS * cgs;
+    for (int it = tid; it < nitems; it += NT) {
+        const int cg = it % cgs;
+        int r = it / cgs;
+        const int oy = r % TH, xsi = r / TH;   // row-fastest item order (see bank note in DESIGN.md)
+        const int ox0 = xsi * 7;
+        float acc[7][4];
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c] = bias[c0 + cg * kCG + c];
+        }
+#pragma unroll
+        for (int o = 0; o < 7; ++o)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[o][c] = bv[c];
+#pragma unroll 1
+        for (int ky = 0; ky < 7; ++ky) {
+            float in[13][4];
+            const T* rowp = xs + ((oy + ky) * PW + ox0) * kCS + cg * kCG;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCS), in[i]);
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) {
+                const float4 wv = *reinterpret_cast<const float4*>(ws + (ky * 7 + kx) * kCS + cg * kCG);
+#pragma unroll
+                for (int o = 0; o < 7; ++o) {
+                    acc[o][0] = fmaf(in[o + kx][0], wv.x, acc[o][0]);
+                    acc[o][1] = fmaf(in[o + kx][1], wv.y, acc[o][1]);
+                    acc[o][2] = fmaf(in[o + kx][2], wv.z, acc[o][2]);
+                    acc[o][3] = fmaf(in[o + kx][3], wv.w, acc[o][3]);
+                }
+            }
+        }
+        const int yy = y0 + oy;
+        if (yy < H) {
+#pragma unroll
+            for (int o = 0; o < 7; ++o) {
+                const int xx = x0 + ox0 + o;
+                if (xx < W) {
+                    const long off = (img + (long)yy * W + xx) * C + c0 + cg * kCG;
+                    if (res) {
+                        float rv[4];
+                        load4(res + off, rv);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[o][c] += rv[c];
+                    }
+                    store4(y + off, acc[o]);
+                }
+            }
+        }
+    }
+}
+
+// dw49[tap][c] += sum_{b,y,x} dy[b,y,x,c] * x[b,y+ky-3,x+kx-3,c];   dbias[c] += sum dy
+// persistent: blockIdx.x walks tiles with stride gridDim.x, blockIdx.y = channel slice.
+template <typename T, int TH, int TW, int NT>
+__global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           float* __restrict__ dw49, float* __restrict__ dbias, int B,
+                                                           int H, int W, int C) {
+    constexpr int PW = TW + 6, PH = TH + 6;
+    constexpr int RS = TH / 7;  // row groups of 7 output rows
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T* xs = reinterpret_cast<T*>(smem);                                   // [PH*PW][kCS]
+    T* ds = reinterpret_cast<T*>(smem + PH * PW * kCS * sizeof(T));       // [TH*TW][kCS]
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long ntiles = (long)B * tiles_x * tiles_y;
+    const int c0 = blockIdx.y * kCS;
+    const int cs = min(kCS, C - c0);
+    const int cgs = cs / kCG;
+    // item = (cg, ky, row group): keeps acc[7 kx][4 ch] (+ 4 bias sums) in registers across tiles
+    const int nitems = cgs * 7 * RS;
+    const bool active = tid < nitems;
+    const int cg = tid % cgs;
+    const int ky = (tid / cgs) % 7;
+    const int rg = tid / (cgs * 7);
+    float acc[7][4], bsum[4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[k][c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) bsum[c] = 0.f;
+
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        long tt = t;
+        const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+        const int ty = (int)(tt % tiles_y);
+        const long b = tt / tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        const long img = b * H * W;
+        __syncthreads();  // previous tile fully consumed
+        stage_halo<T, TH, TW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
+        for (int i = tid; i < TH * TW * cgs; i += NT) {
+            const int g = i % cgs, p = i / cgs;
+            const int py = p / TW, px = p - py * TW;
+            const int yy = y0 + py, xx = x0 + px;
+            typename vec4<T>::type v;
+            if (yy < H && xx < W)
+                v = *reinterpret_cast<const typename vec4<T>::type*>(dy + (img + (long)yy * W + xx) * C + c0 + g * kCG);
+            else
+                memset(&v, 0, sizeof(v));
+            *reinterpret_cast<typename vec4<T>::type*>(ds + p * kCS + g * kCG) = v;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll 1
+            for (int r = 0; r < 7; ++r) {
+                const int oy = rg * 7 + r;
+#pragma unroll 1
+                for (int xs0 = 0; xs0 < TW; xs0 += 7) {
+                    float in[13][4], g[7][4];
+                    const T* rowp = xs + ((oy + ky) * PW + xs0) * kCS + cg * kCG;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i)
+                        cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCS), in[i]);
+                    const T* dp = ds + (oy * TW + xs0) * kCS + cg * kCG;
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(dp + i * kCS), g[i]);
+#pragma unroll
+                    for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                        for (int o = 0; o < 7; ++o)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[kx][c] = fmaf(g[o][c], in[o + kx][c], acc[kx][c]);
+                    if (ky == 0) {
+#pragma unroll
+                        for (int o = 0; o < 7; ++o)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) bsum[c] += g[o][c];
+                    }
+                }
+            }
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dw49 + (long)(ky * 7 + kx) * C + c0 + cg * kCG + c, acc[kx][c]);
+        if (ky == 0 && dbias) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dbias + c0 + cg * kCG + c, bsum[c]);
+        }
+    }
+}
+
+template <typename T>
+int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
+                  int C, int flip, hipStream_t s) {
+    const int slices = cdiv(C, kCS);
+    if (H % 14 == 0 && W % 14 == 0) {
+        constexpr int TH = 14, TW = 14, NT = 256;
+        const size_t lds = (TH + 6) * (TW + 6) * kCS * sizeof(T) + 49 * kCS * 4;
+        auto k = dwconv7_kernel<T, TH, TW, NT>;
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                ga_set_error("dwconv7: cannot reserve %zu B of LDS", lds);
+                return GA_ERR_HIP;
+            }
+            once = true;
+        }
+        dim3 grid(B * (H / TH) * (W / TW), slices);
+        hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, (const T*)x, w49, bias, (const T*)res, (T*)y, H, W, C, flip);
+    } else {
+        constexpr int TH = 7, TW = 7, NT = 128;
+        const size_t lds = (TH + 6) * (TW + 6) * kCS * sizeof(T) + 49 * kCS * 4;
+        dim3 grid(B * cdiv(H, TH) * cdiv(W, TW), slices);
+        hipLaunchKernelGGL((dwconv7_kernel<T, TH, TW, NT>), grid, dim3(NT), lds, s, (const T*)x, w49, bias,
+                           (const T*)res, (T*)y, H, W, C, flip);
+    }
+    return ga_check_launch("ga_dwconv7");
+}
+
+template <typename T>
+int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
+                        hipStream_t s) {
+    const int slices = cdiv(C, kCS);
+    const int num_cu = num_cus();
+    if (H % 14 == 0 && W % 14 == 0) {
+        constexpr int TH = 14, TW = 14, NT = 256;
+        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCS * sizeof(T);
+        auto k = dwconv7_wgrad_kernel<T, TH, TW, NT>;
+        static bool once = false;
+        if (!once) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                ga_set_error("dwconv7_wgrad: cannot reserve %zu B of LDS", lds);
+                return GA_ERR_HIP;
+            }
+            once = true;
+        }
+        const long ntiles = (long)B * (H / TH) * (W / TW);
+        const int gx = (int)std::min<long>(ntiles, std::max(1, 2 * num_cu / slices));
+        hipLaunchKernelGGL(k, dim3(gx, slices), dim3(NT), lds, s, (const T*)dy, (const T*)x, dw49, dbias, B, H, W, C);
+    } else {
+        constexpr int TH = 7, TW = 7, NT = 128;
+        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCS * sizeof(T);
+        const long ntiles = (long)B * cdiv(H, TH) * cdiv(W, TW);
+        const int gx = (int)std::min<long>(ntiles, std::max(1, 4 * num_cu / slices));
+        hipLaunchKernelGGL((dwconv7_wgrad_kernel<T, TH, TW, NT>), dim3(gx, slices), dim3(NT), lds, s, (const T*)dy,
+                           (const T*)x, dw49, dbias, B, H, W, C);
+    }
+    return ga_check_launch("ga_dwconv7_bwd_weight");
+}
+
+}  // namespace
+
+extern "C" int ga_dwconv7_fwd(const void* x, const float* w49, const float* bias, void* y, int B, int H, int W, int C,
+                              int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && w49 && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ga_dwconv7_fwd: bad args (C%%4)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? launch_dwconv<bf16_t>(x, w49, bias, nullptr, y, B, H, W, C, 0, s)
+                            : launch_dwconv<float>(x, w49, bias, nullptr, y, B, H, W, C, 0, s);
+}
+
+extern "C" int ga_dwconv7_bwd_data(const void* dy, const float* w49, const void* res, void* dx, int B, int H, int W,
+                                   int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && w49 && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ga_dwconv7_bwd_data: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? launch_dwconv<bf16_t>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s)
+                            : launch_dwconv<float>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s);
+}
+
+extern "C" int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W,
+                                     int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && x && dw49 && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ga_dwconv7_bwd_weight: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? launch_dwconv_wgrad<bf16_t>(dy, x, dw49, dbias, B, H, W, C, s)
+                            : launch_dwconv_wgrad<float>(dy, x, dw49, dbias, B, H, W, C, s);
+}

@@ -1,0 +1,663 @@
+// MFMA GEMM kernels for gfx950 (MI355X): ga_gemm (NT, forward + dgrad) and ga_wgrad (TN, reduction over rows).
+//
+// Design (see DESIGN.md "GEMM family"):
+//  * 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles),
+//    K streamed in 128-byte slabs (64 bf16 / 32 fp32), register-staged global->LDS with a 2-deep LDS ring:
+//    the global loads of slab t+1 are in flight while slab t is multiplied (one barrier per slab).
+//  * bf16: v_mfma_f32_16x16x32_bf16;  fp32 (parity math mode): v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain).
+//  * LDS images are XOR-swizzled at 16-byte granularity so that the ds_read_b128 fragment reads
+//    (16 rows x one 16-B chunk per 16-lane group) are bank-conflict free.
+//  * The weight fragment is passed as the MFMA "A" operand so each lane ends up with 4 CONSECUTIVE output
+//    columns of one output row; the tile is then staged through LDS (fp32) and written with 16-byte stores,
+//    which is also where bias / GELU / GELU' / DropPath row-scale / residual / ReLU / BatchNorm column
+//    statistics are fused.
+//  * wgrad reads both operands "k-strided" (rows = reduction index): bf16 uses ds_read_b64_tr_b16, the gfx950
+//    transposing LDS read, on a [rows][128] image whose 32-byte pieces are XOR-swizzled conflict-free.
+//  * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous chunk of the tile list so that
+//    workgroups sharing an operand panel hit the same L2.
+#include "common.h"
+
+namespace {
+
+constexpr int kBM = 128, kBN = 128, kThreads = 256;
+constexpr int kRowBytes = 128;          // bytes of K per LDS row (NT kernel)
+constexpr int kTileBytes = kBM * kRowBytes;  // 16 KiB per operand per buffer
+constexpr int kLdc = 132;               // padded fp32 row stride of the staged C tile
+constexpr int kSmemNT = kBM * kLdc * 4; // 67584 B >= 4 * kTileBytes
+
+// bijective XCD-aware remap of a linear workgroup id (guide T1): blocks b, b+8, b+16.. share an XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A-operand gather (implicit im2col).  One RowCtx per staged row; one chunk = 16 bytes of T.
+// ------------------------------------------------------------------------------------------------
+struct RowCtx {
+    long base;   // element offset of the row start (plain) / of the patch origin pixel (gather kinds)
+    int y, x;    // output pixel coords (CONV3)
+    bool valid;
+};
+
+__device__ __forceinline__ RowCtx make_row(int kind, long m, long M, long ld, int H, int W, int C) {
+    RowCtx r;
+    r.valid = m < M;
+    r.y = r.x = 0;
+    r.base = 0;
+    if (!r.valid) return r;
+    if (kind == GA_A_PLAIN) {
+        r.base = m * ld;
+    } else if (kind == GA_A_PATCH2) {
+        const int OW = W >> 1, OH = H >> 1;
+        const int ox = (int)(m % OW);
+        const long t = m / OW;
+        const int oy = (int)(t % OH);
+        const long b = t / OH;
+        r.base = ((b * H + 2 * oy) * W + 2 * ox) * (long)C;
+    } else if (kind == GA_A_CONV3) {
+        const int x = (int)(m % W);
+        const long t = m / W;
+        const int y = (int)(t % H);
+        const long b = t / H;
+        r.base = b * H * W;  // pixel index of the image start
+        r.y = y;
+        r.x = x;
+    } else {  // GA_A_STEM4_NCHW: fp32 NCHW input, C == 3 planes
+        const int OW = W >> 2, OH = H >> 2;
+        const int ox = (int)(m % OW);
+        const long t = m / OW;
+        const int oy = (int)(t % OH);
+        const long b = t / OH;
+        r.base = ((b * C) * H + 4 * oy) * (long)W + 4 * ox;  // float index of (b, c=0, 4oy, 4ox)
+    }
+    return r;
+}
+
+// per-thread decomposition of the chunk's first k index (same for all rows a thread stages)
+struct KCtx {
+    long off;    // element offset added to RowCtx.base
+    int dy, dx;  // tap offset (CONV3)
+    bool valid;
+};
+
+__device__ __forceinline__ KCtx make_k(int kind, int k, int K, int H, int W, int C) {
+    KCtx c;
+    c.valid = k < K;
+    c.off = 0;
+    c.dy = c.dx = 0;
+    if (!c.valid) return c;
+    if (kind == GA_A_PLAIN) {
+        c.off = k;
+    } else if (kind == GA_A_PATCH2) {
+        const int tap = k / C, ch = k - tap * C;
+        c.off = ((long)(tap >> 1) * W + (tap & 1)) * C + ch;
+    } else if (kind == GA_A_CONV3) {
+        const int tap = k / C, ch = k - tap * C;
+        c.dy = tap / 3 - 1;
+        c.dx = tap % 3 - 1;
+        c.off = ((long)c.dy * W + c.dx) * C + ch;
+    } else {  // stem: k = (c, ky, kx)
+        const int ch = k >> 4, ky = (k >> 2) & 3;
+        c.off = ((long)ch * H + ky) * W;  // kx == 0 at a chunk start
+    }
+    return c;
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 load_chunk(int kind, const void* base, const RowCtx& r, const KCtx& k, int H, int W,
+                                            int C) {
+    uint4 z = make_uint4(0, 0, 0, 0);
+    if (!(r.valid && k.valid)) return z;
+    if (kind == GA_A_CONV3) {
+        const int yy = r.y + k.dy, xx = r.x + k.dx;
+        if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return z;
+        const long pix = r.base + (long)r.y * W + r.x;
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(base) + pix * C + k.off);
+    }
+    if (kind == GA_A_STEM4_NCHW) {
+        const float* p = reinterpret_cast<const float*>(base) + r.base + k.off;
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        if constexpr (sizeof(T) == 4) {
+            return make_uint4(__float_as_uint(a.x), __float_as_uint(a.y), __float_as_uint(a.z), __float_as_uint(a.w));
+        } else {
+            const float4 b = *reinterpret_cast<const float4*>(p + W);  // next ky row
+            return make_uint4(pack2bf(a.x, a.y), pack2bf(a.z, a.w), pack2bf(b.x, b.y), pack2bf(b.z, b.w));
+        }
+    }
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(base) + r.base + k.off);
+}
+
+template <typename T> __device__ __forceinline__ uint4 act_chunk(uint4 v, int act) {
+    if (act == GA_ACT_NONE) return v;
+    if constexpr (sizeof(T) == 4) {
+        float f[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = act == GA_ACT_GELU ? gelu_f(f[i]) : fmaxf(f[i], 0.f);
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    } else {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+            lo = act == GA_ACT_GELU ? gelu_f(lo) : fmaxf(lo, 0.f);
+            hi = act == GA_ACT_GELU ? gelu_f(hi) : fmaxf(hi, 0.f);
+            w[i] = pack2bf(lo, hi);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ================================================================================================
+// NT kernel
+// ================================================================================================
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const ga_gemm_desc d) {
+    constexpr int EPC = elt<T>::EPC;
+    constexpr int BK = kRowBytes / (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (d.N + kBN - 1) / kBN, tiles_m = (d.M + kBM - 1) / kBM;
+    const int nwg = tiles_n * tiles_m;
+    const int bid = xcd_remap(blockIdx.x, nwg);
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * kBM, n0 = tile_n * kBN;
+    const int z = blockIdx.z;
+    const int za = d.a_batch_mod > 0 ? z % d.a_batch_mod : z;
+
+    const unsigned char* Ab = reinterpret_cast<const unsigned char*>(d.A) +
+                              (d.a_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * za * d.strideA;
+    const T* Bb = reinterpret_cast<const T*>(d.B) + z * d.strideB;
+
+    // ---- staging roles: thread stages rows r0+32*i (i=0..3), chunk column kc, of both operands
+    const int kc = tid & 7, r0 = tid >> 3;
+    RowCtx arow[4];
+    long brow[4];
+    bool bval[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        arow[i] = make_row(d.a_kind, (long)m0 + r0 + 32 * i, d.M, d.lda, d.a_H, d.a_W, d.a_C);
+        const int n = n0 + r0 + 32 * i;
+        bval[i] = n < d.N;
+        brow[i] = (long)n * d.ldb;
+    }
+    const int nk = (d.K + BK - 1) / BK;
+
+    uint4 ra[4], rb[4];
+    auto g_load = [&](int kt) {
+        const int k = kt * BK + kc * EPC;
+        const KCtx kx = make_k(d.a_kind, k, d.K, d.a_H, d.a_W, d.a_C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = load_chunk<T>(d.a_kind, Ab, arow[i], kx, d.a_H, d.a_W, d.a_C);
+        const bool kv = k < d.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = (kv && bval[i]) ? *reinterpret_cast<const uint4*>(Bb + brow[i] + k) : make_uint4(0, 0, 0, 0);
+    };
+    auto s_store = [&](int buf) {
+        unsigned char* As = smem + buf * 2 * kTileBytes;
+        unsigned char* Bs = As + kTileBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            const int off = row * kRowBytes + ((kc ^ (row & 7)) << 4);
+            *reinterpret_cast<uint4*>(As + off) = act_chunk<T>(ra[i], d.a_act);
+            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
+        }
+    };
+
+    f32x4_t acc[4][4];  // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    g_load(0);
+    s_store(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) g_load(kt + 1);
+        const unsigned char* As = smem + cur * 2 * kTileBytes;
+        const unsigned char* Bs = As + kTileBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 4 + (lane >> 4);
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ra_ = wm * 64 + t * 16 + (lane & 15);
+                af[t] = *reinterpret_cast<const uint4*>(As + ra_ * kRowBytes + ((chunk ^ (ra_ & 7)) << 4));
+                const int rb_ = wn * 64 + t * 16 + (lane & 15);
+                bf[t] = *reinterpret_cast<const uint4*>(Bs + rb_ * kRowBytes + ((chunk ^ (rb_ & 7)) << 4));
+            }
+            if constexpr (sizeof(T) == 2) {
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int tm = 0; tm < 4; ++tm)
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            *reinterpret_cast<const bf16x8_t*>(&bf[tn]), *reinterpret_cast<const bf16x8_t*>(&af[tm]),
+                            acc[tn][tm], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < 4; ++tm)
+                            acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                reinterpret_cast<const float*>(&bf[tn])[j], reinterpret_cast<const float*>(&af[tm])[j],
+                                acc[tn][tm], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) s_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- stage the fp32 tile through LDS: Cs[m][n], lane holds 4 consecutive n of one m
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int m = wm * 64 + tm * 16 + (lane & 15);
+            const int n = wn * 64 + tn * 16 + (lane >> 4) * 4;
+            *reinterpret_cast<f32x4_t*>(Cs + m * kLdc + n) = acc[tn][tm];
+        }
+    __syncthreads();
+
+    // ---- fused epilogue on 8-column pieces; thread owns column group c8 and rows (tid>>4) + 16*i
+    const int c8 = tid & 15;
+    const int n = n0 + c8 * 8;
+    const bool full = n + 8 <= d.N;
+    float bias[8], csum[8], csq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bias[j] = (d.bias && n + j < d.N) ? d.bias[z * d.strideBias + n + j] : 0.f;
+        csum[j] = csq[j] = 0.f;
+    }
+    const T* Hb = d.H ? reinterpret_cast<const T*>(d.H) + z * d.strideH : nullptr;
+    const T* Rb = d.R ? reinterpret_cast<const T*>(d.R) + z * d.strideR : nullptr;
+    // scatter target decomposition (UNPATCH2): n -> (tap, c)
+    long c_off = 0;
+    if (d.c_kind == GA_C_UNPATCH2 && n < d.N) {
+        const int tap = n / d.c_C, ch = n - tap * d.c_C;
+        c_off = ((long)(tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch;
+    }
+    if (n < d.N) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            const long m = (long)m0 + row;
+            if (m >= d.M) break;
+            float v[8];
+            {
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Cs + row * kLdc + c8 * 8);
+                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Cs + row * kLdc + c8 * 8 + 4);
+                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+                v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha + bias[j];
+            if (d.act == GA_ACT_GELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            } else if (d.act == GA_ACT_RELU) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (Hb) {
+                float h[8];
+                if (full) {
+                    load8(Hb + m * d.ldh + n, h);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
+            }
+            if (d.rowscale) {
+                const float s = d.rowscale[m / d.rows_per_scale];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] *= s;
+            }
+            if (Rb) {
+                float r[8];
+                if (full) {
+                    load8(Rb + m * d.ldr + n, r);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] = n + j < d.N ? elt<T>::ld(Rb + m * d.ldr + n + j) : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += r[j];
+            }
+            if (d.relu_after) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (d.colsum) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    csum[j] += v[j];
+                    csq[j] += v[j] * v[j];
+                }
+            }
+            // ---- store
+            long off;
+            if (d.c_kind == GA_C_UNPATCH2) {
+                const int OW = d.c_W >> 1, OH = d.c_H >> 1;
+                const int ox = (int)(m % OW);
+                const long t = m / OW;
+                const int oy = (int)(t % OH);
+                const long b = t / OH;
+                off = ((b * d.c_H + 2 * oy) * d.c_W + 2 * ox) * (long)d.c_C + c_off;
+            } else {
+                off = z * d.strideC + m * d.ldc + n;
+            }
+            if (d.c_f32) {
+                float* Cp = reinterpret_cast<float*>(d.C) + off;
+                if (full) {
+                    store8(Cp, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (n + j < d.N) Cp[j] = v[j];
+                }
+            } else {
+                T* Cp = reinterpret_cast<T*>(d.C) + off;
+                if (full) {
+                    store8(Cp, v);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (n + j < d.N) elt<T>::st(Cp + j, v[j]);
+                }
+            }
+        }
+    }
+    if (d.colsum) {  // workgroup-level column reduction, then one atomic per column
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);  // [2][16][128]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(tid >> 4) * 128 + c8 * 8 + j] = csum[j];
+            red[2048 + (tid >> 4) * 128 + c8 * 8 + j] = csq[j];
+        }
+        __syncthreads();
+        const int col = tid & 127, which = tid >> 7;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[which * 2048 + r * 128 + col];
+        if (n0 + col < d.N) {
+            if (which == 0) atomicAdd(d.colsum + z * d.strideCol + n0 + col, s);
+            else if (d.colsumsq) atomicAdd(d.colsumsq + z * d.strideCol + n0 + col, s);
+        }
+    }
+}
+
+// ================================================================================================
+// TN (wgrad) kernel: dW[n][k] = sum_m Y[m][n] X[m][k]
+// LDS images are [rows = m][128 columns]; bf16: 64 rows x 256 B, fp32: 32 rows x 512 B (16 KiB each)
+// ================================================================================================
+template <typename T> struct TN {
+    static constexpr int EPC = elt<T>::EPC;
+    static constexpr int RB = 128 * (int)sizeof(T);   // row bytes
+    static constexpr int ROWS = 16384 / RB;           // m rows per slab: 64 (bf16) / 32 (fp32)
+    static constexpr int CPR = RB / 16;               // chunks per row: 16 / 32
+    static constexpr int RSTEP = kThreads / CPR;      // rows covered by one pass of the 256 threads: 16 / 8
+};
+
+__device__ __forceinline__ int tn_swz(int row) { return ((row & 3) << 1) | (((row >> 3) & 1) << 3); }
+
+template <typename T>
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_desc d) {
+    using P = TN<T>;
+    constexpr int EPC = P::EPC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tiles_k = (d.K + 127) / 128;
+    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const int z = blockIdx.z;
+    // m range of this split, in whole slabs
+    const long slabs = (d.M + P::ROWS - 1) / P::ROWS;
+    const long per = (slabs + d.split_m - 1) / d.split_m;
+    const long s_begin = (long)blockIdx.y * per;
+    const long s_end = s_begin + per < slabs ? s_begin + per : slabs;
+    if (s_begin >= s_end) return;
+
+    const T* Yb = reinterpret_cast<const T*>(d.Y) + z * d.strideY;
+    const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X) +
+                              (d.x_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * z * d.strideX;
+
+    const int cc = tid % P::CPR, rr = tid / P::CPR;  // chunk column, first row
+    const int ny = n0 + cc * EPC;                    // Y column of this thread's chunks
+    const bool yv = ny < d.N;
+    const KCtx kx = make_k(d.x_kind, k0 + cc * EPC, d.K, d.x_H, d.x_W, d.x_C);
+
+    uint4 ry[4], rx[4];
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    const bool do_bias = d.dbias != nullptr && tile_k == 0;
+
+    auto g_load = [&](long slab) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = slab * P::ROWS + rr + P::RSTEP * i;
+            ry[i] = (yv && m < d.M) ? *reinterpret_cast<const uint4*>(Yb + m * d.ldy + ny) : make_uint4(0, 0, 0, 0);
+            const RowCtx r = make_row(d.x_kind, m, d.M, d.ldx, d.x_H, d.x_W, d.x_C);
+            rx[i] = load_chunk<T>(d.x_kind, Xb, r, kx, d.x_H, d.x_W, d.x_C);
+        }
+    };
+    auto s_store = [&](int buf) {
+        unsigned char* Ys = smem + buf * 32768;
+        unsigned char* Xs = Ys + 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = rr + P::RSTEP * i;
+            const int off = sizeof(T) == 2 ? row * P::RB + ((cc ^ tn_swz(row)) << 4) : row * P::RB + (cc << 4);
+            *reinterpret_cast<uint4*>(Ys + off) = ry[i];
+            *reinterpret_cast<uint4*>(Xs + off) = act_chunk<T>(rx[i], d.x_act);
+            if (do_bias) {
+                if constexpr (sizeof(T) == 2) {
+                    const unsigned w[4] = {ry[i].x, ry[i].y, ry[i].z, ry[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bsum[2 * j] += __uint_as_float(w[j] << 16);
+                        bsum[2 * j + 1] += __uint_as_float(w[j] & 0xffff0000u);
+                    }
+                } else {
+                    bsum[0] += __uint_as_float(ry[i].x); bsum[1] += __uint_as_float(ry[i].y);
+                    bsum[2] += __uint_as_float(ry[i].z); bsum[3] += __uint_as_float(ry[i].w);
+                }
+            }
+        }
+    };
+
+    f32x4_t acc[4][4];  // [tn][tk]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    g_load(s_begin);
+    s_store(0);
+    __syncthreads();
+    for (long s = s_begin; s < s_end; ++s) {
+        const int cur = (int)((s - s_begin) & 1);
+        if (s + 1 < s_end) g_load(s + 1);
+        const unsigned char* Ys = smem + cur * 32768;
+        const unsigned char* Xs = Ys + 16384;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // 32 reduction rows per MFMA
+                s16x4_t yf[4][2], xf[4][2];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int row = ks * 32 + 8 * (lane >> 4) + 4 * hf + ((lane & 15) >> 2);
+                    const int sw = tn_swz(row);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int ch_y = ((wn * 64 + t * 16) >> 3) + ((lane & 3) >> 1);
+                        const int ch_x = ((wk * 64 + t * 16) >> 3) + ((lane & 3) >> 1);
+                        const unsigned ay = row * P::RB + ((ch_y ^ sw) << 4) + 8 * (lane & 1);
+                        const unsigned ax = row * P::RB + ((ch_x ^ sw) << 4) + 8 * (lane & 1);
+                        yf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(Ys + ay));
+                        xf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4_t*)(Xs + ax));
+                    }
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int tk = 0; tk < 4; ++tk)
+                        acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]), *reinterpret_cast<const bf16x8_t*>(&xf[tk][0]),
+                            acc[tn][tk], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {  // 4 reduction rows per MFMA
+                const int row = ks * 4 + (lane >> 4);
+                float yf[4], xf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    yf[t] = *reinterpret_cast<const float*>(Ys + row * P::RB + (wn * 64 + t * 16 + (lane & 15)) * 4);
+                    xf[t] = *reinterpret_cast<const float*>(Xs + row * P::RB + (wk * 64 + t * 16 + (lane & 15)) * 4);
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                    for (int tk = 0; tk < 4; ++tk)
+                        acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(yf[tn], xf[tk], acc[tn][tk], 0, 0, 0);
+            }
+        }
+        if (s + 1 < s_end) s_store(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- write out: D[n][k]; lane: k = lane&15 (col), n = (lane>>4)*4 + r (rows)
+    float* W = d.dW + z * d.strideW;
+    const bool atomic = d.accumulate || d.split_m > 1;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + tn * 16 + (lane >> 4) * 4 + r;
+                const int k = k0 + wk * 64 + tk * 16 + (lane & 15);
+                if (n < d.N && k < d.K) {
+                    const float v = acc[tn][tk][r] * d.alpha;
+                    if (atomic) atomicAdd(W + (long)n * d.ldw + k, v);
+                    else W[(long)n * d.ldw + k] = v;
+                }
+            }
+    if (do_bias) {  // reduce the per-thread column sums over the threads that share a chunk column
+        float* red = reinterpret_cast<float*>(smem);  // [RSTEP][128]
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) red[rr * 128 + cc * EPC + j] = bsum[j];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < d.N) {
+            float s = 0.f;
+            for (int r = 0; r < P::RSTEP; ++r) s += red[r * 128 + tid];
+            atomicAdd(d.dbias + z * d.strideDbias + n0 + tid, s * d.alpha);
+        }
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
+    GA_REQUIRE(d && d->A && d->B && d->C, "ga_gemm: null operand");
+    GA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1, "ga_gemm: bad shape M=%d N=%d K=%d batch=%d", d->M,
+               d->N, d->K, d->batch);
+    GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "ga_gemm: bad dtype %d", d->dtype);
+    const int epc = d->dtype == GA_BF16 ? 8 : 4;
+    GA_REQUIRE(aligned16(d->A) && aligned16(d->B) && aligned16(d->C), "ga_gemm: operands must be 16-byte aligned");
+    GA_REQUIRE(d->ldb % epc == 0 && d->strideB % epc == 0, "ga_gemm: ldb/strideB must be multiples of %d", epc);
+    GA_REQUIRE(d->K % epc == 0, "ga_gemm: K=%d must be a multiple of %d (pad the operand)", d->K, epc);
+    if (d->a_kind == GA_A_PLAIN) {
+        GA_REQUIRE(d->lda % epc == 0 && d->strideA % epc == 0, "ga_gemm: lda/strideA must be multiples of %d", epc);
+    } else if (d->a_kind == GA_A_PATCH2) {
+        GA_REQUIRE(d->a_C % epc == 0 && d->a_H % 2 == 0 && d->a_W % 2 == 0 && d->K == 4 * d->a_C &&
+                       (long)d->M % ((d->a_H / 2) * (d->a_W / 2)) == 0,
+                   "ga_gemm: PATCH2 needs C%%%d==0, even H,W, K==4C", epc);
+    } else if (d->a_kind == GA_A_CONV3) {
+        GA_REQUIRE(d->a_C % epc == 0 && d->K == 9 * d->a_C && (long)d->M % (d->a_H * d->a_W) == 0,
+                   "ga_gemm: CONV3 needs C%%%d==0, K==9C", epc);
+    } else if (d->a_kind == GA_A_STEM4_NCHW) {
+        GA_REQUIRE(d->a_C == 3 && d->K == 48 && d->a_H % 4 == 0 && d->a_W % 4 == 0, "ga_gemm: STEM4 needs C=3,K=48");
+    } else {
+        GA_REQUIRE(false, "ga_gemm: bad a_kind %d", d->a_kind);
+    }
+    if (d->c_kind == GA_C_UNPATCH2) {
+        GA_REQUIRE(d->c_C % 8 == 0 && d->N == 4 * d->c_C && !d->c_f32, "ga_gemm: UNPATCH2 needs N==4*c_C, c_C%%8==0");
+    } else {
+        GA_REQUIRE(d->c_kind == GA_C_PLAIN, "ga_gemm: bad c_kind");
+    }
+    if (d->H) GA_REQUIRE(aligned16(d->H) && d->ldh % 8 == 0, "ga_gemm: H alignment");
+    if (d->R) GA_REQUIRE(aligned16(d->R) && d->ldr % 8 == 0, "ga_gemm: R alignment");
+    if (d->rowscale) GA_REQUIRE(d->rows_per_scale > 0, "ga_gemm: rows_per_scale");
+    // vector stores need an 8-element aligned leading dimension; otherwise every piece takes the scalar path,
+    // which the kernel selects per piece only at the N edge -> require it here.
+    GA_REQUIRE(d->c_kind != GA_C_PLAIN || d->ldc % 8 == 0, "ga_gemm: ldc=%ld must be a multiple of 8", (long)d->ldc);
+    const int tiles = cdiv(d->M, kBM) * cdiv(d->N, kBN);
+    dim3 grid(tiles, 1, d->batch), block(kThreads);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool attr_ok = [] {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<bf16_t>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSmemNT) == hipSuccess &&
+               hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<float>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSmemNT) == hipSuccess;
+    }();
+    if (!attr_ok) {
+        ga_set_error("ga_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", kSmemNT);
+        return GA_ERR_HIP;
+    }
+    if (d->dtype == GA_BF16)
+        hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, block, kSmemNT, s, *d);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, kSmemNT, s, *d);
+    return ga_check_launch("ga_gemm");
+}
+
+extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
+    GA_REQUIRE(d && d->Y && d->X && d->dW, "ga_wgrad: null operand");
+    GA_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->batch >= 1 && d->split_m >= 1, "ga_wgrad: bad shape");
+    GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "ga_wgrad: bad dtype %d", d->dtype);
+    const int epc = d->dtype == GA_BF16 ? 8 : 4;
+    GA_REQUIRE(aligned16(d->Y) && aligned16(d->X), "ga_wgrad: operands must be 16-byte aligned");
+    GA_REQUIRE(d->N % epc == 0 && d->ldy % epc == 0 && d->strideY % epc == 0, "ga_wgrad: N/ldy must be multiples of %d",
+               epc);
+    GA_REQUIRE(d->K % epc == 0, "ga_wgrad: K must be a multiple of %d", epc);
+    if (d->x_kind == GA_A_PLAIN) {
+        GA_REQUIRE(d->ldx % epc == 0 && d->strideX % epc == 0, "ga_wgrad: ldx must be a multiple of %d", epc);
+    } else if (d->x_kind == GA_A_PATCH2) {
+        GA_REQUIRE(d->x_C % epc == 0 && d->K == 4 * d->x_C, "ga_wgrad: PATCH2 needs K==4C");
+    } else if (d->x_kind == GA_A_CONV3) {
+        GA_REQUIRE(d->x_C % epc == 0 && d->K == 9 * d->x_C, "ga_wgrad: CONV3 needs K==9C");
+    } else if (d->x_kind == GA_A_STEM4_NCHW) {
+        GA_REQUIRE(d->x_C == 3 && d->K == 48, "ga_wgrad: STEM4 needs C=3,K=48");
+    } else {
+        GA_REQUIRE(false, "ga_wgrad: bad x_kind %d", d->x_kind);
+    }
+    dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128), d->split_m, d->batch), block(kThreads);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == GA_BF16)
+        hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, s, *d);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 65536, s, *d);
+    return ga_check_launch("ga_wgrad");
+}

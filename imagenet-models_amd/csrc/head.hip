@@ -1,0 +1,596 @@
+// GA head kernels for gfx950 (all small / HBM- or latency-bound, no MFMA here; the GEMM-shaped parts of the
+// head go through ga_gemm / ga_wgrad):
+//   multi-scale aggregate (avg-pool / copy / bilinear x2 into the channel-concat buffer) + backward,
+//   squeeze-excite (pool, per-sample MLP, gate) + backward,
+//   Gram triu-pack + L2 normalise + backward (produces the symmetric matrix for the dX product),
+//   single-query class attention + backward, token concat / split.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+int nblk(long n, int per = 256, int cap = 8192) { return (int)std::max<long>(1, std::min<long>(cap, (n + per - 1) / per)); }
+
+// ------------------------------------------------------------------------------------------------
+// aggregate: dst[b, oy, ox, c_off + c] = pool(src)[b, oy, ox, c]      (4 channels per thread)
+//   mode 0: f x f average (f = Hin / Hout; f == 1 -> copy);  mode 1: bilinear x2 (align_corners = False)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bil_coef(int o, int n_in, int& i0, int& i1, float& l) {
+    float s = 0.5f * (o + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n_in - 1 ? 1 : 0);
+    l = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_concat_kernel(const T* __restrict__ src, T* __restrict__ dst, int B,
+                                                          int Hin, int Win, int C, int Hout, int Wout, int ldd,
+                                                          int c_off, int mode) {
+    const int cgs = C >> 2;
+    const long total = (long)B * Hout * Wout * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        long p = i / cgs;
+        const int ox = (int)(p % Wout); p /= Wout;
+        const int oy = (int)(p % Hout);
+        const long b = p / Hout;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* sb = src + b * Hin * Win * C + cg * 4;
+        if (mode == 0) {
+            const int f = Hin / Hout;
+            for (int dy = 0; dy < f; ++dy)
+                for (int dx = 0; dx < f; ++dx) {
+                    float v[4];
+                    load4(sb + ((long)(oy * f + dy) * Win + ox * f + dx) * C, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+                }
+            const float inv = 1.f / (float)(f * f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= inv;
+        } else {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bil_coef(oy, Hin, y0, y1, ly);
+            bil_coef(ox, Win, x0, x1, lx);
+            float a[4], bb[4], c[4], d[4];
+            load4(sb + ((long)y0 * Win + x0) * C, a);
+            load4(sb + ((long)y0 * Win + x1) * C, bb);
+            load4(sb + ((long)y1 * Win + x0) * C, c);
+            load4(sb + ((long)y1 * Win + x1) * C, d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[e] = (1.f - ly) * ((1.f - lx) * a[e] + lx * bb[e]) + ly * ((1.f - lx) * c[e] + lx * d[e]);
+        }
+        store4(dst + ((b * Hout + oy) * Wout + ox) * (long)ldd + c_off + cg * 4, acc);
+    }
+}
+
+// backward: dsrc[b, iy, ix, c] = (dres) + sum over the outputs that read this input pixel
+template <typename T>
+__global__ __launch_bounds__(256) void pool_concat_bwd_kernel(const T* __restrict__ dcat, const T* __restrict__ dres,
+                                                              T* __restrict__ dsrc, int B, int Hin, int Win, int C,
+                                                              int Hout, int Wout, int ldd, int c_off, int mode) {
+    const int cgs = C >> 2;
+    const long total = (long)B * Hin * Win * cgs;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int cg = (int)(i % cgs);
+        long p = i / cgs;
+        const int ix = (int)(p % Win); p /= Win;
+        const int iy = (int)(p % Hin);
+        const long b = p / Hin;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* db = dcat + b * Hout * Wout * ldd + c_off + cg * 4;
+        if (mode == 0) {
+            const int f = Hin / Hout;
+            float v[4];
+            load4(db + ((long)(iy / f) * Wout + ix / f) * ldd, v);
+            const float inv = 1.f / (float)(f * f);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = v[e] * inv;
+        } else {
+            for (int oy = max(0, 2 * iy - 2); oy <= min(Hout - 1, 2 * iy + 3); ++oy) {
+                int y0, y1;
+                float ly;
+                bil_coef(oy, Hin, y0, y1, ly);
+                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = max(0, 2 * ix - 2); ox <= min(Wout - 1, 2 * ix + 3); ++ox) {
+                    int x0, x1;
+                    float lx;
+                    bil_coef(ox, Win, x0, x1, lx);
+                    const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                    if (wx == 0.f) continue;
+                    float v[4];
+                    load4(db + ((long)oy * Wout + ox) * ldd, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += wy * wx * v[e];
+                }
+            }
+        }
+        const long off = ((b * Hin + iy) * Win + ix) * (long)C + cg * 4;
+        if (dres) {
+            float r[4];
+            load4(dres + off, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += r[e];
+        }
+        store4(dsrc + off, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-(b,c) spatial reductions:  out[b][c] = scale * sum_hw a[b,hw,c] (* b2[b,hw,c])
+// one workgroup per (b, 64-channel slice); thread = (4 channels, 16 row slots)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const T* __restrict__ a, const T* __restrict__ b2,
+                                                          float* __restrict__ out, int HW, int C, float scale) {
+    __shared__ float red[16][64];
+    const long b = blockIdx.x;
+    const int c0 = blockIdx.y * 64;
+    const int cgs = min(64, C - c0) >> 2;
+    const int cg = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (cg < cgs) {
+        for (int p = slot; p < HW; p += 16) {
+            const long off = (b * HW + p) * C + c0 + cg * 4;
+            float v[4];
+            load4(a + off, v);
+            if (b2) {
+                float w[4];
+                load4(b2 + off, w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= w[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[slot][cg * 4 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < cgs * 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+        out[b * C + c0 + threadIdx.x] = s * scale;
+    }
+}
+
+// SE MLP: gate = sigmoid(W2 relu(W1 s + b1) + b2); one workgroup per sample.  hid saved for backward.
+__global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ s, const float* __restrict__ W1,
+                                                     const float* __restrict__ b1, const float* __restrict__ W2,
+                                                     const float* __restrict__ b2, float* __restrict__ hid,
+                                                     float* __restrict__ gate, int C, int R) {
+    extern __shared__ float sm[];  // s[C], h[R]
+    float* ss = sm;
+    float* hh = sm + C;
+    const long b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) ss[c] = s[b * C + c];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += W1[(long)r * C + c] * ss[c];
+        a = wave_sum(a);
+        if (lane == 0) {
+            a = fmaxf(a + b1[r], 0.f);
+            hh[r] = a;
+            hid[b * R + r] = a;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = b2[c];
+        for (int r = 0; r < R; ++r) a += W2[(long)c * R + r] * hh[r];
+        gate[b * C + c] = 1.f / (1.f + __expf(-a));
+    }
+}
+
+// SE MLP backward: dgate[b][c] -> ds[b][c] (grad of the pooled mean) + parameter gradients (atomics)
+__global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                         const float* __restrict__ hid, const float* __restrict__ s,
+                                                         const float* __restrict__ W1, const float* __restrict__ W2,
+                                                         float* __restrict__ ds, float* __restrict__ dW1,
+                                                         float* __restrict__ db1, float* __restrict__ dW2,
+                                                         float* __restrict__ db2, int C, int R) {
+    extern __shared__ float sm[];  // da[C], hh[R], dh[R], ss[C]
+    float* da = sm;
+    float* hh = sm + C;
+    float* dh = hh + R;
+    float* ss = dh + R;
+    const long b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = gate[b * C + c];
+        da[c] = dgate[b * C + c] * g * (1.f - g);
+        ss[c] = s[b * C + c];
+    }
+    for (int r = threadIdx.x; r < R; r += 256) hh[r] = hid[b * R + r];
+    __syncthreads();
+    // dW2[c][r] += da[c] * h[r]; db2[c] += da[c]
+    for (int i = threadIdx.x; i < C * R; i += 256) {
+        const int c = i / R, r = i - c * R;
+        atomicAdd(dW2 + i, da[c] * hh[r]);
+    }
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(db2 + c, da[c]);
+    // dh[r] = (h[r] > 0) * sum_c W2[c][r] da[c]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += 4) {
+        float a = 0.f;
+        for (int c = lane; c < C; c += 64) a += W2[(long)c * R + r] * da[c];
+        a = wave_sum(a);
+        if (lane == 0) dh[r] = hh[r] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * R; i += 256) {
+        const int r = i / C, c = i - r * C;
+        atomicAdd(dW1 + i, dh[r] * ss[c]);
+    }
+    for (int r = threadIdx.x; r < R; r += 256) atomicAdd(db1 + r, dh[r]);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < R; ++r) a += W1[(long)r * C + c] * dh[r];
+        ds[b * C + c] = a;
+    }
+}
+
+// y[b,hw,c] = x[b,hw,c] * g[b][c] + add[b][c]        (g / add may be NULL), 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ add, T* __restrict__ y, long n8,
+                                                         int HW, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % C);
+        const long b = e / ((long)HW * C);
+        float v[8];
+        load8(x + e, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (g) v[j] *= g[b * C + c + j];
+            if (add) v[j] += add[b * C + c + j];
+        }
+        store8(y + e, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gram pack: G fp32 [B][C][C] -> upper-tri (row-major, i<=j) vector, L2-normalised, written in the grouped/padded
+// layout [B][groups][Kp] that the grouped embedding GEMM reads.  One workgroup per sample.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_ij(int t, int C, int& i, int& j) {
+    // row-major upper-triangular index t -> (i, j>=i); rows before i hold i*C - i*(i-1)/2 entries
+    float fi = ((2.f * C + 1.f) - sqrtf((2.f * C + 1.f) * (2.f * C + 1.f) - 8.f * (float)t)) * 0.5f;
+    i = (int)fi;
+    while (i > 0 && (long)i * C - (long)i * (i - 1) / 2 > t) --i;
+    while ((long)(i + 1) * C - (long)(i + 1) * i / 2 <= t) ++i;
+    j = i + t - (int)((long)i * C - (long)i * (i - 1) / 2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ G, T* __restrict__ out,
+                                                        float* __restrict__ inv_norm, int C, int groups, int Kg,
+                                                        int Kp) {
+    __shared__ float red[4];
+    const long b = blockIdx.x;
+    const int ntri = C * (C + 1) / 2;
+    const float* Gb = G + b * C * C;
+    float ss = 0.f;
+    for (int t = threadIdx.x; t < ntri; t += 256) {
+        int i, j;
+        tri_ij(t, C, i, j);
+        const float v = Gb[i * C + j];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    if (threadIdx.x == 0) inv_norm[b] = inv;
+    T* ob = out + b * groups * Kp;
+    for (int t = threadIdx.x; t < groups * Kp; t += 256) {
+        const int g = t / Kp, k = t - g * Kp;
+        float v = 0.f;
+        if (k < Kg) {
+            int i, j;
+            tri_ij(g * Kg + k, C, i, j);
+            v = Gb[i * C + j] * inv;
+        }
+        elt<T>::st(ob + t, v);
+    }
+}
+
+// backward of normalise + pack: S[b][i][j] (T, symmetric; diagonal doubled) = d(raw gram entry)
+//   draw = inv * (dvec - vhat * <vhat, dvec>)
+template <typename T>
+__global__ __launch_bounds__(256) void gram_pack_bwd_kernel(const T* __restrict__ dvec, const T* __restrict__ vhat,
+                                                            const float* __restrict__ inv_norm, T* __restrict__ S,
+                                                            int C, int groups, int Kg, int Kp) {
+    __shared__ float red[4];
+    const long b = blockIdx.x;
+    const T* db = dvec + b * groups * Kp;
+    const T* vb = vhat + b * groups * Kp;
+    float dot = 0.f;
+    for (int t = threadIdx.x; t < groups * Kp; t += 256) {
+        const int k = t % Kp;
+        if (k < Kg) dot += elt<T>::ld(db + t) * elt<T>::ld(vb + t);
+    }
+    dot = wave_sum(dot);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    dot = red[0] + red[1] + red[2] + red[3];
+    const float inv = inv_norm[b];
+    T* Sb = S + b * C * C;
+    for (int e = threadIdx.x; e < C * C; e += 256) {
+        const int i = e / C, j = e - i * C;
+        const int lo = min(i, j), hi = max(i, j);
+        const int t = (int)((long)lo * C - (long)lo * (lo - 1) / 2) + (hi - lo);
+        const int g = t / Kg, k = t - g * Kg;
+        const float draw = inv * (elt<T>::ld(db + g * Kp + k) - elt<T>::ld(vb + g * Kp + k) * dot);
+        elt<T>::st(Sb + e, i == j ? 2.f * draw : draw);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token concat / split for the class-attention input u = cat(x_cls, tokens)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void token_cat_kernel(const T* __restrict__ cls, const T* __restrict__ tok,
+                                                        T* __restrict__ u, long n8, int N, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % C);
+        const long r = e / C;
+        const int n = (int)(r % (N + 1));
+        const long b = r / (N + 1);
+        const T* src = n == 0 ? cls + b * C + c : tok + (b * N + n - 1) * C + c;
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(u) + e * sizeof(T)) =
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src));
+        if constexpr (sizeof(T) == 4)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(u) + e * 4 + 16) =
+                *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src) + 16);
+    }
+}
+// dcls[b] (+)= du[b,0];  dtok[b,n] (+)= du[b,1+n]
+template <typename T>
+__global__ __launch_bounds__(256) void token_split_kernel(const T* __restrict__ du, T* __restrict__ dcls,
+                                                          T* __restrict__ dtok, long n8, int N, int C, int acc_cls,
+                                                          int acc_tok) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % C);
+        const long r = e / C;
+        const int n = (int)(r % (N + 1));
+        const long b = r / (N + 1);
+        float v[8];
+        load8(du + e, v);
+        T* dst = n == 0 ? dcls + b * C + c : dtok + (b * N + n - 1) * C + c;
+        if (n == 0 ? acc_cls : acc_tok) {
+            float o[8];
+            load8(dst, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        store8(dst, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// class attention, one query per (sample, head).   q [B][E] (T), kv [B*N][2E] (k | v), E = heads*hd
+//   p = softmax_n(scale * q.k_n);  out[b][h*hd+d] = sum_n p_n v[n][h*hd+d];   p saved fp32 [B][heads][N]
+// one workgroup (256 threads = 4 waves) per sample; wave loops over heads
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void class_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                             T* __restrict__ out, float* __restrict__ P, int N,
+                                                             int heads, int hd, float scale) {
+    extern __shared__ float sm[];  // per wave: p[N], q[64]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int E = heads * hd;
+    float* pw = sm + wave * (N + 64);
+    float* qv = pw + N;
+    for (int h = wave; h < heads; h += 4) {
+        if (lane < hd) qv[lane] = elt<T>::ld(q + b * E + h * hd + lane) * scale;
+        float mx = -3.0e38f;
+        for (int n = lane; n < N; n += 64) {
+            const T* kp = kv + (b * N + n) * (long)(2 * E) + h * hd;
+            float s = 0.f;
+            for (int d = 0; d < hd; ++d) s += qv[d] * elt<T>::ld(kp + d);
+            pw[n] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            const float e = __expf(pw[n] - mx);
+            pw[n] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int n = lane; n < N; n += 64) {
+            const float p = pw[n] * inv;
+            pw[n] = p;
+            P[(b * heads + h) * N + n] = p;
+        }
+        // out[d] = sum_n p[n] v[n][d]: lane = d (hd <= 64); a wave's LDS accesses complete in issue order
+        if (lane < hd) {
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a += pw[n] * elt<T>::ld(kv + (b * N + n) * (long)(2 * E) + E + h * hd + lane);
+            elt<T>::st(out + b * E + h * hd + lane, a);
+        }
+    }
+}
+
+// backward: dout [B][E] -> dq [B][E], dkv [B*N][2E]
+template <typename T>
+__global__ __launch_bounds__(256) void class_attn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                             const T* __restrict__ kv, const float* __restrict__ P,
+                                                             T* __restrict__ dq, T* __restrict__ dkv, int N, int heads,
+                                                             int hd, float scale) {
+    extern __shared__ float sm[];  // per wave: ds[N], q[64], dout[64]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int E = heads * hd;
+    float* dsw = sm + wave * (N + 128);
+    float* qv = dsw + N;
+    float* dov = qv + 64;
+    for (int h = wave; h < heads; h += 4) {
+        if (lane < hd) {
+            dov[lane] = elt<T>::ld(dout + b * E + h * hd + lane);
+            qv[lane] = elt<T>::ld(q + b * E + h * hd + lane);
+        }
+        const float* pp = P + (b * heads + h) * N;
+        float dot = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            const T* vp = kv + (b * N + n) * (long)(2 * E) + E + h * hd;
+            float dp = 0.f;
+            for (int d = 0; d < hd; ++d) dp += dov[d] * elt<T>::ld(vp + d);
+            dsw[n] = dp;
+            dot += dp * pp[n];
+        }
+        dot = wave_sum(dot);
+        for (int n = lane; n < N; n += 64) {
+            const float p = pp[n];
+            const float ds = p * (dsw[n] - dot);  // grad wrt the scaled score
+            dsw[n] = ds;
+            T* dk = dkv + (b * N + n) * (long)(2 * E) + h * hd;
+            T* dv = dk + E;
+            for (int d = 0; d < hd; ++d) {
+                elt<T>::st(dk + d, ds * scale * qv[d]);
+                elt<T>::st(dv + d, p * dov[d]);
+            }
+        }
+        if (lane < hd) {
+            float a = 0.f;
+            for (int n = 0; n < N; ++n) a += dsw[n] * elt<T>::ld(kv + (b * N + n) * (long)(2 * E) + h * hd + lane);
+            elt<T>::st(dq + b * E + h * hd + lane, a * scale);
+        }
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, KERNEL, grid, block, lds, s, ...)                                              \
+    do {                                                                                                 \
+        if ((dtype) == GA_BF16) { using T = bf16_t; hipLaunchKernelGGL(KERNEL<T>, grid, block, lds, s, __VA_ARGS__); } \
+        else { using T = float; hipLaunchKernelGGL(KERNEL<T>, grid, block, lds, s, __VA_ARGS__); }          \
+    } while (0)
+
+extern "C" int ga_pool_concat_fwd(const void* src, void* dst, int B, int Hin, int Win, int C, int Hout, int Wout,
+                                  int ldd, int c_off, int mode, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(src && dst && C % 4 == 0 && c_off % 4 == 0 && ldd % 4 == 0, "ga_pool_concat_fwd: alignment");
+    GA_REQUIRE(mode == 0 ? (Hin % Hout == 0 && Win % Wout == 0 && Hin / Hout == Win / Wout)
+                         : (Hout == 2 * Hin && Wout == 2 * Win),
+               "ga_pool_concat_fwd: unsupported geometry %dx%d -> %dx%d mode %d", Hin, Win, Hout, Wout, mode);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)B * Hout * Wout * (C / 4);
+    DISPATCH_T(dtype, pool_concat_kernel, dim3(nblk(total)), dim3(256), 0, s, (const T*)src, (T*)dst, B, Hin, Win, C,
+               Hout, Wout, ldd, c_off, mode);
+    return ga_check_launch("ga_pool_concat_fwd");
+}
+
+extern "C" int ga_pool_concat_bwd(const void* dcat, const void* dres, void* dsrc, int B, int Hin, int Win, int C,
+                                  int Hout, int Wout, int ldd, int c_off, int mode, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dcat && dsrc && C % 4 == 0 && c_off % 4 == 0 && ldd % 4 == 0, "ga_pool_concat_bwd: alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long total = (long)B * Hin * Win * (C / 4);
+    DISPATCH_T(dtype, pool_concat_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, (const T*)dcat, (const T*)dres,
+               (T*)dsrc, B, Hin, Win, C, Hout, Wout, ldd, c_off, mode);
+    return ga_check_launch("ga_pool_concat_bwd");
+}
+
+extern "C" int ga_spatial_sum(const void* a, const void* b2, float* out, int B, int HW, int C, float scale, int dtype,
+                              ga_stream_t stream) {
+    GA_REQUIRE(a && out && C % 4 == 0, "ga_spatial_sum: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, spatial_sum_kernel, dim3(B, cdiv(C, 64)), dim3(256), 0, s, (const T*)a, (const T*)b2, out, HW, C,
+               scale);
+    return ga_check_launch("ga_spatial_sum");
+}
+
+extern "C" int ga_se_mlp_fwd(const float* s, const float* W1, const float* b1, const float* W2, const float* b2,
+                             float* hid, float* gate, int B, int C, int R, ga_stream_t stream) {
+    GA_REQUIRE(s && W1 && b1 && W2 && b2 && hid && gate, "ga_se_mlp_fwd: null");
+    hipLaunchKernelGGL(se_mlp_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                       s, W1, b1, W2, b2, hid, gate, C, R);
+    return ga_check_launch("ga_se_mlp_fwd");
+}
+
+extern "C" int ga_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* s, const float* W1,
+                             const float* W2, float* ds, float* dW1, float* db1, float* dW2, float* db2, int B, int C,
+                             int R, ga_stream_t stream) {
+    GA_REQUIRE(dgate && gate && hid && s && W1 && W2 && ds && dW1 && db1 && dW2 && db2, "ga_se_mlp_bwd: null");
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float),
+                       reinterpret_cast<hipStream_t>(stream), dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2, C, R);
+    return ga_check_launch("ga_se_mlp_bwd");
+}
+
+extern "C" int ga_chan_scale(const void* x, const float* g, const float* add, void* y, int B, int HW, int C, int dtype,
+                             ga_stream_t stream) {
+    GA_REQUIRE(x && y && C % 8 == 0, "ga_chan_scale: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n8 = (long)B * HW * C / 8;
+    DISPATCH_T(dtype, chan_scale_kernel, dim3(nblk(n8)), dim3(256), 0, s, (const T*)x, g, add, (T*)y, n8, HW, C);
+    return ga_check_launch("ga_chan_scale");
+}
+
+extern "C" int ga_gram_pack_fwd(const float* G, void* out, float* inv_norm, int B, int C, int groups, int Kp, int dtype,
+                                ga_stream_t stream) {
+    const int ntri = C * (C + 1) / 2;
+    GA_REQUIRE(G && out && inv_norm && ntri % groups == 0 && Kp >= ntri / groups, "ga_gram_pack_fwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(256), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp);
+    return ga_check_launch("ga_gram_pack_fwd");
+}
+
+extern "C" int ga_gram_pack_bwd(const void* dvec, const void* vhat, const float* inv_norm, void* S, int B, int C,
+                                int groups, int Kp, int dtype, ga_stream_t stream) {
+    const int ntri = C * (C + 1) / 2;
+    GA_REQUIRE(dvec && vhat && inv_norm && S && ntri % groups == 0, "ga_gram_pack_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(256), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
+               groups, ntri / groups, Kp);
+    return ga_check_launch("ga_gram_pack_bwd");
+}
+
+extern "C" int ga_token_cat(const void* cls, const void* tok, void* u, int B, int N, int C, int dtype,
+                            ga_stream_t stream) {
+    GA_REQUIRE(cls && tok && u && C % 8 == 0, "ga_token_cat: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n8 = (long)B * (N + 1) * C / 8;
+    DISPATCH_T(dtype, token_cat_kernel, dim3(nblk(n8)), dim3(256), 0, s, (const T*)cls, (const T*)tok, (T*)u, n8, N, C);
+    return ga_check_launch("ga_token_cat");
+}
+
+extern "C" int ga_token_split(const void* du, void* dcls, void* dtok, int B, int N, int C, int acc_cls, int acc_tok,
+                              int dtype, ga_stream_t stream) {
+    GA_REQUIRE(du && dcls && dtok && C % 8 == 0, "ga_token_split: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long n8 = (long)B * (N + 1) * C / 8;
+    DISPATCH_T(dtype, token_split_kernel, dim3(nblk(n8)), dim3(256), 0, s, (const T*)du, (T*)dcls, (T*)dtok, n8, N, C,
+               acc_cls, acc_tok);
+    return ga_check_launch("ga_token_split");
+}
+
+extern "C" int ga_class_attn_fwd(const void* q, const void* kv, void* out, float* P, int B, int N, int heads, int hd,
+                                 float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(q && kv && out && P && hd >= 1 && hd <= 64 && N >= 1, "ga_class_attn_fwd: bad args (hd<=64)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, class_attn_fwd_kernel, dim3(B), dim3(256), 4 * (N + 64) * sizeof(float), s, (const T*)q,
+               (const T*)kv, (T*)out, P, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_fwd");
+}
+
+extern "C" int ga_class_attn_bwd(const void* dout, const void* q, const void* kv, const float* P, void* dq, void* dkv,
+                                 int B, int N, int heads, int hd, float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dout && q && kv && P && dq && dkv && hd >= 1 && hd <= 64, "ga_class_attn_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, class_attn_bwd_kernel, dim3(B), dim3(256), 4 * (N + 128) * sizeof(float), s, (const T*)dout,
+               (const T*)q, (const T*)kv, P, (T*)dq, (T*)dkv, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_bwd");
+}

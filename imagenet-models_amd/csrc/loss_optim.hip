@@ -1,0 +1,202 @@
+// GA training loss (fused forward + gradient), top-k metric and the flat fused optimizer step (gfx950).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = -3.0e38f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// One workgroup per sample.  logits fp32 [K][B][NC].
+//   loss = sum_k L(out_k, y) + lam * sum_k KL_mean(log_softmax(out_k) || log_softmax(mean_j out_j))   (GA/train.py:735-745)
+//   kind 0: cross entropy with label smoothing `smooth` (mean over B); kind 1: BCE-with-logits on smoothed one-hot
+//   targets (timm BinaryCrossEntropy, mean over B*NC).
+//   dlogits[k][b][c] (T) = d loss / d out_k * gscale     (mean target is detached, as in the reference)
+template <typename T>
+__global__ __launch_bounds__(256) void ga_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                      float* __restrict__ loss, T* __restrict__ dlogits, int K, int B,
+                                                      int NC, float lam, int kind, float smooth, float gscale) {
+    extern __shared__ float sm[];  // mean logits -> r[NC]; red[8]
+    float* r = sm;
+    float* red = sm + NC;
+    const long b = blockIdx.x;
+    const int y = (int)target[b];
+    const float invB = 1.f / (float)B, invBN = 1.f / ((float)B * (float)NC);
+    // r = softmax(mean_k out_k)
+    float mx = -3.0e38f;
+    for (int c = threadIdx.x; c < NC; c += 256) {
+        float m = 0.f;
+        for (int k = 0; k < K; ++k) m += logits[((long)k * B + b) * NC + c];
+        m /= (float)K;
+        r[c] = m;
+        mx = fmaxf(mx, m);
+    }
+    mx = block_max(mx, red);
+    float se = 0.f;
+    for (int c = threadIdx.x; c < NC; c += 256) se += __expf(r[c] - mx);
+    se = block_sum(se, red);
+    const float lse_r = mx + __logf(se);
+    for (int c = threadIdx.x; c < NC; c += 256) r[c] = r[c] - lse_r;  // log r
+    __syncthreads();
+    float total = 0.f;  // this thread's share of the loss
+    for (int k = 0; k < K; ++k) {
+        const float* o = logits + ((long)k * B + b) * NC;
+        float m2 = -3.0e38f;
+        for (int c = threadIdx.x; c < NC; c += 256) m2 = fmaxf(m2, o[c]);
+        m2 = block_max(m2, red);
+        float s2 = 0.f;
+        for (int c = threadIdx.x; c < NC; c += 256) s2 += __expf(o[c] - m2);
+        s2 = block_sum(s2, red);
+        const float lse = m2 + __logf(s2);
+        const float off = smooth / (float)NC, on = 1.f - smooth + off;
+        for (int c = threadIdx.x; c < NC; c += 256) {
+            const float logp = o[c] - lse, p = __expf(logp);
+            const float logr = r[c], rr = __expf(logr);
+            // KL term: exp(target) * (target - input), mean over B*NC
+            total += lam * rr * (logr - logp) * invBN;
+            float g = lam * invBN * (p - rr);
+            const float t = (c == y) ? on : off;
+            if (kind == 0) {
+                total += -t * logp * invB;
+                g += (p - t) * invB;
+            } else {
+                const float x = o[c];
+                // BCE with logits: max(x,0) - x*t + log(1 + exp(-|x|))
+                total += (fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)))) * invBN;
+                g += (1.f / (1.f + __expf(-x)) - t) * invBN;
+            }
+            if (dlogits) elt<T>::st(dlogits + ((long)k * B + b) * NC + c, g * gscale);
+        }
+    }
+    total = block_sum(total, red);
+    if (threadIdx.x == 0) atomicAdd(loss, total);
+}
+
+// sum over heads + top-k (k <= 8) with lowest-index tie-break; one wave per sample.
+__global__ __launch_bounds__(64) void heads_topk_kernel(const float* __restrict__ logits, int K, int B, int NC, int topk,
+                                                        float* __restrict__ out_sum, int64_t* __restrict__ out_idx) {
+    extern __shared__ float sv[];  // [NC]
+    const long b = blockIdx.x;
+    const int lane = threadIdx.x;
+    for (int c = lane; c < NC; c += 64) {
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += logits[((long)k * B + b) * NC + c];
+        sv[c] = s;
+        if (out_sum) out_sum[b * NC + c] = s;
+    }
+    __syncthreads();
+    for (int t = 0; t < topk; ++t) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < NC; c += 64) {
+            const float v = sv[c];
+            if (v > best || (v == best && c < bi)) {
+                best = v;
+                bi = c;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            out_idx[b * topk + t] = bi;
+            sv[bi] = -INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+// hp = {lr, weight_decay, momentum|beta1, beta2, eps, bias_corr1, bias_corr2, first_step}
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, const float* __restrict__ hp, long n,
+                                                  int nesterov, float wd_mult) {
+    const float lr = hp[0], wd = hp[1] * wd_mult, mu = hp[2], first = hp[7];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gi = g[i] + wd * p[i];
+        float bi = first != 0.f ? gi : mu * buf[i] + gi;
+        buf[i] = bi;
+        gi = nesterov ? gi + mu * bi : bi;
+        p[i] -= lr * gi;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ hp, long n, float wd_mult) {
+    const float lr = hp[0], wd = hp[1] * wd_mult, b1 = hp[2], b2 = hp[3], eps = hp[4], bc1 = hp[5], bc2 = hp[6];
+    const float step = lr / bc1, rbc2 = rsqrtf(bc2);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float pi = p[i] * (1.f - lr * wd);
+        p[i] = pi - step * mi / (sqrtf(vi) * rbc2 + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int ga_loss_fwd_bwd(const float* logits, const int64_t* target, float* loss, void* dlogits, int K, int B,
+                               int NC, float lam, int kind, float smoothing, float grad_scale, int dtype,
+                               ga_stream_t stream) {
+    GA_REQUIRE(logits && target && loss && K >= 1 && B >= 1 && NC >= 1 && (kind == 0 || kind == 1), "ga_loss_fwd_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (NC + 8) * sizeof(float);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(ga_loss_kernel<bf16_t>, dim3(B), dim3(256), lds, s, logits, target, loss, (bf16_t*)dlogits, K,
+                           B, NC, lam, kind, smoothing, grad_scale);
+    else
+        hipLaunchKernelGGL(ga_loss_kernel<float>, dim3(B), dim3(256), lds, s, logits, target, loss, (float*)dlogits, K, B,
+                           NC, lam, kind, smoothing, grad_scale);
+    return ga_check_launch("ga_loss_fwd_bwd");
+}
+
+extern "C" int ga_heads_topk(const float* logits, int K, int B, int NC, int topk, float* out_sum, int64_t* out_idx,
+                             ga_stream_t stream) {
+    GA_REQUIRE(logits && out_idx && K >= 1 && topk >= 1 && topk <= NC, "ga_heads_topk: bad args");
+    hipLaunchKernelGGL(heads_topk_kernel, dim3(B), dim3(64), NC * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                       logits, K, B, NC, topk, out_sum, out_idx);
+    return ga_check_launch("ga_heads_topk");
+}
+
+extern "C" int ga_sgd_step(float* p, const float* g, float* buf, const float* hp, int64_t n, int nesterov,
+                           float wd_mult, ga_stream_t stream) {
+    GA_REQUIRE(p && g && buf && hp && n > 0, "ga_sgd_step: bad args");
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
+    hipLaunchKernelGGL(sgd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, buf, hp,
+                       (long)n, nesterov, wd_mult);
+    return ga_check_launch("ga_sgd_step");
+}
+
+extern "C" int ga_adamw_step(float* p, const float* g, float* m, float* v, const float* hp, int64_t n, float wd_mult,
+                             ga_stream_t stream) {
+    GA_REQUIRE(p && g && m && v && hp && n > 0, "ga_adamw_step: bad args");
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, hp,
+                       (long)n, wd_mult);
+    return ga_check_launch("ga_adamw_step");
+}

@@ -1,0 +1,410 @@
+// LayerNorm (rows x C) and BatchNorm (train-mode batch statistics) kernels for gfx950.  All HBM-bound:
+// a row of C channels is spread over G = 4..64 lanes (4 channels per lane per step, 8/16-byte accesses), row
+// reductions are wave shuffles; parameter-gradient column sums are kept in registers by persistent
+// workgroups and reach memory as one fp32 atomic per column per workgroup.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxCh = 4;  // chunks (of 4 channels) per lane
+
+int pick_group(int C) {
+    const int nch = C / 4;
+    for (int g = 4; g <= 64; g <<= 1)
+        if (kMaxCh * g >= nch) return g;
+    return 0;
+}
+
+int grid_blocks(long work_items, int per_block, int max_blocks = 2048) {
+    return (int)std::max<long>(1, std::min<long>(max_blocks, (work_items + per_block - 1) / per_block));
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                     int C, float eps) {
+    const int lg = threadIdx.x % G, rib = threadIdx.x / G, rpb = 256 / G;
+    const int nch = C >> 2;
+    const float invC = 1.f / (float)C;
+    for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
+        float v[kMaxCh][4];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+                load4(x + row * C + ci * 4, v[j]);
+                s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+            } else {
+                v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+            }
+        }
+        const float mu = group_sum<G>(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = v[j][e] - mu;
+                    q += dlt * dlt;
+                }
+            }
+        }
+        const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
+        if (lg == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (v[j][e] - mu) * rs;
+                    if (w) o[e] = o[e] * w[ci * 4 + e] + b[ci * 4 + e];
+                }
+                store4(y + row * C + ci * 4, o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward.  xhat = xnorm ? x : (x - mean) * rstd
+//   dx = rstd * (gw - mean_c(gw) - xhat * mean_c(gw * xhat)) + dres,   gw = g * w
+//   dw[c] += sum_rows g * xhat ;  db[c] += sum_rows g
+// ------------------------------------------------------------------------------------------------
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ w, const T* __restrict__ dres,
+                                                     T* __restrict__ dx, float* __restrict__ dw,
+                                                     float* __restrict__ db, long rows, int C, int xnorm) {
+    extern __shared__ __attribute__((aligned(16))) float red[];  // [2][rpb][C] when dw != null
+    const int lg = threadIdx.x % G, rib = threadIdx.x / G, rpb = 256 / G;
+    const int nch = C >> 2;
+    const float invC = 1.f / (float)C;
+    float aw[kMaxCh][4], ab[kMaxCh][4], wv[kMaxCh][4];
+#pragma unroll
+    for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            aw[j][e] = ab[j][e] = 0.f;
+            const int ci = lg + G * j;
+            wv[j][e] = (w && ci < nch) ? w[ci * 4 + e] : 1.f;
+        }
+    for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
+        const float rs = rstd[row];
+        const float mu = xnorm ? 0.f : mean[row];
+        const float sc = xnorm ? 1.f : rs;
+        float gv[kMaxCh][4], xh[kMaxCh][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+                load4(g + row * C + ci * 4, gv[j]);
+                load4(x + row * C + ci * 4, xh[j]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[j][e] = (xh[j][e] - mu) * sc;
+                    aw[j][e] += gv[j][e] * xh[j][e];
+                    ab[j][e] += gv[j][e];
+                    gv[j][e] *= wv[j][e];
+                    s1 += gv[j][e];
+                    s2 += gv[j][e] * xh[j][e];
+                }
+            }
+        }
+        s1 = group_sum<G>(s1) * invC;
+        s2 = group_sum<G>(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+                float o[4];
+                if (dres) load4(dres + row * C + ci * 4, o);
+                else o[0] = o[1] = o[2] = o[3] = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += rs * (gv[j][e] - s1 - xh[j][e] * s2);
+                store4(dx + row * C + ci * 4, o);
+            }
+        }
+    }
+    if (dw) {  // reduce the per-thread column partials over the rpb row slots of this workgroup
+        float* rw = red;
+        float* rb = red + rpb * C;
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+            if (ci < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    rw[rib * C + ci * 4 + e] = aw[j][e];
+                    rb[rib * C + ci * 4 + e] = ab[j][e];
+                }
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, bb = 0.f;
+            for (int r = 0; r < rpb; ++r) {
+                a += rw[r * C + c];
+                bb += rb[r * C + c];
+            }
+            atomicAdd(dw + c, a);
+            if (db) atomicAdd(db + c, bb);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm: finalize (C threads), affine apply, backward reduce/apply
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float n, const float* w, const float* b,
+                                   float eps, float momentum, float* rmean, float* rvar, float* mean_out,
+                                   float* rstd_out, float* scale, float* shift, int C, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mu, var;
+    if (training) {
+        mu = sum[c] / n;
+        var = fmaxf(sumsq[c] / n - mu * mu, 0.f);
+        if (rmean) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * (n / fmaxf(n - 1.f, 1.f));
+        }
+    } else {
+        mu = rmean[c];
+        var = rvar[c];
+    }
+    const float rs = rsqrtf(var + eps);
+    if (mean_out) mean_out[c] = mu;
+    if (rstd_out) rstd_out[c] = rs;
+    const float a = (w ? w[c] : 1.f) * rs;
+    scale[c] = a;
+    shift[c] = (b ? b[c] : 0.f) - mu * a;
+}
+
+// y = x * scale[c] + shift[c] (+ res) (relu); 8 channels per thread
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res,
+                                                         T* __restrict__ y, long n8, int C, int relu) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % C);
+        float v[8], r[8];
+        load8(x + e, v);
+        if (res) load8(res + e, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j];
+            if (scale) t = t * scale[c + j] + shift[c + j];
+            if (res) t += r[j];
+            if (relu) t = fmaxf(t, 0.f);
+            v[j] = t;
+        }
+        store8(y + e, v);
+    }
+}
+
+// column sums s1[c] += sum g, s2[c] += sum g*xhat with g = dy * (yrelu > 0); persistent workgroups,
+// thread = (4-channel group, row slot); blockIdx.y = 64-channel slice
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ yrelu,
+                                                            const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ s1,
+                                                            float* __restrict__ s2, long rows, int C) {
+    __shared__ float red[2][16][64];
+    const int c0 = blockIdx.y * 64;
+    const int cgs = min(64, C - c0) >> 2;
+    const int cg = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    if (cg < cgs) {
+        float mu[4], rs[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mu[e] = mean[c0 + cg * 4 + e];
+            rs[e] = rstd[c0 + cg * 4 + e];
+        }
+        for (long row = (long)blockIdx.x * 16 + slot; row < rows; row += (long)gridDim.x * 16) {
+            const long off = row * C + c0 + cg * 4;
+            float g[4], xv[4];
+            load4(dy + off, g);
+            load4(x + off, xv);
+            if (yrelu) {
+                float yv[4];
+                load4(yrelu + off, yv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a1[e] += g[e];
+                a2[e] += g[e] * (xv[e] - mu[e]) * rs[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][slot][cg * 4 + e] = a1[e];
+        red[1][slot][cg * 4 + e] = a2[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int which = threadIdx.x >> 6, c = threadIdx.x & 63;
+        if (c < cgs * 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += red[which][r][c];
+            atomicAdd((which ? s2 : s1) + c0 + c, s);
+        }
+    }
+}
+
+// dx = w*rstd * (g - s1/n - xhat * s2/n), g = dy * (yrelu > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ yrelu,
+                                                           const T* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ w,
+                                                           const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           float inv_n, T* __restrict__ dx, long n8, int C) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const int c = (int)(e % C);
+        float g[8], xv[8], yv[8];
+        load8(dy + e, g);
+        load8(x + e, xv);
+        if (yrelu) load8(yrelu + e, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float gg = g[j];
+            if (yrelu && !(yv[j] > 0.f)) gg = 0.f;
+            const float rs = rstd[c + j];
+            const float xh = (xv[j] - mean[c + j]) * rs;
+            g[j] = (w ? w[c + j] : 1.f) * rs * (gg - s1[c + j] * inv_n - xh * s2[c + j] * inv_n);
+        }
+        store8(dx + e, g);
+    }
+}
+
+}  // namespace
+
+#define LN_DISPATCH(G, KERNEL, ...)                                                              \
+    switch (G) {                                                                                 \
+        case 4: hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__); break;                          \
+        case 8: hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__); break;                          \
+        case 16: hipLaunchKernelGGL((KERNEL<T, 16>), __VA_ARGS__); break;                        \
+        case 32: hipLaunchKernelGGL((KERNEL<T, 32>), __VA_ARGS__); break;                        \
+        default: hipLaunchKernelGGL((KERNEL<T, 64>), __VA_ARGS__); break;                        \
+    }
+
+template <typename T>
+static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows,
+                    int C, float eps, hipStream_t s) {
+    const int G = pick_group(C);
+    const int rpb = 256 / G;
+    dim3 grid(grid_blocks(rows, rpb, 4096)), block(256);
+    LN_DISPATCH(G, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
+    return ga_check_launch("ga_layernorm_fwd");
+}
+
+template <typename T>
+static int ln_bwd_t(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
+                    const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int xnorm, hipStream_t s) {
+    const int G = pick_group(C);
+    const int rpb = 256 / G;
+    // persistent when parameter gradients are reduced (bounds the number of atomics)
+    dim3 grid(grid_blocks(rows, rpb, dw ? 1024 : 4096)), block(256);
+    const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
+    LN_DISPATCH(G, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
+                dw, db, (long)rows, C, xnorm);
+    return ga_check_launch("ga_layernorm_bwd");
+}
+
+extern "C" int ga_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                int64_t rows, int C, float eps, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && pick_group(C) > 0, "ga_layernorm_fwd: C=%d unsupported", C);
+    GA_REQUIRE((w == nullptr) == (b == nullptr), "ga_layernorm_fwd: w and b must both be given or both NULL");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? ln_fwd_t<bf16_t>(x, w, b, y, mean, rstd, rows, C, eps, s)
+                            : ln_fwd_t<float>(x, w, b, y, mean, rstd, rows, C, eps, s);
+}
+
+extern "C" int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
+                                const void* dres, void* dx, float* dw, float* db, int64_t rows, int C,
+                                int x_is_normalized, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(g && x && rstd && dx && rows > 0 && C % 4 == 0 && pick_group(C) > 0, "ga_layernorm_bwd: bad args");
+    GA_REQUIRE(x_is_normalized || mean, "ga_layernorm_bwd: mean required");
+    GA_REQUIRE(pick_group(C) >= 8 || !dw || (size_t)2 * 64 * C * 4 <= 65536, "ga_layernorm_bwd: LDS");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? ln_bwd_t<bf16_t>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s)
+                            : ln_bwd_t<float>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s);
+}
+
+extern "C" int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* w, const float* b,
+                              float eps, float momentum, float* running_mean, float* running_var, float* mean_out,
+                              float* rstd_out, float* scale, float* shift, int C, int training, ga_stream_t stream) {
+    GA_REQUIRE(scale && shift && C > 0 && (training ? (sum && sumsq && n > 0) : (running_mean && running_var)),
+               "ga_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), sum,
+                       sumsq, (float)n, w, b, eps, momentum, running_mean, running_var, mean_out, rstd_out, scale, shift,
+                       C, training);
+    return ga_check_launch("ga_bn_finalize");
+}
+
+extern "C" int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y,
+                             int64_t rows, int C, int relu, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)), "ga_affine_act: bad args");
+    const long n8 = rows * C / 8;
+    dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, scale, shift,
+                           (const bf16_t*)res, (bf16_t*)y, n8, C, relu);
+    else
+        hipLaunchKernelGGL(affine_act_kernel<float>, grid, block, 0, s, (const float*)x, scale, shift, (const float*)res,
+                           (float*)y, n8, C, relu);
+    return ga_check_launch("ga_affine_act");
+}
+
+extern "C" int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
+                                float* s1, float* s2, int64_t rows, int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && rows > 0 && C % 4 == 0, "ga_bn_bwd_reduce: bad args");
+    const int slices = cdiv(C, 64);
+    dim3 grid(std::max(1, std::min<int>((int)((rows + 15) / 16), std::max(1, 1024 / slices))), slices), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
+                           (const bf16_t*)x, mean, rstd, s1, s2, (long)rows, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
+                           (const float*)x, mean, rstd, s1, s2, (long)rows, C);
+    return ga_check_launch("ga_bn_bwd_reduce");
+}
+
+extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
+                               const float* w, const float* s1, const float* s2, int64_t n, void* dx, int64_t rows,
+                               int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0, "ga_bn_bwd_apply: bad args");
+    const long n8 = rows * C / 8;
+    dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
+                           (const bf16_t*)x, mean, rstd, w, s1, s2, 1.f / (float)n, (bf16_t*)dx, n8, C);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
+                           (const float*)x, mean, rstd, w, s1, s2, 1.f / (float)n, (float*)dx, n8, C);
+    return ga_check_launch("ga_bn_bwd_apply");
+}

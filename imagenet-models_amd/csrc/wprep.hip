@@ -1,0 +1,307 @@
+// Weight preparation / gradient un-folding and small fp32 utility kernels (gfx950).
+// Per optimizer step the fp32 master weights are re-laid-out once into the "effective" operand copies the
+// GEMMs read (dtype = bf16 or fp32): k-order (ky,kx,ci), LayerNorm scale / LayerScale gamma folded in,
+// transposed copy for the data-gradient product.  The inverse maps the effective-weight gradients back.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ long w_index(int n, int kcol, int Ci, int KH, int KW, int stem, int* ci_out) {
+    const int KK = Ci * KH * KW;
+    if (stem || (KH == 1 && KW == 1)) {
+        *ci_out = stem ? kcol / (KH * KW) : kcol;
+        return (long)n * KK + kcol;
+    }
+    const int tap = kcol / Ci, ci = kcol - tap * Ci;
+    *ci_out = ci;
+    return ((long)n * Ci + ci) * (KH * KW) + tap;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wprep_out_kernel(const float* __restrict__ w, const float* __restrict__ rs,
+                                                        const float* __restrict__ cs, T* __restrict__ out, long ldo,
+                                                        int rows, int Ci, int KH, int KW, int stem) {
+    const int KK = Ci * KH * KW;
+    const long total = (long)rows * ldo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / ldo), kcol = (int)(i - (long)n * ldo);
+        float v = 0.f;
+        if (kcol < KK) {
+            int ci;
+            v = w[w_index(n, kcol, Ci, KH, KW, stem, &ci)];
+            if (rs) v *= rs[n];
+            if (cs) v *= cs[ci];
+        }
+        elt<T>::st(out + i, v);
+    }
+}
+
+// outT: non-flip [G][KK][ldt] (co contiguous); flip [G][Ci][ldt] with column ((KH-1-ky)*KW + KW-1-kx)*Co + co
+template <typename T>
+__global__ __launch_bounds__(256) void wprep_outT_kernel(const float* __restrict__ w, const float* __restrict__ rs,
+                                                         const float* __restrict__ cs, T* __restrict__ outT, long ldt,
+                                                         int G, int Co, int Ci, int KH, int KW, int stem, int flip) {
+    const int KK = Ci * KH * KW;
+    const int trows = flip ? Ci : KK;
+    const long total = (long)G * trows * ldt;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % ldt);
+        const long t = i / ldt;
+        const int r = (int)(t % trows), g = (int)(t / trows);
+        float v = 0.f;
+        if (!flip) {
+            if (col < Co) {
+                const int n = g * Co + col;
+                int ci;
+                v = w[w_index(n, r, Ci, KH, KW, stem, &ci)];
+                if (rs) v *= rs[n];
+                if (cs) v *= cs[ci];
+            }
+        } else {
+            if (col < KH * KW * Co) {
+                const int tapf = col / Co, co = col - tapf * Co;
+                const int tap = KH * KW - 1 - tapf;  // (KH-1-ky, KW-1-kx) <-> flipped linear tap index
+                const int n = g * Co + co;
+                v = w[((long)n * Ci + r) * (KH * KW) + tap];
+                if (rs) v *= rs[n];
+                if (cs) v *= cs[r];
+            }
+        }
+        elt<T>::st(outT + i, v);
+    }
+}
+
+// be[n] = rs[n] * (b[n] + sum_c W[n][c] v[c]); one wave per n
+__global__ __launch_bounds__(256) void bias_fold_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                        const float* __restrict__ rs, const float* __restrict__ v,
+                                                        float* __restrict__ be, int N, int C) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float s = 0.f;
+    if (v)
+        for (int c = lane; c < C; c += 64) s += W[(long)n * C + c] * v[c];
+    s = wave_sum(s);
+    if (lane == 0) be[n] = (rs ? rs[n] : 1.f) * ((b ? b[n] : 0.f) + s);
+}
+
+// dW[orig layout] += rs[n] * G[n][kcol] * cs[ci]
+__global__ __launch_bounds__(256) void unfold_dw_kernel(const float* __restrict__ G, long ldg,
+                                                        const float* __restrict__ rs, const float* __restrict__ cs,
+                                                        const float* __restrict__ gb, const float* __restrict__ v,
+                                                        float* __restrict__ dW, int N, int Ci, int KH, int KW, int stem) {
+    const int KK = Ci * KH * KW;
+    const long total = (long)N * KK;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / KK), kcol = (int)(i - (long)n * KK);
+        int ci;
+        const long wi = w_index(n, kcol, Ci, KH, KW, stem, &ci);
+        float val = G[(long)n * ldg + kcol];
+        if (cs) val *= cs[ci];
+        if (gb && v) val += gb[n] * v[ci];   // bias-fold path: be[n] = rs[n] * (b[n] + sum_c W[n][c] v[c])
+        if (rs) val *= rs[n];
+        dW[wi] += val;
+    }
+}
+
+// per-row: d_rs[n] += sum_k G*W*cs + gb[n]*b[n];  db[n] += rs[n]*gb[n]      (one wave per n)
+__global__ __launch_bounds__(256) void unfold_rows_kernel(const float* __restrict__ G, long ldg,
+                                                          const float* __restrict__ gb, const float* __restrict__ W,
+                                                          const float* __restrict__ b, const float* __restrict__ rs,
+                                                          const float* __restrict__ cs, const float* __restrict__ v,
+                                                          float* __restrict__ d_rs, float* __restrict__ db, int N,
+                                                          int Ci, int KH, int KW, int stem) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    const int KK = Ci * KH * KW;
+    if (d_rs) {
+        float s = 0.f;
+        for (int k = lane; k < KK; k += 64) {
+            int ci;
+            const long wi = w_index(n, k, Ci, KH, KW, stem, &ci);
+            s += G[(long)n * ldg + k] * W[wi] * (cs ? cs[ci] : 1.f);
+            if (gb && v) s += gb[n] * W[wi] * v[ci];
+        }
+        s = wave_sum(s);
+        if (lane == 0) d_rs[n] += s + ((gb && b) ? gb[n] * b[n] : 0.f);
+    }
+    if (db && gb && lane == 0) db[n] += (rs ? rs[n] : 1.f) * gb[n];
+}
+
+// per-column (KH=KW=1): d_cs[c] += sum_n rs[n] G[n][c] W[n][c];  d_v[c] += sum_n gb[n] rs[n] W[n][c]
+// grid (C/64, N/64): 64 columns x 4 row lanes per workgroup, 16 rows per thread, fp32 atomics
+__global__ __launch_bounds__(256) void unfold_cols_kernel(const float* __restrict__ G, long ldg,
+                                                          const float* __restrict__ gb, const float* __restrict__ W,
+                                                          const float* __restrict__ rs, float* __restrict__ d_cs,
+                                                          float* __restrict__ d_v, int N, int C) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    float a = 0.f, bsum = 0.f;
+    if (c < C) {
+        for (int i = 0; i < 16; ++i) {
+            const int n = blockIdx.y * 64 + rl * 16 + i;
+            if (n < N) {
+                const float wv = W[(long)n * C + c] * (rs ? rs[n] : 1.f);
+                a += G[(long)n * ldg + c] * wv;
+                if (gb) bsum += gb[n] * wv;
+            }
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = a;
+    red[1][rl][threadIdx.x & 63] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 64 && c < C) {
+        const float s0 = red[0][0][threadIdx.x] + red[0][1][threadIdx.x] + red[0][2][threadIdx.x] + red[0][3][threadIdx.x];
+        const float s1 = red[1][0][threadIdx.x] + red[1][1][threadIdx.x] + red[1][2][threadIdx.x] + red[1][3][threadIdx.x];
+        if (d_cs) atomicAdd(d_cs + c, s0);
+        if (d_v) atomicAdd(d_v + c, s1);
+    }
+}
+
+// out[c][r] (+)= in[r][c]   (fp32; dwconv weight [C][49] <-> [49][C])
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int R, int C, int accumulate) {
+    const long total = (long)R * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i / R), r = (int)(i - (long)c * R);  // out index i = c*R + r
+        const float v = in[(long)r * C + c];
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, const float* __restrict__ x, float a,
+                                                       long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+
+// y[row][:] = x[row][:] * s[row / rows_per_scale]   (DropPath mask on a gradient), 8 elements per thread
+template <typename T>
+__global__ __launch_bounds__(256) void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                       T* __restrict__ y, long n8, long elems_per_scale) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const long e = i * 8;
+        const float sc = s[e / elems_per_scale];
+        float v[8];
+        load8(x + e, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= sc;
+        store8(y + e, v);
+    }
+}
+
+// dst (T) = cast(src fp32), contiguous
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) elt<T>::st(dst + i, src[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void uncast_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = elt<T>::ld(src + i);
+}
+
+int nblocks(long n, int cap = 4096) { return (int)std::max<long>(1, std::min<long>(cap, (n + 255) / 256)); }
+
+}  // namespace
+
+extern "C" int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream) {
+    GA_REQUIRE(d && d->w && d->G >= 1 && d->Co >= 1 && d->Ci >= 1 && d->KH >= 1 && d->KW >= 1, "ga_weight_prep: bad args");
+    GA_REQUIRE(!(d->cs && d->G > 1), "ga_weight_prep: column scale with groups unsupported");
+    GA_REQUIRE(!(d->flip && d->stem), "ga_weight_prep: flip+stem unsupported");
+    const int KK = d->Ci * d->KH * d->KW;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->out) {
+        GA_REQUIRE(d->ldo >= KK, "ga_weight_prep: ldo < K");
+        const long total = (long)d->G * d->Co * d->ldo;
+        if (d->dtype == GA_BF16)
+            hipLaunchKernelGGL(wprep_out_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
+                               (bf16_t*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
+        else
+            hipLaunchKernelGGL(wprep_out_kernel<float>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
+                               (float*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
+    }
+    if (d->outT) {
+        GA_REQUIRE(d->ldt >= (d->flip ? d->KH * d->KW * d->Co : d->Co), "ga_weight_prep: ldt too small");
+        const long total = (long)d->G * (d->flip ? d->Ci : KK) * d->ldt;
+        if (d->dtype == GA_BF16)
+            hipLaunchKernelGGL(wprep_outT_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
+                               (bf16_t*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
+        else
+            hipLaunchKernelGGL(wprep_outT_kernel<float>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
+                               (float*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
+    }
+    return ga_check_launch("ga_weight_prep");
+}
+
+extern "C" int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, float* be, int N, int C,
+                            ga_stream_t stream) {
+    GA_REQUIRE(be && N > 0 && (!v || W), "ga_bias_fold: bad args");
+    hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, b, rs,
+                       v, be, N, C);
+    return ga_check_launch("ga_bias_fold");
+}
+
+extern "C" int ga_weight_unfold(const ga_wunfold_desc* d, ga_stream_t stream) {
+    GA_REQUIRE(d && d->G && d->N > 0 && d->Ci > 0, "ga_weight_unfold: bad args");
+    GA_REQUIRE(!((d->d_cs || d->d_v || d->v) && (d->KH != 1 || d->KW != 1)),
+               "ga_weight_unfold: column grads / bias-fold vector need a 1x1 kernel");
+    GA_REQUIRE(!((d->d_rs || d->d_cs || d->d_v) && !d->W), "ga_weight_unfold: W required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int KK = d->Ci * d->KH * d->KW;
+    if (d->dW)
+        hipLaunchKernelGGL(unfold_dw_kernel, dim3(nblocks((long)d->N * KK)), dim3(256), 0, s, d->G, (long)d->ldg, d->rs,
+                           d->cs, d->gb, d->v, d->dW, d->N, d->Ci, d->KH, d->KW, d->stem);
+    if (d->d_rs || (d->db && d->gb))
+        hipLaunchKernelGGL(unfold_rows_kernel, dim3(cdiv(d->N, 4)), dim3(256), 0, s, d->G, (long)d->ldg, d->gb, d->W,
+                           d->b, d->rs, d->cs, d->v, d->d_rs, d->db, d->N, d->Ci, d->KH, d->KW, d->stem);
+    if (d->d_cs || d->d_v)
+        hipLaunchKernelGGL(unfold_cols_kernel, dim3(cdiv(d->Ci, 64), cdiv(d->N, 64)), dim3(256), 0, s, d->G,
+                           (long)d->ldg, d->gb, d->W, d->rs, d->d_cs, d->d_v, d->N, d->Ci);
+    return ga_check_launch("ga_weight_unfold");
+}
+
+extern "C" int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream) {
+    GA_REQUIRE(in && out && R > 0 && C > 0, "ga_transpose_f32: bad args");
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3(nblocks((long)R * C)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), in, out, R, C, accumulate);
+    return ga_check_launch("ga_transpose_f32");
+}
+
+extern "C" int ga_axpy_f32(float* y, const float* x, float a, int64_t n, ga_stream_t stream) {
+    GA_REQUIRE(y && x && n > 0, "ga_axpy_f32: bad args");
+    hipLaunchKernelGGL(axpy_f32_kernel, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x, a,
+                       (long)n);
+    return ga_check_launch("ga_axpy_f32");
+}
+
+extern "C" int ga_rowscale(const void* x, const float* s, void* y, int64_t n, int64_t elems_per_scale, int dtype,
+                           ga_stream_t stream) {
+    GA_REQUIRE(x && s && y && n > 0 && n % 8 == 0 && elems_per_scale % 8 == 0, "ga_rowscale: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(rowscale_kernel<bf16_t>, dim3(nblocks(n / 8, 8192)), dim3(256), 0, st, (const bf16_t*)x, s,
+                           (bf16_t*)y, (long)(n / 8), (long)elems_per_scale);
+    else
+        hipLaunchKernelGGL(rowscale_kernel<float>, dim3(nblocks(n / 8, 8192)), dim3(256), 0, st, (const float*)x, s,
+                           (float*)y, (long)(n / 8), (long)elems_per_scale);
+    return ga_check_launch("ga_rowscale");
+}
+
+extern "C" int ga_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(src && dst && n > 0, "ga_cast_from_f32: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, src, (bf16_t*)dst, (long)n);
+    else
+        hipLaunchKernelGGL(cast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, src, (float*)dst, (long)n);
+    return ga_check_launch("ga_cast_from_f32");
+}
+
+extern "C" int ga_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(src && dst && n > 0, "ga_cast_to_f32: bad args");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(uncast_kernel<bf16_t>, dim3(nblocks(n)), dim3(256), 0, st, (const bf16_t*)src, dst, (long)n);
+    else
+        hipLaunchKernelGGL(uncast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (const float*)src, dst, (long)n);
+    return ga_check_launch("ga_cast_to_f32");
+}

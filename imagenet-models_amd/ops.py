@@ -1,0 +1,276 @@
+"""Launch plans over the libgaext C ABI.
+
+A `Plan` is a pre-resolved list of C-ABI calls (ctypes function + fully built argument tuple) over persistent
+device buffers.  The engine builds the forward / backward / optimizer plans ONCE per (batch size, mode) and then
+replays them on a HIP stream every step: no per-step descriptor construction, no allocation, no host sync --
+the MI355X-native replacement for the reference's eager ATen dispatch (and directly capturable in a hipGraph).
+Every method records one call; `run()` enqueues them all.  `Plan(eager=True)` also executes each call as it is
+recorded (used by the unit tests).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (A_CONV3, A_PATCH2, A_PLAIN, A_STEM4_NCHW, ACT_GELU, ACT_NONE, ACT_RELU, C_PLAIN, C_UNPATCH2,  # noqa: F401
+                   GA_BF16, GA_F32)
+
+
+def ga_dtype(t):
+    if isinstance(t, torch.dtype):
+        dt = t
+    else:
+        dt = t.dtype
+    if dt == torch.bfloat16:
+        return GA_BF16
+    if dt == torch.float32:
+        return GA_F32
+    raise TypeError(f'unsupported dtype {dt}')
+
+
+def torch_dtype(ga):
+    return torch.bfloat16 if ga == GA_BF16 else torch.float32
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    assert t.is_cuda, 'libgaext operands must live in device memory (no CPU fallback)'
+    return t.data_ptr()
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Plan:
+    def __init__(self, eager=False, name=''):
+        self.lib = L.load()
+        self.calls = []      # (cfunc, args tuple, label)
+        self.keep = []       # tensors / descriptors kept alive
+        self.eager = eager
+        self.name = name
+
+    # -- core ---------------------------------------------------------------------------------------
+    def _add(self, fname, args, label=None, keep=()):
+        fn = getattr(self.lib, fname)
+        self.calls.append((fn, args, label or fname))
+        self.keep.extend(keep)
+        if self.eager:
+            L.check(fn(*args, current_stream_ptr()), label or fname)
+
+    def run(self, stream=None):
+        s = current_stream_ptr() if stream is None else stream
+        for fn, args, label in self.calls:
+            rc = fn(*args, s)
+            if rc != 0:
+                L.check(rc, f'{self.name}:{label}')
+
+    def __len__(self):
+        return len(self.calls)
+
+    # -- GEMM family --------------------------------------------------------------------------------
+    def gemm(self, A, B, Cout, M, N, K, dtype, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, strideC=0,
+             a_batch_mod=0, a_kind=A_PLAIN, a_dims=(0, 0, 0), a_act=ACT_NONE, c_kind=C_PLAIN, c_dims=(0, 0, 0),
+             c_f32=False, alpha=1.0, bias=None, strideBias=0, act=ACT_NONE, H=None, ldh=0, strideH=0, rowscale=None,
+             rows_per_scale=1, R=None, ldr=0, strideR=0, relu_after=False, colsum=None, colsumsq=None, strideCol=0,
+             label=None):
+        d = L.GemmDesc()
+        d.M, d.N, d.K, d.batch, d.dtype = M, N, K, batch, dtype
+        d.A, d.lda, d.strideA, d.a_batch_mod, d.a_kind = _ptr(A), (K if lda is None else lda), strideA, a_batch_mod, a_kind
+        d.a_H, d.a_W, d.a_C = a_dims
+        d.a_act = a_act
+        d.B, d.ldb, d.strideB = _ptr(B), (K if ldb is None else ldb), strideB
+        d.C, d.ldc, d.strideC, d.c_kind = _ptr(Cout), (N if ldc is None else ldc), strideC, c_kind
+        d.c_H, d.c_W, d.c_C = c_dims
+        d.c_f32 = int(c_f32)
+        d.alpha = alpha
+        d.bias, d.strideBias, d.act = _ptr(bias), strideBias, act
+        d.H, d.ldh, d.strideH = _ptr(H), ldh, strideH
+        d.rowscale, d.rows_per_scale = _ptr(rowscale), rows_per_scale
+        d.R, d.ldr, d.strideR, d.relu_after = _ptr(R), ldr, strideR, int(relu_after)
+        d.colsum, d.colsumsq, d.strideCol = _ptr(colsum), _ptr(colsumsq), strideCol
+        self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq))
+
+    def wgrad(self, Y, X, dW, M, N, K, dtype, ldy=None, ldx=None, ldw=None, batch=1, strideY=0, strideX=0, strideW=0,
+              x_kind=A_PLAIN, x_dims=(0, 0, 0), x_act=ACT_NONE, dbias=None, strideDbias=0, alpha=1.0, split_m=None,
+              accumulate=True, label=None):
+        d = L.WgradDesc()
+        d.M, d.N, d.K, d.batch, d.dtype = M, N, K, batch, dtype
+        d.Y, d.ldy, d.strideY = _ptr(Y), (N if ldy is None else ldy), strideY
+        d.X, d.ldx, d.strideX, d.x_kind = _ptr(X), (K if ldx is None else ldx), strideX, x_kind
+        d.x_H, d.x_W, d.x_C = x_dims
+        d.x_act = x_act
+        d.dW, d.ldw, d.strideW = _ptr(dW), (K if ldw is None else ldw), strideW
+        d.dbias, d.strideDbias = _ptr(dbias), strideDbias
+        d.alpha = alpha
+        if split_m is None:
+            split_m = pick_split_m(M, N, K, batch, dtype)
+        d.split_m, d.accumulate = split_m, int(accumulate)
+        self._add('ga_wgrad', (C.byref(d),), label, keep=(d, Y, X, dW, dbias))
+
+    def weight_prep(self, w, G, Co, Ci, KH, KW, dtype, out=None, ldo=0, outT=None, ldt=0, rs=None, cs=None, flip=False,
+                    stem=False, label=None):
+        d = L.WprepDesc()
+        d.w, d.G, d.Co, d.Ci, d.KH, d.KW = _ptr(w), G, Co, Ci, KH, KW
+        d.rs, d.cs, d.dtype = _ptr(rs), _ptr(cs), dtype
+        d.out, d.ldo, d.outT, d.ldt, d.flip, d.stem = _ptr(out), ldo, _ptr(outT), ldt, int(flip), int(stem)
+        self._add('ga_weight_prep', (C.byref(d),), label, keep=(d, w, out, outT, rs, cs))
+
+    def bias_fold(self, W, b, rs, v, be, N, Cdim, label=None):
+        self._add('ga_bias_fold', (_ptr(W), _ptr(b), _ptr(rs), _ptr(v), _ptr(be), N, Cdim), label, keep=(W, b, rs, v, be))
+
+    def weight_unfold(self, G, ldg, N, Ci, KH=1, KW=1, gb=None, W=None, b=None, rs=None, cs=None, v=None, stem=False, dW=None,
+                      db=None, d_rs=None, d_cs=None, d_v=None, label=None):
+        d = L.WunfoldDesc()
+        d.G, d.ldg, d.gb, d.W, d.b, d.rs, d.cs, d.v = _ptr(G), ldg, _ptr(gb), _ptr(W), _ptr(b), _ptr(rs), _ptr(cs), _ptr(v)
+        d.N, d.Ci, d.KH, d.KW, d.stem = N, Ci, KH, KW, int(stem)
+        d.dW, d.db, d.d_rs, d.d_cs, d.d_v = _ptr(dW), _ptr(db), _ptr(d_rs), _ptr(d_cs), _ptr(d_v)
+        self._add('ga_weight_unfold', (C.byref(d),), label, keep=(d, G, gb, W, b, rs, cs, v, dW, db, d_rs, d_cs, d_v))
+
+    # -- depthwise conv / norms ---------------------------------------------------------------------
+    def dwconv7_fwd(self, x, w49, bias, y, B, H, W, Cdim, dtype, label=None):
+        self._add('ga_dwconv7_fwd', (_ptr(x), _ptr(w49), _ptr(bias), _ptr(y), B, H, W, Cdim, dtype), label,
+                  keep=(x, w49, bias, y))
+
+    def dwconv7_bwd_data(self, dy, w49, res, dx, B, H, W, Cdim, dtype, label=None):
+        self._add('ga_dwconv7_bwd_data', (_ptr(dy), _ptr(w49), _ptr(res), _ptr(dx), B, H, W, Cdim, dtype), label,
+                  keep=(dy, w49, res, dx))
+
+    def dwconv7_bwd_weight(self, dy, x, dw49, dbias, B, H, W, Cdim, dtype, label=None):
+        self._add('ga_dwconv7_bwd_weight', (_ptr(dy), _ptr(x), _ptr(dw49), _ptr(dbias), B, H, W, Cdim, dtype), label,
+                  keep=(dy, x, dw49, dbias))
+
+    def layernorm_fwd(self, x, w, b, y, mean, rstd, rows, Cdim, eps, dtype, label=None):
+        self._add('ga_layernorm_fwd', (_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, Cdim, eps, dtype),
+                  label, keep=(x, w, b, y, mean, rstd))
+
+    def layernorm_bwd(self, g, x, mean, rstd, w, dres, dx, dw, db, rows, Cdim, x_is_normalized, dtype, label=None):
+        self._add('ga_layernorm_bwd', (_ptr(g), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dres), _ptr(dx), _ptr(dw),
+                                       _ptr(db), rows, Cdim, int(x_is_normalized), dtype), label,
+                  keep=(g, x, mean, rstd, w, dres, dx, dw, db))
+
+    def bn_finalize(self, ssum, ssq, n, w, b, eps, momentum, rmean, rvar, mean_out, rstd_out, scale, shift, Cdim,
+                    training, label=None):
+        self._add('ga_bn_finalize', (_ptr(ssum), _ptr(ssq), n, _ptr(w), _ptr(b), eps, momentum, _ptr(rmean), _ptr(rvar),
+                                     _ptr(mean_out), _ptr(rstd_out), _ptr(scale), _ptr(shift), Cdim, int(training)),
+                  label, keep=(ssum, ssq, w, b, rmean, rvar, mean_out, rstd_out, scale, shift))
+
+    def affine_act(self, x, scale, shift, res, y, rows, Cdim, relu, dtype, label=None):
+        self._add('ga_affine_act', (_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y), rows, Cdim, int(relu), dtype),
+                  label, keep=(x, scale, shift, res, y))
+
+    def bn_bwd_reduce(self, dy, y_relu, x, mean, rstd, s1, s2, rows, Cdim, dtype, label=None):
+        self._add('ga_bn_bwd_reduce', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2), rows,
+                                       Cdim, dtype), label, keep=(dy, y_relu, x, mean, rstd, s1, s2))
+
+    def bn_bwd_apply(self, dy, y_relu, x, mean, rstd, w, s1, s2, n, dx, rows, Cdim, dtype, label=None):
+        self._add('ga_bn_bwd_apply', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(s1), _ptr(s2),
+                                      n, _ptr(dx), rows, Cdim, dtype), label,
+                  keep=(dy, y_relu, x, mean, rstd, w, s1, s2, dx))
+
+    # -- head ---------------------------------------------------------------------------------------
+    def pool_concat_fwd(self, src, dst, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, mode, dtype, label=None):
+        self._add('ga_pool_concat_fwd', (_ptr(src), _ptr(dst), B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, mode, dtype),
+                  label, keep=(src, dst))
+
+    def pool_concat_bwd(self, dcat, dres, dsrc, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, mode, dtype, label=None):
+        self._add('ga_pool_concat_bwd', (_ptr(dcat), _ptr(dres), _ptr(dsrc), B, Hin, Win, Cdim, Hout, Wout, ldd, c_off,
+                                         mode, dtype), label, keep=(dcat, dres, dsrc))
+
+    def spatial_sum(self, a, b2, out, B, HW, Cdim, scale, dtype, label=None):
+        self._add('ga_spatial_sum', (_ptr(a), _ptr(b2), _ptr(out), B, HW, Cdim, scale, dtype), label, keep=(a, b2, out))
+
+    def se_mlp_fwd(self, s, W1, b1, W2, b2, hid, gate, B, Cdim, R, label=None):
+        self._add('ga_se_mlp_fwd', (_ptr(s), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(hid), _ptr(gate), B, Cdim, R),
+                  label, keep=(s, W1, b1, W2, b2, hid, gate))
+
+    def se_mlp_bwd(self, dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2, B, Cdim, R, label=None):
+        self._add('ga_se_mlp_bwd', (_ptr(dgate), _ptr(gate), _ptr(hid), _ptr(s), _ptr(W1), _ptr(W2), _ptr(ds), _ptr(dW1),
+                                    _ptr(db1), _ptr(dW2), _ptr(db2), B, Cdim, R), label,
+                  keep=(dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2))
+
+    def chan_scale(self, x, g, add, y, B, HW, Cdim, dtype, label=None):
+        self._add('ga_chan_scale', (_ptr(x), _ptr(g), _ptr(add), _ptr(y), B, HW, Cdim, dtype), label, keep=(x, g, add, y))
+
+    def gram_pack_fwd(self, G, out, inv_norm, B, Cdim, groups, Kp, dtype, label=None):
+        self._add('ga_gram_pack_fwd', (_ptr(G), _ptr(out), _ptr(inv_norm), B, Cdim, groups, Kp, dtype), label,
+                  keep=(G, out, inv_norm))
+
+    def gram_pack_bwd(self, dvec, vhat, inv_norm, S, B, Cdim, groups, Kp, dtype, label=None):
+        self._add('ga_gram_pack_bwd', (_ptr(dvec), _ptr(vhat), _ptr(inv_norm), _ptr(S), B, Cdim, groups, Kp, dtype), label,
+                  keep=(dvec, vhat, inv_norm, S))
+
+    def token_cat(self, cls, tok, u, B, N, Cdim, dtype, label=None):
+        self._add('ga_token_cat', (_ptr(cls), _ptr(tok), _ptr(u), B, N, Cdim, dtype), label, keep=(cls, tok, u))
+
+    def token_split(self, du, dcls, dtok, B, N, Cdim, acc_cls, acc_tok, dtype, label=None):
+        self._add('ga_token_split', (_ptr(du), _ptr(dcls), _ptr(dtok), B, N, Cdim, int(acc_cls), int(acc_tok), dtype),
+                  label, keep=(du, dcls, dtok))
+
+    def class_attn_fwd(self, q, kv, out, P, B, N, heads, hd, scale, dtype, label=None):
+        self._add('ga_class_attn_fwd', (_ptr(q), _ptr(kv), _ptr(out), _ptr(P), B, N, heads, hd, scale, dtype), label,
+                  keep=(q, kv, out, P))
+
+    def class_attn_bwd(self, dout, q, kv, P, dq, dkv, B, N, heads, hd, scale, dtype, label=None):
+        self._add('ga_class_attn_bwd', (_ptr(dout), _ptr(q), _ptr(kv), _ptr(P), _ptr(dq), _ptr(dkv), B, N, heads, hd,
+                                        scale, dtype), label, keep=(dout, q, kv, P, dq, dkv))
+
+    # -- loss / metric / optimizer ------------------------------------------------------------------
+    def loss_fwd_bwd(self, logits, target, loss, dlogits, K, B, NC, lam, kind, smoothing, grad_scale, dtype, label=None):
+        self._add('ga_loss_fwd_bwd', (_ptr(logits), _ptr(target), _ptr(loss), _ptr(dlogits), K, B, NC, lam, kind,
+                                      smoothing, grad_scale, dtype), label, keep=(logits, target, loss, dlogits))
+
+    def heads_topk(self, logits, K, B, NC, topk, out_sum, out_idx, label=None):
+        self._add('ga_heads_topk', (_ptr(logits), K, B, NC, topk, _ptr(out_sum), _ptr(out_idx)), label,
+                  keep=(logits, out_sum, out_idx))
+
+    def sgd_step(self, p, g, buf, hp, n, nesterov, wd_mult, label=None):
+        self._add('ga_sgd_step', (_ptr(p), _ptr(g), _ptr(buf), _ptr(hp), n, int(nesterov), wd_mult), label,
+                  keep=(p, g, buf, hp))
+
+    def adamw_step(self, p, g, m, v, hp, n, wd_mult, label=None):
+        self._add('ga_adamw_step', (_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hp), n, wd_mult), label,
+                  keep=(p, g, m, v, hp))
+
+    # -- utilities ----------------------------------------------------------------------------------
+    def transpose_f32(self, src, dst, R, Cdim, accumulate=False, label=None):
+        self._add('ga_transpose_f32', (_ptr(src), _ptr(dst), R, Cdim, int(accumulate)), label, keep=(src, dst))
+
+    def axpy_f32(self, y, x, a, n, label=None):
+        self._add('ga_axpy_f32', (_ptr(y), _ptr(x), a, n), label, keep=(y, x))
+
+    def rowscale(self, x, s, y, n, elems_per_scale, dtype, label=None):
+        self._add('ga_rowscale', (_ptr(x), _ptr(s), _ptr(y), n, elems_per_scale, dtype), label, keep=(x, s, y))
+
+    def cast_from_f32(self, src, dst, n, dtype, label=None):
+        self._add('ga_cast_from_f32', (_ptr(src), _ptr(dst), n, dtype), label, keep=(src, dst))
+
+    def cast_to_f32(self, src, dst, n, dtype, label=None):
+        self._add('ga_cast_to_f32', (_ptr(src), _ptr(dst), n, dtype), label, keep=(src, dst))
+
+    def zero(self, t, label=None):
+        """memset a persistent buffer (hipMemsetAsync on the plan's stream)."""
+        self._add('ga_memset', (_ptr(t), 0, t.numel() * t.element_size()), label or 'zero', keep=(t,))
+
+
+_NUM_CU = None
+
+
+def num_cus():
+    global _NUM_CU
+    if _NUM_CU is None:
+        n = C.c_int(256)
+        L.check(L.load().ga_device_info(C.byref(n), None, None), 'ga_device_info')
+        _NUM_CU = n.value
+    return _NUM_CU
+
+
+def pick_split_m(M, N, K, batch, dtype):
+    """Number of row-range splits of a wgrad so that ~2 workgroups per CU are in flight, each with >= 4 slabs."""
+    slab = 64 if dtype == GA_BF16 else 32
+    tiles = ((N + 127) // 128) * ((K + 127) // 128) * batch
+    want = max(1, (2 * 256) // tiles)
+    return int(max(1, min(want, (M + 4 * slab - 1) // (4 * slab))))

@@ -1,0 +1,287 @@
+/* libgaext -- C ABI of the MI355X (gfx950) kernels for the GA-ConvNeXt / GA / MAP training hot path.
+ *
+ * The reference (Lab-LVM/imagenet-models) has NO native layer: its hot path is the list of ATen ops that
+ * GA/ga_convnext.py, GA/train.py execute.  Each entry point below replaces the ATen
+ * op(s) named in its comment (file:line = /root/reference/...).  Conventions:
+ *
+ *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (the library never
+ *    allocates, frees or synchronises); every call only ENQUEUES work on the hipStream_t passed last.
+ *  - activations are NHWC ("channels last"), i.e. 2-D row-major [rows = B*H*W, C]; `dtype` selects the
+ *    element type of activations and of the prepared ("effective") weight copies: GA_F32 = the parity math
+ *    mode, GA_BF16 = the throughput mode (fp32 accumulation, fp32 statistics, fp32 master weights/gradients).
+ *  - return 0 on success; <0 on error (GA_ERR_*), message retrievable with ga_last_error (thread-local).
+ *  - 16-byte alignment of every activation / weight-copy pointer and leading dimensions that are multiples of
+ *    8 elements are required (GA_ERR_BAD_ARG otherwise).
+ */
+#ifndef GAEXT_H
+#define GAEXT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ga_stream_t; /* hipStream_t */
+
+enum { GA_F32 = 0, GA_BF16 = 1 };
+enum { GA_OK = 0, GA_ERR_BAD_ARG = -1, GA_ERR_UNSUPPORTED = -2, GA_ERR_HIP = -3 };
+
+/* activation codes */
+enum { GA_ACT_NONE = 0, GA_ACT_GELU = 1, GA_ACT_RELU = 2 };
+
+/* A-operand gather kinds (implicit im2col): how row m / column k of the GEMM's A matrix map to memory */
+enum {
+    GA_A_PLAIN = 0,      /* A[m*lda + k]                                                              */
+    GA_A_PATCH2 = 1,     /* NHWC [B,H,W,C] -> rows (b,oy,ox) of the 2x2/s2 patches, k = (ky,kx,c)    (ga_convnext.py:127) */
+    GA_A_STEM4_NCHW = 2, /* fp32 NCHW [B,3,H,W] -> rows (b,oy,ox) of the 4x4/s4 patches, k=(c,ky,kx) (ga_convnext.py:357) */
+    GA_A_CONV3 = 3       /* NHWC [B,H,W,C], 3x3 pad 1 stride 1, k = (ky,kx,c)                         (ga_convnext.py:273) */
+};
+/* C-output kinds */
+enum {
+    GA_C_PLAIN = 0,
+    GA_C_UNPATCH2 = 1 /* rows (b,oy,ox), cols (ky,kx,c) scattered back to NHWC [B,H,W,C] (dgrad of the 2x2/s2 conv) */
+};
+
+int ga_version(void);
+/* copies the calling thread's last error message (NUL-terminated) into buf; returns its length */
+int ga_last_error(char* buf, size_t n);
+/* number of compute units / LDS per CU etc. of the current device (used for grid sizing); 0 on success */
+int ga_device_info(int* num_cu, int* lds_bytes, int* wave_size);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ga_gemm:  C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] )          (both operands K-contiguous)
+ * replaces: nn.Linear / 1x1, 2x2-s2, 4x4-s4 and 3x3 nn.Conv2d forward AND their data-gradients
+ *           (ga_convnext.py:94,127,163-167,202-205,259-283,357,407,418,422) -- dgrad uses the transposed
+ *           weight copy made by ga_weight_prep, so it is the same NT product.
+ * epilogue order: v = alpha*acc; v += bias[n]; v = act(v); v *= dact(H[m][n]) (GELU'); v *= rowscale[m / rows_per_scale];
+ *                 v += R[m][n]; if (relu_after) v = max(v,0); colsum[n] += v; colsumsq[n] += v*v; store.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    int batch;             /* grid z (>=1) */
+    int dtype;             /* GA_F32 / GA_BF16: type of A, B, R, H (and of C unless c_f32) */
+    /* A */
+    const void* A;
+    int64_t lda, strideA;
+    int a_batch_mod;       /* A batch index = z % a_batch_mod (0: = z) */
+    int a_kind;            /* GA_A_* */
+    int a_H, a_W, a_C;     /* input dims for the gather kinds */
+    int a_act;             /* GA_ACT_*: applied to A elements while staging (GELU of a stored pre-activation) */
+    /* B (weights, [N][K] K-contiguous) */
+    const void* B;
+    int64_t ldb, strideB;
+    /* C */
+    void* C;
+    int64_t ldc, strideC;
+    int c_kind;            /* GA_C_* */
+    int c_H, c_W, c_C;     /* NHWC dims of the scatter target (GA_C_UNPATCH2) */
+    int c_f32;             /* 1: C is fp32 regardless of dtype */
+    /* epilogue */
+    float alpha;
+    const float* bias;     /* [N] or NULL */
+    int64_t strideBias;
+    int act;               /* GA_ACT_* */
+    const void* H;         /* GELU-backward: multiply by gelu'(H[m][n]) (dtype), or NULL */
+    int64_t ldh, strideH;
+    const float* rowscale; /* per-sample scale (DropPath mask / keep) or NULL */
+    int rows_per_scale;
+    const void* R;         /* residual (dtype) or NULL */
+    int64_t ldr, strideR;
+    int relu_after;
+    float* colsum;         /* [N] fp32 atomics, or NULL  (BatchNorm batch statistics / bias gradients) */
+    float* colsumsq;       /* [N] fp32 atomics, or NULL */
+    int64_t strideCol;
+} ga_gemm_desc;
+int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * ga_wgrad:  dW[z][n][k] (+)= alpha * sum_m Y[z][m][n] * X[z][m][k]              (reduction over the ROW index)
+ * replaces: the weight-gradient of every Linear/Conv2d above (ATen convolution_backward / mm in autograd) and,
+ *           with Y == X, the Gram product X.X^T of GA_ConvNeXt.get_gram (ga_convnext.py:459-460).
+ * The M range is split over `split_m` workgroups that combine with fp32 atomics (split_m == 1: plain store when
+ * accumulate == 0).  dbias[n] += sum_m Y[m][n] when dbias != NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int M, N, K;
+    int batch;
+    int dtype;
+    const void* Y;
+    int64_t ldy, strideY;
+    const void* X;
+    int64_t ldx, strideX;
+    int x_kind;            /* GA_A_* gather of X rows */
+    int x_H, x_W, x_C;
+    int x_act;             /* GA_ACT_GELU: X := gelu(X) while staging */
+    float* dW;             /* fp32 [N][ldw] */
+    int64_t ldw, strideW;
+    float* dbias;          /* fp32 [N] or NULL */
+    int64_t strideDbias;
+    float alpha;
+    int split_m;           /* >=1 */
+    int accumulate;        /* 1: add into dW (atomics); 0 with split_m==1: overwrite */
+} ga_wgrad_desc;
+int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Weight preparation: fp32 master conv/linear weight [G*Co][Ci][KH][KW]  ->  "effective" copies in `dtype`
+ *   out [G][Co][ldo]  with k = (ky,kx,ci)   : out = rs[n] * w * cs[ci]          (B operand of the forward GEMM)
+ *   outT[G][KH*KW*Ci][ldt] (co contiguous)  : transposed copy                   (B operand of the dgrad GEMM);
+ *        flip=1: outT is [G][Ci][ldt >= KH*KW*Co] with column ((KH-1-ky)*KW + KW-1-kx)*Co + co
+ *        (dgrad of a stride-1 'same' conv as a GA_A_CONV3 product over dY).
+ *   stem=1: k = (ci,ky,kx) (the NCHW patch order of GA_A_STEM4_NCHW).
+ * Folds LayerNorm scale (cs) / LayerScale gamma (rs) into the weights (ga_convnext.py:93,95,106,110).
+ * Pads [.., ldo) / [.., ldt) with zeros.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* w;
+    int G, Co, Ci, KH, KW;
+    const float* rs;       /* [G*Co] or NULL */
+    const float* cs;       /* [Ci] or NULL */
+    int dtype;
+    void* out;  int64_t ldo;   /* may be NULL */
+    void* outT; int64_t ldt;   /* may be NULL */
+    int flip;
+    int stem;
+} ga_wprep_desc;
+int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream);
+/* be[n] = rs[n] * (b[n] + sum_c W[n][c] * v[c])   (W fp32 [N][C]; b, rs, v may be NULL) */
+int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, float* be, int N, int C,
+                 ga_stream_t stream);
+/* Inverse of the folding for gradients. G = d(effective weight) fp32 [N][ldg] with k=(ky,kx,ci); gb = d(effective bias),
+ * where We = rs[n]*W*cs[ci] and be[n] = rs[n]*(b[n] + sum_c W[n][c]*v[c]):
+ *   dW[n][ci][ky][kx] += rs[n]*(G*cs[ci] + gb[n]*v[ci]);  d_cs[ci] += sum rs[n]*G*W;
+ *   d_rs[n] += sum_k G*W*cs[ci] + gb[n]*(b[n] + sum_c W*v);  d_v[ci] += sum_n gb[n]*rs[n]*W[n][ci];  db[n] += rs[n]*gb[n].
+ * cs / v / d_cs / d_v need KH=KW=1.  Any output may be NULL. */
+typedef struct {
+    const float* G; int64_t ldg;
+    const float* gb;
+    const float* W; const float* b;
+    const float* rs; const float* cs; const float* v;
+    int N, Ci, KH, KW;
+    int stem;
+    float* dW; float* db; float* d_rs; float* d_cs; float* d_v;
+} ga_wunfold_desc;
+int ga_weight_unfold(const ga_wunfold_desc* d, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Depthwise 7x7 (pad 3) convolution, NHWC  (ga_convnext.py:92,100)
+ *   w49: fp32 [49][C] (tap-major copy of conv_dw.weight), bias fp32 [C]
+ * ------------------------------------------------------------------------------------------------------------ */
+int ga_dwconv7_fwd(const void* x, const float* w49, const float* bias, void* y, int B, int H, int W, int C,
+                   int dtype, ga_stream_t stream);
+/* dx = res + conv7x7(dy, flipped w)   (res may be NULL) */
+int ga_dwconv7_bwd_data(const void* dy, const float* w49, const void* res, void* dx, int B, int H, int W, int C,
+                        int dtype, ga_stream_t stream);
+/* dw49[49][C] += sum dy * shifted x ; dbias[C] += sum dy   (fp32 atomics) */
+int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
+                          int dtype, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim of [rows][C]  (F.layer_norm / LayerNorm2d, ga_convnext.py:51-67,93,233,237)
+ *   fwd: y = (x-mean)*rstd [*w + b];  saves mean/rstd fp32 [rows] (each may be NULL).
+ *   bwd: xhat = x_is_normalized ? x : (x-mean)*rstd;
+ *        dx = rstd * (g*w - mean_c(g*w) - xhat*mean_c(g*w*xhat)) (+ dres);  dw[c] += sum g*xhat; db[c] += sum g
+ * ------------------------------------------------------------------------------------------------------------ */
+int ga_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows,
+                     int C, float eps, int dtype, ga_stream_t stream);
+int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
+                     const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int x_is_normalized,
+                     int dtype, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BatchNorm2d, train mode = per-process batch statistics (ga_convnext.py:261,270,276,283,409,420).
+ * The column sums come from ga_gemm's colsum/colsumsq epilogue.
+ *   finalize: mean/var (biased) -> scale = w*rstd, shift = b - mean*scale; running stats updated with the unbiased
+ *             variance and `momentum`; training=0 builds scale/shift from the running stats instead.
+ *   affine_act: y = x*scale[c] + shift[c] (+ res) (ReLU)             (scale/shift NULL: y = x + res)
+ *   bwd_reduce: s1[c] += sum g, s2[c] += sum g*xhat, g = dy * (y_relu > 0 if given)
+ *   bwd_apply:  dx = w*rstd*(g - s1/n - xhat*s2/n)
+ * ------------------------------------------------------------------------------------------------------------ */
+int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* w, const float* b, float eps,
+                   float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
+                   float* scale, float* shift, int C, int training, ga_stream_t stream);
+int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows, int C,
+                  int relu, int dtype, ga_stream_t stream);
+int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd, float* s1,
+                     float* s2, int64_t rows, int C, int dtype, ga_stream_t stream);
+int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
+                    const float* w, const float* s1, const float* s2, int64_t n, void* dx, int64_t rows, int C,
+                    int dtype, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-scale aggregate (ga_convnext.py:396-397,479-483): write pool(src) into channels [c_off, c_off+C) of the
+ * concat buffer dst[B,Hout,Wout,ldd].  mode 0: f x f average (AdaptiveAvgPool2d to 14; f=1 is a copy);
+ * mode 1: bilinear x2, align_corners=False (nn.Upsample).   bwd: dsrc = (dres +) pool^T(dcat slice).
+ * ------------------------------------------------------------------------------------------------------------ */
+int ga_pool_concat_fwd(const void* src, void* dst, int B, int Hin, int Win, int C, int Hout, int Wout, int ldd,
+                       int c_off, int mode, int dtype, ga_stream_t stream);
+int ga_pool_concat_bwd(const void* dcat, const void* dres, void* dsrc, int B, int Hin, int Win, int C, int Hout,
+                       int Wout, int ldd, int c_off, int mode, int dtype, ga_stream_t stream);
+
+/* Squeeze-excite (timm SEModule via create_attn('se'), ga_convnext.py:279,305):
+ *   ga_spatial_sum: out[b][c] = scale * sum_hw a[b,hw,c] (* b2[b,hw,c] if given)      (fp32 [B][C])
+ *   ga_se_mlp_fwd:  gate = sigmoid(W2 relu(W1 s + b1) + b2)  (W1 [R][C], W2 [C][R], fp32 master weights)
+ *   ga_se_mlp_bwd:  ds = d(pooled mean), parameter gradients accumulated with atomics
+ *   ga_chan_scale:  y[b,hw,c] = x*g[b][c] + add[b][c]   (g/add may be NULL) */
+int ga_spatial_sum(const void* a, const void* b2, float* out, int B, int HW, int C, float scale, int dtype,
+                   ga_stream_t stream);
+int ga_se_mlp_fwd(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, float* hid,
+                  float* gate, int B, int C, int R, ga_stream_t stream);
+int ga_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* s, const float* W1,
+                  const float* W2, float* ds, float* dW1, float* db1, float* dW2, float* db2, int B, int C, int R,
+                  ga_stream_t stream);
+int ga_chan_scale(const void* x, const float* g, const float* add, void* y, int B, int HW, int C, int dtype,
+                  ga_stream_t stream);
+
+/* Gram vector (GA_ConvNeXt.get_gram, ga_convnext.py:452-467; index order :424-430): the fp32 Gram matrices
+ * G[B][C][C] (from ga_wgrad with Y == X) -> row-major upper-triangular entries, L2-normalised (eps 1e-12), stored in
+ * the grouped layout [B][groups][Kp] (Kp >= ntri/groups, zero padded) read by the grouped embedding GEMM.
+ * bwd: S[B][C][C] = symmetric gradient of the raw Gram entries (diagonal doubled) so that dX = alpha * X . S */
+int ga_gram_pack_fwd(const float* G, void* out, float* inv_norm, int B, int C, int groups, int Kp, int dtype,
+                     ga_stream_t stream);
+int ga_gram_pack_bwd(const void* dvec, const void* vhat, const float* inv_norm, void* S, int B, int C, int groups,
+                     int Kp, int dtype, ga_stream_t stream);
+
+/* Class attention with ONE query token (ClassAttn / LayerScaleBlockClassAttn, ga_convnext.py:153-187,244-248):
+ *   token_cat: u[B][N+1][C] = cat(cls[B][C], tok[B][N][C]);  token_split: dcls (+)= du[:,0], dtok (+)= du[:,1:]
+ *   class_attn: q [B][E], kv [B*(N)][2E] (k | v), E = heads*hd <= 64 per head; P fp32 [B][heads][N] saved. */
+int ga_token_cat(const void* cls, const void* tok, void* u, int B, int N, int C, int dtype, ga_stream_t stream);
+int ga_token_split(const void* du, void* dcls, void* dtok, int B, int N, int C, int acc_cls, int acc_tok, int dtype,
+                   ga_stream_t stream);
+int ga_class_attn_fwd(const void* q, const void* kv, void* out, float* P, int B, int N, int heads, int hd, float scale,
+                      int dtype, ga_stream_t stream);
+int ga_class_attn_bwd(const void* dout, const void* q, const void* kv, const float* P, void* dq, void* dkv, int B, int N,
+                      int heads, int hd, float scale, int dtype, ga_stream_t stream);
+
+/* GA training loss, fused forward + gradient (GA/train.py:735-745):
+ *   loss += sum_k L(out_k, y) + lam * sum_k KL_mean(log_softmax(out_k) || log_softmax(mean_j out_j))  (mean detached)
+ *   kind 0: (label-smoothed) cross entropy; kind 1: timm BinaryCrossEntropy on smoothed one-hot targets.
+ *   logits fp32 [K][B][NC]; target int64 [B]; *loss must be zeroed by the caller; dlogits (dtype) = grad * grad_scale */
+int ga_loss_fwd_bwd(const float* logits, const int64_t* target, float* loss, void* dlogits, int K, int B, int NC,
+                    float lam, int kind, float smoothing, float grad_scale, int dtype, ga_stream_t stream);
+/* validate(): output = sum_k out_k.float(); top-k indices, ties -> lowest index  (GA/train.py:848-860) */
+int ga_heads_topk(const float* logits, int K, int B, int NC, int topk, float* out_sum, int64_t* out_idx,
+                  ga_stream_t stream);
+
+/* Flat fused optimizer steps over fp32 [n] (train.py:769; torch.optim.SGD(nesterov) / torch.optim.AdamW semantics).
+ * hp (device, fp32[8]) = {lr, weight_decay, momentum|beta1, beta2, eps, 1-beta1^t, 1-beta2^t, first_step};
+ * wd_mult = 0 for the no-decay segment (timm: ndim<=1 or *.bias). */
+int ga_sgd_step(float* p, const float* g, float* buf, const float* hp, int64_t n, int nesterov, float wd_mult,
+                ga_stream_t stream);
+int ga_adamw_step(float* p, const float* g, float* m, float* v, const float* hp, int64_t n, float wd_mult,
+                  ga_stream_t stream);
+
+/* small fp32 / elementwise utilities */
+int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
+int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
+int ga_axpy_f32(float* y, const float* x, float a, int64_t n, ga_stream_t stream);
+int ga_rowscale(const void* x, const float* s, void* y, int64_t n, int64_t elems_per_scale, int dtype,
+                ga_stream_t stream);
+int ga_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, ga_stream_t stream);
+int ga_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, ga_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAEXT_H */
