@@ -36,7 +36,7 @@ class WgradDesc(C.Structure):
     _fields_ = [
         ('M', i32), ('N', i32), ('K', i32), ('batch', i32), ('dtype', i32),
         ('Y', vp), ('ldy', i64), ('strideY', i64),
-        ('X', vp), ('ldx', i64), ('strideX', i64), ('x_kind', i32),
+        ('X', vp), ('ldx', i64), ('strideX', i64), ('x_batch_mod', i32), ('x_kind', i32),
         ('x_H', i32), ('x_W', i32), ('x_C', i32), ('x_act', i32),
         ('dW', vp), ('ldw', i64), ('strideW', i64),
         ('dbias', vp), ('strideDbias', i64),
@@ -47,14 +47,14 @@ class WgradDesc(C.Structure):
 class WprepDesc(C.Structure):
     _fields_ = [
         ('w', vp), ('G', i32), ('Co', i32), ('Ci', i32), ('KH', i32), ('KW', i32),
-        ('rs', vp), ('cs', vp), ('dtype', i32),
+        ('rs', vp), ('cs', vp), ('row_perm', vp), ('dtype', i32),
         ('out', vp), ('ldo', i64), ('outT', vp), ('ldt', i64), ('flip', i32), ('stem', i32),
     ]
 
 
 class WunfoldDesc(C.Structure):
     _fields_ = [
-        ('G', vp), ('ldg', i64), ('gb', vp), ('W', vp), ('b', vp), ('rs', vp), ('cs', vp), ('v', vp),
+        ('G', vp), ('ldg', i64), ('gb', vp), ('W', vp), ('b', vp), ('rs', vp), ('cs', vp), ('v', vp), ('row_perm', vp),
         ('N', i32), ('Ci', i32), ('KH', i32), ('KW', i32), ('stem', i32),
         ('dW', vp), ('db', vp), ('d_rs', vp), ('d_cs', vp), ('d_v', vp),
     ]
@@ -67,7 +67,7 @@ _SIGS = {
     'ga_gemm': ([C.POINTER(GemmDesc), vp], i32),
     'ga_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ga_weight_prep': ([C.POINTER(WprepDesc), vp], i32),
-    'ga_bias_fold': ([vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    'ga_bias_fold': ([vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
     'ga_weight_unfold': ([C.POINTER(WunfoldDesc), vp], i32),
     'ga_dwconv7_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_dwconv7_bwd_data': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
@@ -75,14 +75,14 @@ _SIGS = {
     'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     'ga_bn_finalize': ([vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
-    'ga_affine_act': ([vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
-    'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),
-    'ga_bn_bwd_apply': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, vp], i32),
+    'ga_affine_act': ([vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp], i32),
+    'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp], i32),
+    'ga_bn_bwd_apply': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp], i32),
     'ga_pool_concat_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_pool_concat_bwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_spatial_sum': ([vp, vp, vp, i32, i32, i32, f32, i32, vp], i32),
     'ga_se_mlp_fwd': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
-    'ga_se_mlp_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    'ga_se_mlp_bwd': ([vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp], i32),
     'ga_chan_scale': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     'ga_gram_pack_fwd': ([vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_gram_pack_bwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),

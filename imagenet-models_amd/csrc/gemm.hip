@@ -434,8 +434,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
     if (s_begin >= s_end) return;
 
     const T* Yb = reinterpret_cast<const T*>(d.Y) + z * d.strideY;
+    const int zx = d.x_batch_mod > 0 ? z % d.x_batch_mod : z;
     const unsigned char* Xb = reinterpret_cast<const unsigned char*>(d.X) +
-                              (d.x_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * z * d.strideX;
+                              (d.x_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * zx * d.strideX;
 
     const int cc = tid % P::CPR, rr = tid / P::CPR;  // chunk column, first row
     const int ny = n0 + cc * EPC;                    // Y column of this thread's chunks
@@ -641,9 +642,10 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
     GA_REQUIRE(aligned16(d->Y) && aligned16(d->X), "ga_wgrad: operands must be 16-byte aligned");
     GA_REQUIRE(d->N % epc == 0 && d->ldy % epc == 0 && d->strideY % epc == 0, "ga_wgrad: N/ldy must be multiples of %d",
                epc);
-    GA_REQUIRE(d->K % epc == 0, "ga_wgrad: K must be a multiple of %d", epc);
     if (d->x_kind == GA_A_PLAIN) {
-        GA_REQUIRE(d->ldx % epc == 0 && d->strideX % epc == 0, "ga_wgrad: ldx must be a multiple of %d", epc);
+        // K (an OUTPUT dim here) may be ragged as long as the X rows are padded to a chunk multiple
+        GA_REQUIRE(d->ldx % epc == 0 && d->strideX % epc == 0 && d->ldx >= (d->K + epc - 1) / epc * epc,
+                   "ga_wgrad: ldx must be a multiple of %d and cover K rounded up", epc);
     } else if (d->x_kind == GA_A_PATCH2) {
         GA_REQUIRE(d->x_C % epc == 0 && d->K == 4 * d->x_C, "ga_wgrad: PATCH2 needs K==4C");
     } else if (d->x_kind == GA_A_CONV3) {

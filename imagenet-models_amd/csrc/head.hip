@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void se_mlp_kernel(const float* __restrict__ s
 __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
                                                          const float* __restrict__ hid, const float* __restrict__ s,
                                                          const float* __restrict__ W1, const float* __restrict__ W2,
-                                                         float* __restrict__ ds, float* __restrict__ dW1,
+                                                         float* __restrict__ ds, float ds_scale, float* __restrict__ dW1,
                                                          float* __restrict__ db1, float* __restrict__ dW2,
                                                          float* __restrict__ db2, int C, int R) {
     extern __shared__ float sm[];  // da[C], hh[R], dh[R], ss[C]
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void se_mlp_bwd_kernel(const float* __restrict
     for (int c = threadIdx.x; c < C; c += 256) {
         float a = 0.f;
         for (int r = 0; r < R; ++r) a += W1[(long)r * C + c] * dh[r];
-        ds[b * C + c] = a;
+        ds[b * C + c] = a * ds_scale;
     }
 }
 
@@ -522,11 +522,12 @@ extern "C" int ga_se_mlp_fwd(const float* s, const float* W1, const float* b1, c
 }
 
 extern "C" int ga_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* s, const float* W1,
-                             const float* W2, float* ds, float* dW1, float* db1, float* dW2, float* db2, int B, int C,
-                             int R, ga_stream_t stream) {
+                             const float* W2, float* ds, float ds_scale, float* dW1, float* db1, float* dW2, float* db2,
+                             int B, int C, int R, ga_stream_t stream) {
     GA_REQUIRE(dgate && gate && hid && s && W1 && W2 && ds && dW1 && db1 && dW2 && db2, "ga_se_mlp_bwd: null");
     hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(B), dim3(256), (2 * C + 2 * R) * sizeof(float),
-                       reinterpret_cast<hipStream_t>(stream), dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2, C, R);
+                       reinterpret_cast<hipStream_t>(stream), dgate, gate, hid, s, W1, W2, ds, ds_scale, dW1, db1, dW2, db2, C,
+                       R);
     return ga_check_launch("ga_se_mlp_bwd");
 }
 

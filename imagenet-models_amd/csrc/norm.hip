@@ -199,10 +199,12 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float n
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res,
+                                                         const float* __restrict__ rowscale, long elems_per_scale,
                                                          T* __restrict__ y, long n8, int C, int relu) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const long e = i * 8;
         const int c = (int)(e % C);
+        const float rsc = rowscale ? rowscale[e / elems_per_scale] : 1.f;
         float v[8], r[8];
         load8(x + e, v);
         if (res) load8(res + e, r);
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
         for (int j = 0; j < 8; ++j) {
             float t = v[j];
             if (scale) t = t * scale[c + j] + shift[c + j];
+            t *= rsc;
             if (res) t += r[j];
             if (relu) t = fmaxf(t, 0.f);
             v[j] = t;
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ yrelu,
                                                             const T* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ s1,
+                                                            const float* __restrict__ rstd, const float* __restrict__ rowscale,
+                                                            long rows_per_scale, float* __restrict__ s1,
                                                             float* __restrict__ s2, long rows, int C) {
     __shared__ float red[2][16][64];
     const int c0 = blockIdx.y * 64;
@@ -247,6 +251,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 load4(yrelu + off, yv);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            }
+            if (rowscale) {
+                const float rsc = rowscale[row / rows_per_scale];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] *= rsc;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -278,17 +287,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ x, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const float* __restrict__ w,
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
+                                                           const float* __restrict__ rowscale, long elems_per_scale,
                                                            float inv_n, T* __restrict__ dx, long n8, int C) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
         const long e = i * 8;
         const int c = (int)(e % C);
+        const float rsc = rowscale ? rowscale[e / elems_per_scale] : 1.f;
         float g[8], xv[8], yv[8];
         load8(dy + e, g);
         load8(x + e, xv);
         if (yrelu) load8(yrelu + e, yv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float gg = g[j];
+            float gg = g[j] * rsc;
             if (yrelu && !(yv[j] > 0.f)) gg = 0.f;
             const float rs = rstd[c + j];
             const float xh = (xv[j] - mean[c + j]) * rs;
@@ -346,7 +357,6 @@ extern "C" int ga_layernorm_bwd(const void* g, const void* x, const float* mean,
                                 int x_is_normalized, int dtype, ga_stream_t stream) {
     GA_REQUIRE(g && x && rstd && dx && rows > 0 && C % 4 == 0 && pick_group(C) > 0, "ga_layernorm_bwd: bad args");
     GA_REQUIRE(x_is_normalized || mean, "ga_layernorm_bwd: mean required");
-    GA_REQUIRE(pick_group(C) >= 8 || !dw || (size_t)2 * 64 * C * 4 <= 65536, "ga_layernorm_bwd: LDS");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == GA_BF16 ? ln_bwd_t<bf16_t>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s)
                             : ln_bwd_t<float>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s);
@@ -363,48 +373,53 @@ extern "C" int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, c
     return ga_check_launch("ga_bn_finalize");
 }
 
-extern "C" int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y,
-                             int64_t rows, int C, int relu, int dtype, ga_stream_t stream) {
+extern "C" int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res,
+                             const float* rowscale, int64_t rows_per_scale, void* y, int64_t rows, int C, int relu,
+                             int dtype, ga_stream_t stream) {
     GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)), "ga_affine_act: bad args");
     const long n8 = rows * C / 8;
     dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)res, (bf16_t*)y, n8, C, relu);
+                           (const bf16_t*)res, rowscale, (long)rows_per_scale * C, (bf16_t*)y, n8, C, relu);
     else
         hipLaunchKernelGGL(affine_act_kernel<float>, grid, block, 0, s, (const float*)x, scale, shift, (const float*)res,
-                           (float*)y, n8, C, relu);
+                           rowscale, (long)rows_per_scale * C, (float*)y, n8, C, relu);
     return ga_check_launch("ga_affine_act");
 }
 
 extern "C" int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
-                                float* s1, float* s2, int64_t rows, int C, int dtype, ga_stream_t stream) {
+                                const float* rowscale, int64_t rows_per_scale, float* s1, float* s2, int64_t rows, int C,
+                                int dtype, ga_stream_t stream) {
     GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && rows > 0 && C % 4 == 0, "ga_bn_bwd_reduce: bad args");
     const int slices = cdiv(C, 64);
     dim3 grid(std::max(1, std::min<int>((int)((rows + 15) / 16), std::max(1, 1024 / slices))), slices), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
-                           (const bf16_t*)x, mean, rstd, s1, s2, (long)rows, C);
+                           (const bf16_t*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
-                           (const float*)x, mean, rstd, s1, s2, (long)rows, C);
+                           (const float*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C);
     return ga_check_launch("ga_bn_bwd_reduce");
 }
 
 extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
-                               const float* w, const float* s1, const float* s2, int64_t n, void* dx, int64_t rows,
-                               int C, int dtype, ga_stream_t stream) {
+                               const float* w, const float* s1, const float* s2, const float* rowscale,
+                               int64_t rows_per_scale, int64_t n, void* dx, int64_t rows, int C, int dtype,
+                               ga_stream_t stream) {
     GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0, "ga_bn_bwd_apply: bad args");
     const long n8 = rows * C / 8;
     dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
-                           (const bf16_t*)x, mean, rstd, w, s1, s2, 1.f / (float)n, (bf16_t*)dx, n8, C);
+                           (const bf16_t*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
+                           (bf16_t*)dx, n8, C);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
-                           (const float*)x, mean, rstd, w, s1, s2, 1.f / (float)n, (float*)dx, n8, C);
+                           (const float*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
+                           (float*)dx, n8, C);
     return ga_check_launch("ga_bn_bwd_apply");
 }

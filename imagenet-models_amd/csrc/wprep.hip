@@ -20,12 +20,14 @@ __device__ __forceinline__ long w_index(int n, int kcol, int Ci, int KH, int KW,
 
 template <typename T>
 __global__ __launch_bounds__(256) void wprep_out_kernel(const float* __restrict__ w, const float* __restrict__ rs,
-                                                        const float* __restrict__ cs, T* __restrict__ out, long ldo,
-                                                        int rows, int Ci, int KH, int KW, int stem) {
+                                                        const float* __restrict__ cs, const int* __restrict__ perm,
+                                                        T* __restrict__ out, long ldo, int rows, int Ci, int KH, int KW,
+                                                        int stem) {
     const int KK = Ci * KH * KW;
     const long total = (long)rows * ldo;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int n = (int)(i / ldo), kcol = (int)(i - (long)n * ldo);
+        const int no = (int)(i / ldo), kcol = (int)(i - (long)no * ldo);
+        const int n = perm ? perm[no] : no;   // source row
         float v = 0.f;
         if (kcol < KK) {
             int ci;
@@ -40,8 +42,9 @@ __global__ __launch_bounds__(256) void wprep_out_kernel(const float* __restrict_
 // outT: non-flip [G][KK][ldt] (co contiguous); flip [G][Ci][ldt] with column ((KH-1-ky)*KW + KW-1-kx)*Co + co
 template <typename T>
 __global__ __launch_bounds__(256) void wprep_outT_kernel(const float* __restrict__ w, const float* __restrict__ rs,
-                                                         const float* __restrict__ cs, T* __restrict__ outT, long ldt,
-                                                         int G, int Co, int Ci, int KH, int KW, int stem, int flip) {
+                                                         const float* __restrict__ cs, const int* __restrict__ perm,
+                                                         T* __restrict__ outT, long ldt, int G, int Co, int Ci, int KH,
+                                                         int KW, int stem, int flip) {
     const int KK = Ci * KH * KW;
     const int trows = flip ? Ci : KK;
     const long total = (long)G * trows * ldt;
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void wprep_outT_kernel(const float* __restrict
         float v = 0.f;
         if (!flip) {
             if (col < Co) {
-                const int n = g * Co + col;
+                const int n = perm ? perm[g * Co + col] : g * Co + col;
                 int ci;
                 v = w[w_index(n, r, Ci, KH, KW, stem, &ci)];
                 if (rs) v *= rs[n];
@@ -62,7 +65,7 @@ __global__ __launch_bounds__(256) void wprep_outT_kernel(const float* __restrict
             if (col < KH * KW * Co) {
                 const int tapf = col / Co, co = col - tapf * Co;
                 const int tap = KH * KW - 1 - tapf;  // (KH-1-ky, KW-1-kx) <-> flipped linear tap index
-                const int n = g * Co + co;
+                const int n = perm ? perm[g * Co + co] : g * Co + co;
                 v = w[((long)n * Ci + r) * (KH * KW) + tap];
                 if (rs) v *= rs[n];
                 if (cs) v *= cs[r];
@@ -75,30 +78,34 @@ __global__ __launch_bounds__(256) void wprep_outT_kernel(const float* __restrict
 // be[n] = rs[n] * (b[n] + sum_c W[n][c] v[c]); one wave per n
 __global__ __launch_bounds__(256) void bias_fold_kernel(const float* __restrict__ W, const float* __restrict__ b,
                                                         const float* __restrict__ rs, const float* __restrict__ v,
-                                                        float* __restrict__ be, int N, int C) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (n >= N) return;
+                                                        const int* __restrict__ perm, float* __restrict__ be, int N,
+                                                        int C) {
+    const int no = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (no >= N) return;
+    const int n = perm ? perm[no] : no;
     float s = 0.f;
     if (v)
         for (int c = lane; c < C; c += 64) s += W[(long)n * C + c] * v[c];
     s = wave_sum(s);
-    if (lane == 0) be[n] = (rs ? rs[n] : 1.f) * ((b ? b[n] : 0.f) + s);
+    if (lane == 0) be[no] = (rs ? rs[n] : 1.f) * ((b ? b[n] : 0.f) + s);
 }
 
 // dW[orig layout] += rs[n] * G[n][kcol] * cs[ci]
 __global__ __launch_bounds__(256) void unfold_dw_kernel(const float* __restrict__ G, long ldg,
                                                         const float* __restrict__ rs, const float* __restrict__ cs,
                                                         const float* __restrict__ gb, const float* __restrict__ v,
-                                                        float* __restrict__ dW, int N, int Ci, int KH, int KW, int stem) {
+                                                        const int* __restrict__ perm, float* __restrict__ dW, int N,
+                                                        int Ci, int KH, int KW, int stem) {
     const int KK = Ci * KH * KW;
     const long total = (long)N * KK;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int n = (int)(i / KK), kcol = (int)(i - (long)n * KK);
+        const int no = (int)(i / KK), kcol = (int)(i - (long)no * KK);
+        const int n = perm ? perm[no] : no;   // master-weight row of effective row `no`
         int ci;
         const long wi = w_index(n, kcol, Ci, KH, KW, stem, &ci);
-        float val = G[(long)n * ldg + kcol];
+        float val = G[(long)no * ldg + kcol];
         if (cs) val *= cs[ci];
-        if (gb && v) val += gb[n] * v[ci];   // bias-fold path: be[n] = rs[n] * (b[n] + sum_c W[n][c] v[c])
+        if (gb && v) val += gb[no] * v[ci];   // bias-fold path: be[n] = rs[n] * (b[n] + sum_c W[n][c] v[c])
         if (rs) val *= rs[n];
         dW[wi] += val;
     }
@@ -109,23 +116,25 @@ __global__ __launch_bounds__(256) void unfold_rows_kernel(const float* __restric
                                                           const float* __restrict__ gb, const float* __restrict__ W,
                                                           const float* __restrict__ b, const float* __restrict__ rs,
                                                           const float* __restrict__ cs, const float* __restrict__ v,
-                                                          float* __restrict__ d_rs, float* __restrict__ db, int N,
-                                                          int Ci, int KH, int KW, int stem) {
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (n >= N) return;
+                                                          const int* __restrict__ perm, float* __restrict__ d_rs,
+                                                          float* __restrict__ db, int N, int Ci, int KH, int KW,
+                                                          int stem) {
+    const int no = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (no >= N) return;
+    const int n = perm ? perm[no] : no;
     const int KK = Ci * KH * KW;
     if (d_rs) {
         float s = 0.f;
         for (int k = lane; k < KK; k += 64) {
             int ci;
             const long wi = w_index(n, k, Ci, KH, KW, stem, &ci);
-            s += G[(long)n * ldg + k] * W[wi] * (cs ? cs[ci] : 1.f);
-            if (gb && v) s += gb[n] * W[wi] * v[ci];
+            s += G[(long)no * ldg + k] * W[wi] * (cs ? cs[ci] : 1.f);
+            if (gb && v) s += gb[no] * W[wi] * v[ci];
         }
         s = wave_sum(s);
-        if (lane == 0) d_rs[n] += s + ((gb && b) ? gb[n] * b[n] : 0.f);
+        if (lane == 0) d_rs[n] += s + ((gb && b) ? gb[no] * b[n] : 0.f);
     }
-    if (db && gb && lane == 0) db[n] += (rs ? rs[n] : 1.f) * gb[n];
+    if (db && gb && lane == 0) db[n] += (rs ? rs[n] : 1.f) * gb[no];
 }
 
 // per-column (KH=KW=1): d_cs[c] += sum_n rs[n] G[n][c] W[n][c];  d_v[c] += sum_n gb[n] rs[n] W[n][c]
@@ -214,29 +223,29 @@ extern "C" int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream) {
         const long total = (long)d->G * d->Co * d->ldo;
         if (d->dtype == GA_BF16)
             hipLaunchKernelGGL(wprep_out_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
-                               (bf16_t*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
+                               d->row_perm, (bf16_t*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
         else
             hipLaunchKernelGGL(wprep_out_kernel<float>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
-                               (float*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
+                               d->row_perm, (float*)d->out, (long)d->ldo, d->G * d->Co, d->Ci, d->KH, d->KW, d->stem);
     }
     if (d->outT) {
         GA_REQUIRE(d->ldt >= (d->flip ? d->KH * d->KW * d->Co : d->Co), "ga_weight_prep: ldt too small");
         const long total = (long)d->G * (d->flip ? d->Ci : KK) * d->ldt;
         if (d->dtype == GA_BF16)
             hipLaunchKernelGGL(wprep_outT_kernel<bf16_t>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
-                               (bf16_t*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
+                               d->row_perm, (bf16_t*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
         else
             hipLaunchKernelGGL(wprep_outT_kernel<float>, dim3(nblocks(total)), dim3(256), 0, s, d->w, d->rs, d->cs,
-                               (float*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
+                               d->row_perm, (float*)d->outT, (long)d->ldt, d->G, d->Co, d->Ci, d->KH, d->KW, d->stem, d->flip);
     }
     return ga_check_launch("ga_weight_prep");
 }
 
-extern "C" int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, float* be, int N, int C,
-                            ga_stream_t stream) {
+extern "C" int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, const int* row_perm,
+                            float* be, int N, int C, ga_stream_t stream) {
     GA_REQUIRE(be && N > 0 && (!v || W), "ga_bias_fold: bad args");
     hipLaunchKernelGGL(bias_fold_kernel, dim3(cdiv(N, 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, b, rs,
-                       v, be, N, C);
+                       v, row_perm, be, N, C);
     return ga_check_launch("ga_bias_fold");
 }
 
@@ -245,14 +254,15 @@ extern "C" int ga_weight_unfold(const ga_wunfold_desc* d, ga_stream_t stream) {
     GA_REQUIRE(!((d->d_cs || d->d_v || d->v) && (d->KH != 1 || d->KW != 1)),
                "ga_weight_unfold: column grads / bias-fold vector need a 1x1 kernel");
     GA_REQUIRE(!((d->d_rs || d->d_cs || d->d_v) && !d->W), "ga_weight_unfold: W required");
+    GA_REQUIRE(!(d->row_perm && (d->d_cs || d->d_v)), "ga_weight_unfold: row_perm with column grads unsupported");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int KK = d->Ci * d->KH * d->KW;
     if (d->dW)
         hipLaunchKernelGGL(unfold_dw_kernel, dim3(nblocks((long)d->N * KK)), dim3(256), 0, s, d->G, (long)d->ldg, d->rs,
-                           d->cs, d->gb, d->v, d->dW, d->N, d->Ci, d->KH, d->KW, d->stem);
+                           d->cs, d->gb, d->v, d->row_perm, d->dW, d->N, d->Ci, d->KH, d->KW, d->stem);
     if (d->d_rs || (d->db && d->gb))
         hipLaunchKernelGGL(unfold_rows_kernel, dim3(cdiv(d->N, 4)), dim3(256), 0, s, d->G, (long)d->ldg, d->gb, d->W,
-                           d->b, d->rs, d->cs, d->v, d->d_rs, d->db, d->N, d->Ci, d->KH, d->KW, d->stem);
+                           d->b, d->rs, d->cs, d->v, d->row_perm, d->d_rs, d->db, d->N, d->Ci, d->KH, d->KW, d->stem);
     if (d->d_cs || d->d_v)
         hipLaunchKernelGGL(unfold_cols_kernel, dim3(cdiv(d->Ci, 64), cdiv(d->N, 64)), dim3(256), 0, s, d->G,
                            (long)d->ldg, d->gb, d->W, d->rs, d->d_cs, d->d_v, d->N, d->Ci);

@@ -1,0 +1,789 @@
+"""GAEngine: the static launch plans (weight prep / forward / backward) of one GA_ConvNeXt for a fixed
+(batch, train|eval, math mode), over persistent NHWC device buffers.
+
+Data layout in HBM (bf16 mode; fp32 mode is identical with 4-byte elements):
+  * activations: row-major [B*H*W, C] (= NHWC), bf16; per-row LayerNorm rstd fp32; BatchNorm stats fp32 [C];
+  * weights: fp32 masters in ONE flat buffer ([decay | no-decay]); per step they are re-laid-out once into the
+    "effective" bf16 GEMM operands (k = (ky,kx,ci); LayerNorm scale and LayerScale gamma folded in; a transposed
+    copy for the data-gradient product) by ga_weight_prep -- so the hot GEMMs only ever see bias / GELU / residual
+    epilogues;
+  * gradients: fp32, ONE flat buffer aliased by every param.grad; the wgrad kernels atomically accumulate either
+    directly into it or into a zeroed scratch arena of effective-weight gradients that ga_weight_unfold maps back.
+What is saved for backward per ConvNeXt block: xhat (LN output, no affine), rstd, h (pre-GELU hidden) and the
+block output; GELU / GELU' are recomputed inside the GEMM loader / epilogue.
+
+Reference semantics restated here: /root/reference/GA/ga_convnext.py:98-112 (block), :139-150 (stage + taps),
+:294-318 (Bottleneck), :452-467 (get_gram), :153-248 (class attention block), :469-505 (forward).
+"""
+import torch
+
+from . import ops
+from .ops import (A_CONV3, A_PATCH2, A_STEM4_NCHW, ACT_GELU, C_UNPATCH2, GA_BF16, GA_F32, Plan)
+
+
+def pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def tap_indices(nblocks, naggre):
+    """ga_convnext.py:141-147"""
+    taps = []
+    if nblocks > 5:
+        for i in range(nblocks):
+            if (i + 1) % (nblocks // (naggre + 1)) == 0 and len(taps) < naggre:
+                taps.append(i)
+    return taps
+
+
+class GAFunction(torch.autograd.Function):
+    """Autograd glue: one node for the whole network. Parameter gradients are accumulated by the HIP kernels
+    straight into the flat gradient buffer behind every param.grad (so this node returns no tensor grads)."""
+
+    @staticmethod
+    def forward(ctx, eng, x, anchor):
+        ctx.eng = eng
+        return eng.forward(x)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.eng.backward(dlogits)
+        return None, None, None
+
+
+class GAEngine:
+    def __init__(self, model, batch, training, mode):
+        self.m = model
+        self.cfg = model.cfg
+        self.B = batch
+        self.training = training
+        self.dt = GA_BF16 if mode == 'bf16' else GA_F32
+        self.tdt = ops.torch_dtype(self.dt)
+        flat = model.flat_state()
+        self.dev = flat['params'].device
+        self.P = dict(model.named_parameters())
+        self.Bf = dict(model.named_buffers())
+        self.bufs = {}
+        self.tmps = {}
+        self.W = {}
+        self.weights_dirty = True
+        self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
+        self.input_descs = []
+        self.blocks = {}
+        self.x_ref = None
+        self.img = 224
+        # DropPath schedule (ga_convnext.py:362,376,413)
+        self.dp_rates = self._drop_path_rates()
+        self.dp_scale = {}   # block prefix -> fp32 [B] (mask / keep)
+        if training:
+            for pre, r in self.dp_rates.items():
+                if r > 0:
+                    self.dp_scale[pre] = torch.ones(batch, device=self.dev)
+        # scratch arena for effective-weight gradients (zeroed once per backward)
+        self.arena = None
+        self.arena_off = 0
+        if training:
+            self.arena = torch.zeros(int(flat['total'] * 1.15) + (1 << 20), device=self.dev)
+        self._nbt = [t for n, t in self.Bf.items() if n.endswith('num_batches_tracked')]
+        self.prep = Plan(name='prep')
+        self.fwd = Plan(name='fwd')
+        self.bwd = Plan(name='bwd') if training else None
+        self._build()
+
+    # ------------------------------------------------------------------------------------------
+    # buffers
+    # ------------------------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=None, zero=False):
+        dtype = dtype or self.tdt
+        if name not in self.bufs:
+            self.bufs[name] = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        t = self.bufs[name]
+        assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, name
+        return t
+
+    def tmp(self, tag, shape, dtype=None):
+        """transient buffer shared by every call site with the same (tag, shape, dtype) -- stream order makes it safe"""
+        dtype = dtype or self.tdt
+        key = (tag, tuple(shape), dtype)
+        if key not in self.tmps:
+            self.tmps[key] = torch.empty(shape, dtype=dtype, device=self.dev)
+        return self.tmps[key]
+
+    def act(self, name, shape, dtype=None):
+        """activation saved for backward (uniquely named, persistent)"""
+        return self.buf(name, shape, dtype)
+
+    def blk_act(self, name, shape, dtype=None):
+        """per-block saved activation: persistent when training, one shared transient per shape in eval"""
+        return self.buf(name, shape, dtype) if self.training else self.tmp(name.rsplit('.', 1)[-1], shape, dtype)
+
+    def gbuf(self, shape):
+        n = 1
+        for s in shape:
+            n *= s
+        off = (self.arena_off + 63) // 64 * 64
+        assert off + n <= self.arena.numel(), 'gradient scratch arena too small'
+        self.arena_off = off + n
+        return self.arena[off:off + n].view(shape)
+
+    def grad(self, name):
+        return self.P[name].grad
+
+    def _drop_path_rates(self):
+        dep = self.cfg['depths']
+        rate = self.cfg['drop_path_rate']
+        pts = torch.linspace(0, rate, sum(dep)).split(list(dep))
+        out = {}
+        for i in range(4):
+            for j in range(dep[i]):
+                out[f'stages.{i}.blocks.{j}.'] = float(pts[i][j])
+        out['stages.4.'] = float(rate)
+        for k in range(self.cfg['branches']):
+            out[f'gram_layer.{k}.blocks.0.'] = float(pts[-1][0])   # dp_rates[-1] (ga_convnext.py:413)
+            out[f'ga.{k}.'] = 0.0                                    # LayerScaleBlockClassAttn default drop_path=0
+        return out
+
+    def sample_drop_path(self, generator=None):
+        """fresh per-sample Bernoulli(keep)/keep factors for every stochastic-depth site (timm DropPath)"""
+        for pre, t in self.dp_scale.items():
+            keep = 1.0 - self.dp_rates[pre]
+            t.copy_((torch.rand(self.B, device=self.dev, generator=generator) < keep).float() / keep)
+
+    def set_drop_path_masks(self, masks):
+        for pre, t in self.dp_scale.items():
+            t.copy_(masks[pre].to(self.dev).float())
+
+    # ------------------------------------------------------------------------------------------
+    # build
+    # ------------------------------------------------------------------------------------------
+    def _build(self):
+        cfg = self.cfg
+        d, dep = cfg['dims'], cfg['depths']
+        B, T, F = self.B, self.training, self.fwd
+        dt = self.dt
+        S0 = self.img // 4
+        self.x_in = None
+        # ---------------- stem ----------------
+        M0 = B * S0 * S0
+        Wst = self._w_plain('stem.0.weight', d[0], 3, 4, 4, stem=True, need_T=False)
+        stem_pre = self.act('stem.pre', (M0, d[0]))
+        self.x_placeholder = torch.zeros(8, device=self.dev)  # patched by set_input
+        F.gemm(self.x_placeholder, Wst, stem_pre, M0, d[0], 48, dt, a_kind=A_STEM4_NCHW, a_dims=(self.img, self.img, 3),
+               bias=self.P['stem.0.bias'], label='stem.conv')
+        self.input_descs.append(self._last_desc(F))
+        mean = self.act('stem.mean', (M0,), torch.float32)
+        rstd = self.act('stem.rstd', (M0,), torch.float32)
+        x = self.buf('stem.out', (M0, d[0]))
+        F.layernorm_fwd(stem_pre, self.P['stem.1.weight'], self.P['stem.1.bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
+                        label='stem.ln')
+        # ---------------- stages 0..3 ----------------
+        feats, taps = [], []
+        res = S0
+        stage_in = []
+        for i in range(4):
+            if i > 0:
+                Hp = res
+                res //= 2
+                Mi = B * res * res
+                Mp = B * Hp * Hp
+                pre = f'stages.{i}.downsample.'
+                ln = self.act(pre + 'ln', (Mp, d[i - 1]))
+                mean = self.act(pre + 'mean', (Mp,), torch.float32)
+                rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
+                F.layernorm_fwd(x, self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln, mean, rstd, Mp, d[i - 1], 1e-6, dt,
+                                label=pre + 'ln')
+                Wd = self._w_plain(pre + '1.weight', d[i], d[i - 1], 2, 2)
+                xo = self.buf(pre + 'out', (Mi, d[i]))
+                F.gemm(ln, Wd, xo, Mi, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2, a_dims=(Hp, Hp, d[i - 1]),
+                       bias=self.P[pre + '1.bias'], label=pre + 'conv')
+                stage_in.append((x, Hp))
+                x = xo
+            tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
+            for j in range(dep[i]):
+                x = self._block_fwd(f'stages.{i}.blocks.{j}.', x, res, d[i])
+                if j in tap_at:
+                    taps.append(x)
+            feats.append((x, res))
+        # ---------------- aggregate (ga_convnext.py:479-483) ----------------
+        Hc = 14
+        M4 = B * Hc * Hc
+        ctot = sum(d[:-1]) + d[2] * cfg['naggre']
+        cat = self.act('agg.cat', (M4, ctot))
+        segs = [(feats[0][0], feats[0][1], d[0], 0), (feats[1][0], feats[1][1], d[1], 0)]
+        segs += [(t, feats[2][1], d[2], 0) for t in taps]
+        segs += [(feats[2][0], feats[2][1], d[2], 0), (feats[3][0], feats[3][1], d[3], 1)]
+        off = 0
+        self.agg_segs = []
+        for src, hw, c, mode in segs:
+            F.pool_concat_fwd(src, cat, B, hw, hw, c, Hc, Hc, ctot, off, mode, dt, label=f'agg.{off}')
+            self.agg_segs.append((src, hw, c, mode, off))
+            off += c
+        assert off == ctot
+        # ---------------- Bottleneck "stage 4" ----------------
+        x4 = self._bottleneck_fwd(cat, M4, ctot, d[4])
+        # ---------------- heads ----------------
+        NC, K = cfg['num_classes'], cfg['branches']
+        assert NC % 8 == 0, 'num_classes must be a multiple of 8 (pad the classifier)'
+        self.logits = self.buf('logits', (K, B, NC), torch.float32)
+        self.heads = []
+        for k in range(K):
+            self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
+        # ---------------- backward ----------------
+        if T:
+            self._build_backward(feats, taps, stage_in, x4, M4, ctot)
+
+    @staticmethod
+    def _last_desc(plan):
+        # the ctypes descriptor of the most recently recorded gemm/wgrad call
+        for obj in reversed(plan.keep):
+            if hasattr(obj, '_fields_'):
+                return obj
+        raise RuntimeError('no descriptor')
+
+    # ------------------------------------------------------------------------------------------
+    # effective weights (recorded into self.prep)
+    # ------------------------------------------------------------------------------------------
+    def _w_plain(self, name, Co, Ci, KH, KW, stem=False, need_T=True, flip=False, groups=1, rs=None, cs=None,
+                 row_perm=None, ldo=None, key=None):
+        """effective copy (and transposed copy when training) of a conv/linear weight; returns the forward copy"""
+        key = key or name
+        if key in self.W:
+            return self.W[key]
+        KK = Ci * KH * KW
+        ldo = ldo or pad8(KK)
+        out = self.buf('w.' + key, (groups * Co, ldo))
+        outT = None
+        ldt = 0
+        if need_T and self.training:
+            if flip:
+                ldt = pad8(KH * KW * Co)
+                outT = self.buf('wT.' + key, (groups * Ci, ldt))
+            else:
+                ldt = pad8(Co)
+                outT = self.buf('wT.' + key, (groups * KK, ldt))
+            self.W[key + '.T'] = outT
+        self.prep.weight_prep(self.P[name], groups, Co, Ci, KH, KW, self.dt, out=out, ldo=ldo, outT=outT, ldt=ldt, rs=rs,
+                              cs=cs, flip=flip, stem=stem, row_perm=row_perm, label='prep.' + key)
+        self.W[key] = out
+        return out
+
+    def _block_weights(self, pre, C):
+        if pre + 'w49' in self.W:
+            return
+        P = self.P
+        w49 = self.buf('w.' + pre + 'w49', (49, C), torch.float32)
+        self.prep.transpose_f32(P[pre + 'conv_dw.weight'], w49, C, 49, label='prep.' + pre + 'w49')
+        self.W[pre + 'w49'] = w49
+        self._w_plain(pre + 'mlp.fc1.weight', 4 * C, C, 1, 1, cs=P[pre + 'norm.weight'])
+        b1e = self.buf('w.' + pre + 'b1e', (4 * C,), torch.float32)
+        self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm.bias'], b1e, 4 * C, C)
+        self.W[pre + 'b1e'] = b1e
+        self._w_plain(pre + 'mlp.fc2.weight', C, 4 * C, 1, 1, rs=P[pre + 'gamma'])
+        b2e = self.buf('w.' + pre + 'b2e', (C,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma'], None, b2e, C, 4 * C)
+        self.W[pre + 'b2e'] = b2e
+
+    # ------------------------------------------------------------------------------------------
+    # ConvNeXt block
+    # ------------------------------------------------------------------------------------------
+    def _block_fwd(self, pre, x, res, C):
+        assert C % 8 == 0
+        F, dt, B = self.fwd, self.dt, self.B
+        M = B * res * res
+        self._block_weights(pre, C)
+        W = self.W
+        u = self.tmp('u', (M, C))
+        F.dwconv7_fwd(x, W[pre + 'w49'], self.P[pre + 'conv_dw.bias'], u, B, res, res, C, dt, label=pre + 'dw')
+        xn = self.blk_act(pre + 'xn', (M, C))
+        rstd = self.blk_act(pre + 'rstd', (M,), torch.float32)
+        F.layernorm_fwd(u, None, None, xn, None, rstd, M, C, 1e-6, dt, label=pre + 'ln')
+        h = self.blk_act(pre + 'h', (M, 4 * C))
+        F.gemm(xn, W[pre + 'mlp.fc1.weight'], h, M, 4 * C, C, dt, bias=W[pre + 'b1e'], label=pre + 'fc1')
+        y = self.buf(pre + 'y', (M, C))
+        F.gemm(h, W[pre + 'mlp.fc2.weight'], y, M, C, 4 * C, dt, a_act=ACT_GELU, bias=W[pre + 'b2e'],
+               rowscale=self.dp_scale.get(pre), rows_per_scale=res * res, R=x, ldr=C, label=pre + 'fc2')
+        self.blocks[pre] = dict(x=x, xn=xn, rstd=rstd, h=h, y=y, res=res, C=C)
+        return y
+
+    def _block_bwd(self, pre, dy, dx):
+        """dy: grad wrt the block output; writes dx (a different buffer) = grad wrt the block input"""
+        Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
+        b = self.blocks[pre]
+        res, C = b['res'], b['C']
+        M = B * res * res
+        dp = self.dp_scale.get(pre)
+        dyz = dy
+        if dp is not None:
+            dyz = self.tmp('dyz', (M, C))
+            Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
+        G2, gb2 = self.gbuf((C, 4 * C)), self.gbuf((C,))
+        Bk.wgrad(dyz, b['h'], G2, M, C, 4 * C, dt, x_act=ACT_GELU, dbias=gb2, label=pre + 'wg2')
+        dh = self.tmp('dh', (M, 4 * C))
+        gb1 = self.gbuf((4 * C,))
+        Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['h'], ldh=4 * C, colsum=gb1, label=pre + 'dg2')
+        G1 = self.gbuf((4 * C, C))
+        Bk.wgrad(dh, b['xn'], G1, M, 4 * C, C, dt, label=pre + 'wg1')
+        g = self.tmp('g', (M, C))
+        Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], g, M, C, 4 * C, dt, label=pre + 'dg1')
+        du = self.tmp('du', (M, C))
+        Bk.layernorm_bwd(g, b['xn'], None, b['rstd'], None, None, du, None, None, M, C, True, dt, label=pre + 'lnb')
+        Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, label=pre + 'dwd')
+        dw49 = self.gbuf((49, C))
+        Bk.dwconv7_bwd_weight(du, b['x'], dw49, self.grad(pre + 'conv_dw.bias'), B, res, res, C, dt, label=pre + 'dww')
+        Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
+                         rs=P[pre + 'gamma'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
+                         d_rs=self.grad(pre + 'gamma'), label=pre + 'unf2')
+        Bk.weight_unfold(G1, C, 4 * C, C, gb=gb1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'],
+                         cs=P[pre + 'norm.weight'], v=P[pre + 'norm.bias'], dW=self.grad(pre + 'mlp.fc1.weight'),
+                         db=self.grad(pre + 'mlp.fc1.bias'), d_cs=self.grad(pre + 'norm.weight'),
+                         d_v=self.grad(pre + 'norm.bias'), label=pre + 'unf1')
+        Bk.transpose_f32(dw49, self.grad(pre + 'conv_dw.weight'), 49, C, accumulate=True, label=pre + 'unfdw')
+
+    # ------------------------------------------------------------------------------------------
+    # BatchNorm helper (stats come from the producing GEMM's colsum epilogue)
+    # ------------------------------------------------------------------------------------------
+    def _bn_bufs(self, pre, C):
+        return dict(s=self.buf(pre + 's', (C,), torch.float32, zero=True), q=self.buf(pre + 'q', (C,), torch.float32, zero=True),
+                    mean=self.buf(pre + 'bmean', (C,), torch.float32), rstd=self.buf(pre + 'brstd', (C,), torch.float32),
+                    scale=self.buf(pre + 'scale', (C,), torch.float32), shift=self.buf(pre + 'shift', (C,), torch.float32))
+
+    def _bn_finalize(self, pre, bn, n, C):
+        self.fwd.bn_finalize(bn['s'], bn['q'], n, self.P[pre + 'weight'], self.P[pre + 'bias'], 1e-5, 0.1,
+                             self.Bf[pre + 'running_mean'], self.Bf[pre + 'running_var'], bn['mean'], bn['rstd'],
+                             bn['scale'], bn['shift'], C, self.training, label=pre + 'fin')
+
+    def _bn_bwd(self, pre, bn, dy, y_relu, x, dx, rows, C, rowscale=None, rps=1):
+        Bk = self.bwd
+        s1, s2 = self.gbuf((C,)), self.gbuf((C,))
+        Bk.bn_bwd_reduce(dy, y_relu, x, bn['mean'], bn['rstd'], s1, s2, rows, C, self.dt, rowscale=rowscale,
+                         rows_per_scale=rps, label=pre + 'bnr')
+        Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'], s1, s2, rows, dx, rows, C, self.dt,
+                        rowscale=rowscale, rows_per_scale=rps, label=pre + 'bna')
+        Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, C)
+        Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, C)
+
+    # ------------------------------------------------------------------------------------------
+    # Bottleneck (ga_convnext.py:294-318)
+    # ------------------------------------------------------------------------------------------
+    def _bottleneck_fwd(self, cat, M4, ctot, cout):
+        F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
+        pre = 'stages.4.'
+        w = cout // 4
+        HW = M4 // B
+        st = self.bott = dict(cat=cat, w=w, cout=cout, ctot=ctot)
+        stats = T  # batch statistics only in train mode
+
+        def conv_bn(name, bnname, A, Wt, N, Kdim, bias=None, **kw):
+            c = self.act(pre + name + '.out', (M4, N))
+            bn = self._bn_bufs(pre + bnname + '.', N)
+            if stats:
+                F.zero(bn['s']); F.zero(bn['q'])
+            F.gemm(A, Wt, c, M4, N, Kdim, dt, bias=bias, colsum=bn['s'] if stats else None,
+                   colsumsq=bn['q'] if stats else None, label=pre + name, **kw)
+            self._bn_finalize(pre + bnname + '.', bn, M4, N)
+            return c, bn
+
+        Wc1 = self._w_plain(pre + 'conv1.weight', w, ctot, 1, 1)
+        st['c1'], st['bn1'] = conv_bn('conv1', 'bn1', cat, Wc1, w, ctot)
+        st['y1'] = self.act(pre + 'y1', (M4, w))
+        F.affine_act(st['c1'], st['bn1']['scale'], st['bn1']['shift'], None, st['y1'], M4, w, True, dt, label=pre + 'bn1')
+        Wc2 = self._w_plain(pre + 'conv2.weight', w, w, 3, 3, flip=True)
+        st['c2'], st['bn2'] = conv_bn('conv2', 'bn2', st['y1'], Wc2, w, 9 * w, a_kind=A_CONV3, a_dims=(14, 14, w))
+        st['y2'] = self.act(pre + 'y2', (M4, w))
+        F.affine_act(st['c2'], st['bn2']['scale'], st['bn2']['shift'], None, st['y2'], M4, w, True, dt, label=pre + 'bn2')
+        # squeeze-excite
+        R = P[pre + 'se.fc1.weight'].shape[0]
+        st['R'] = R
+        st['sp'] = self.act(pre + 'se.sp', (B, w), torch.float32)
+        st['hid'] = self.act(pre + 'se.hid', (B, R), torch.float32)
+        st['gate'] = self.act(pre + 'se.gate', (B, w), torch.float32)
+        F.spatial_sum(st['y2'], None, st['sp'], B, HW, w, 1.0 / HW, dt, label=pre + 'se.pool')
+        F.se_mlp_fwd(st['sp'], P[pre + 'se.fc1.weight'], P[pre + 'se.fc1.bias'], P[pre + 'se.fc2.weight'],
+                     P[pre + 'se.fc2.bias'], st['hid'], st['gate'], B, w, R, label=pre + 'se.mlp')
+        st['z'] = self.act(pre + 'se.z', (M4, w))
+        F.chan_scale(st['y2'], st['gate'], None, st['z'], B, HW, w, dt, label=pre + 'se.scale')
+        Wc3 = self._w_plain(pre + 'conv3.weight', cout, w, 1, 1)
+        st['c3'], st['bn3'] = conv_bn('conv3', 'bn3', st['z'], Wc3, cout, w)
+        Wds = self._w_plain(pre + 'downsample.0.weight', cout, ctot, 1, 1)
+        st['sc'], st['bnd'] = conv_bn('downsample.0', 'downsample.1', cat, Wds, cout, ctot, bias=P[pre + 'downsample.0.bias'])
+        t = self.tmp('bott.t', (M4, cout))
+        F.affine_act(st['sc'], st['bnd']['scale'], st['bnd']['shift'], None, t, M4, cout, False, dt, label=pre + 'bnd')
+        x4 = self.buf(pre + 'out', (M4, cout))
+        F.affine_act(st['c3'], st['bn3']['scale'], st['bn3']['shift'], t, x4, M4, cout, True, dt,
+                     rowscale=self.dp_scale.get(pre), rows_per_scale=HW, label=pre + 'bn3+add')
+        st['x4'] = x4
+        return x4
+
+    def _bottleneck_bwd(self, dx4, dcat):
+        Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
+        pre = 'stages.4.'
+        st = self.bott
+        w, cout, ctot = st['w'], st['cout'], st['ctot']
+        M4 = dx4.shape[0]
+        HW = M4 // B
+        dp = self.dp_scale.get(pre)
+        dc3 = self.tmp('bott.dc3', (M4, cout))
+        self._bn_bwd(pre + 'bn3.', st['bn3'], dx4, st['x4'], st['c3'], dc3, M4, cout, rowscale=dp, rps=HW)
+        dsc = self.tmp('bott.dsc', (M4, cout))
+        self._bn_bwd(pre + 'downsample.1.', st['bnd'], dx4, st['x4'], st['sc'], dsc, M4, cout)
+        # conv3
+        Bk.wgrad(dc3, st['z'], self.grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
+        dz = self.tmp('bott.dz', (M4, w))
+        Bk.gemm(dc3, W[pre + 'conv3.weight.T'], dz, M4, w, cout, dt, label=pre + 'conv3.dg')
+        # squeeze-excite
+        dgate = self.tmp('bott.dgate', (B, w), torch.float32)
+        dsp = self.tmp('bott.dsp', (B, w), torch.float32)
+        Bk.spatial_sum(dz, st['y2'], dgate, B, HW, w, 1.0, dt, label=pre + 'se.dgate')
+        Bk.se_mlp_bwd(dgate, st['gate'], st['hid'], st['sp'], P[pre + 'se.fc1.weight'], P[pre + 'se.fc2.weight'], dsp,
+                      self.grad(pre + 'se.fc1.weight'), self.grad(pre + 'se.fc1.bias'), self.grad(pre + 'se.fc2.weight'),
+                      self.grad(pre + 'se.fc2.bias'), B, w, st['R'], ds_scale=1.0 / HW, label=pre + 'se.mlpb')
+        dy2 = self.tmp('bott.dy2', (M4, w))
+        Bk.chan_scale(dz, st['gate'], dsp, dy2, B, HW, w, dt, label=pre + 'se.back')
+        dc2 = self.tmp('bott.dc2', (M4, w))
+        self._bn_bwd(pre + 'bn2.', st['bn2'], dy2, st['y2'], st['c2'], dc2, M4, w)
+        # conv2 3x3
+        G = self.gbuf((w, 9 * w))
+        Bk.wgrad(dc2, st['y1'], G, M4, w, 9 * w, dt, x_kind=A_CONV3, x_dims=(14, 14, w), label=pre + 'conv2.wg')
+        Bk.weight_unfold(G, 9 * w, w, w, 3, 3, dW=self.grad(pre + 'conv2.weight'), label=pre + 'conv2.unf')
+        dy1 = self.tmp('bott.dy1', (M4, w))
+        Bk.gemm(dc2, W[pre + 'conv2.weight.T'], dy1, M4, w, 9 * w, dt, a_kind=A_CONV3, a_dims=(14, 14, w),
+                ldb=pad8(9 * w), label=pre + 'conv2.dg')
+        dc1 = self.tmp('bott.dc1', (M4, w))
+        self._bn_bwd(pre + 'bn1.', st['bn1'], dy1, st['y1'], st['c1'], dc1, M4, w)
+        # conv1 and the shortcut conv both read `cat`
+        Bk.wgrad(dc1, st['cat'], self.grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
+        Bk.gemm(dc1, W[pre + 'conv1.weight.T'], dcat, M4, ctot, w, dt, ldb=pad8(w), label=pre + 'conv1.dg')
+        Bk.wgrad(dsc, st['cat'], self.grad(pre + 'downsample.0.weight'), M4, cout, ctot, dt,
+                 dbias=self.grad(pre + 'downsample.0.bias'), label=pre + 'ds.wg')
+        Bk.gemm(dsc, W[pre + 'downsample.0.weight.T'], dcat, M4, ctot, cout, dt, ldb=pad8(cout), R=dcat, ldr=ctot,
+                label=pre + 'ds.dg')
+
+    # ------------------------------------------------------------------------------------------
+    # one GA head (ga_convnext.py:491-504)
+    # ------------------------------------------------------------------------------------------
+    def _head_fwd(self, k, x4, M4, cout, Hc):
+        F, dt, B, P, T, cfg = self.fwd, self.dt, self.B, self.P, self.training, self.cfg
+        g, E, nh, mg, NC = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['num_classes']
+        groups = cfg['gram_groups']
+        HW = Hc * Hc
+        hd = E // nh
+        assert E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0
+        h = dict(k=k)
+        # --- gram_contraction: conv1x1 + BN
+        pre = f'gram_contraction.{k}.'
+        Wgc = self._w_plain(pre + '0.weight', g, cout, 1, 1)
+        h['gc'] = self.act(pre + 'out', (M4, g))
+        h['bn_gc'] = self._bn_bufs(pre + '1.', g)
+        if T:
+            F.zero(h['bn_gc']['s']); F.zero(h['bn_gc']['q'])
+        F.gemm(x4, Wgc, h['gc'], M4, g, cout, dt, bias=P[pre + '0.bias'], colsum=h['bn_gc']['s'] if T else None,
+               colsumsq=h['bn_gc']['q'] if T else None, label=pre + 'conv')
+        self._bn_finalize(pre + '1.', h['bn_gc'], M4, g)
+        h['g0'] = self.buf(pre + 'g0', (M4, g))
+        F.affine_act(h['gc'], h['bn_gc']['scale'], h['bn_gc']['shift'], None, h['g0'], M4, g, False, dt, label=pre + 'bn')
+        # --- gram_layer: one ConvNeXt block at 14x14
+        h['blk'] = f'gram_layer.{k}.blocks.0.'
+        g1 = self._block_fwd(h['blk'], h['g0'], Hc, g)
+        h['g1'] = g1
+        # --- Gram vector (fp32 accumulate; the reference's fp64 branch for train & B<128 is covered by the 1e-3 gate)
+        alpha = 1.0 / (Hc * Hc * HW)
+        h['alpha'] = alpha
+        G = self.tmp('gramG', (B, g, g), torch.float32)
+        F.wgrad(g1, g1, G, HW, g, g, dt, batch=B, strideY=HW * g, strideX=HW * g, strideW=g * g, split_m=1,
+                accumulate=False, alpha=alpha, label=f'gram.{k}')
+        ntri = g * (g + 1) // 2
+        Kg = ntri // groups
+        Kp = pad8(Kg)
+        h['Kg'], h['Kp'] = Kg, Kp
+        h['vec'] = self.act(f'gram.{k}.vec', (B, groups * Kp))
+        h['inv'] = self.act(f'gram.{k}.inv', (B,), torch.float32)
+        F.gram_pack_fwd(G, h['vec'], h['inv'], B, g, groups, Kp, dt, label=f'gram.{k}.pack')
+        # --- gram_embedding: grouped 1x1 + BN on (B, cout)
+        pre = f'gram_embedding.{k}.'
+        cg = cout // groups
+        Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp)
+        h['e'] = self.act(pre + 'out', (B, cout))
+        h['bn_e'] = self._bn_bufs(pre + '1.', cout)
+        if T:
+            F.zero(h['bn_e']['s']); F.zero(h['bn_e']['q'])
+        F.gemm(h['vec'], Wemb, h['e'], B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
+               ldc=cout, strideC=cg, bias=P[pre + '0.bias'], strideBias=cg, colsum=h['bn_e']['s'] if T else None,
+               colsumsq=h['bn_e']['q'] if T else None, strideCol=cg, label=pre + 'conv')
+        self._bn_finalize(pre + '1.', h['bn_e'], B, cout)
+        h['cls0'] = self.buf(pre + 'cls0', (B, cout))
+        F.affine_act(h['e'], h['bn_e']['scale'], h['bn_e']['shift'], None, h['cls0'], B, cout, False, dt, label=pre + 'bn')
+        # --- class-attention block
+        pre = f'ga.{k}.'
+        N = HW
+        h['u'] = self.act(pre + 'u', (B * (N + 1), cout))
+        F.token_cat(h['cls0'], x4, h['u'], B, N, cout, dt, label=pre + 'cat')
+        h['un'] = self.act(pre + 'un', (B * (N + 1), cout))
+        h['m1'] = self.act(pre + 'm1', (B * (N + 1),), torch.float32)
+        h['r1'] = self.act(pre + 'r1', (B * (N + 1),), torch.float32)
+        F.layernorm_fwd(h['u'], P[pre + 'norm1.weight'], P[pre + 'norm1.bias'], h['un'], h['m1'], h['r1'], B * (N + 1), cout,
+                        1e-5, dt, label=pre + 'ln1')
+        # k and v projections as one GEMM: attn.k.weight and attn.v.weight are adjacent in the flat parameter
+        # buffer, so together they already are the stacked [2E, cout] matrix
+        pk, pv = P[pre + 'attn.k.weight'], P[pre + 'attn.v.weight']
+        assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
+        Wkv = self.buf('w.' + pre + 'kv', (2 * E, cout))
+        WkvT = self.buf('wT.' + pre + 'kv', (cout, 2 * E)) if T else None
+        self.prep.weight_prep(pk, 1, 2 * E, cout, 1, 1, dt, out=Wkv, ldo=cout, outT=WkvT, ldt=2 * E if T else 0,
+                              label='prep.' + pre + 'kv')
+        h['Wkv'], h['WkvT'] = Wkv, WkvT
+        h['kv'] = self.act(pre + 'kv', (B * (N + 1), 2 * E))
+        F.gemm(h['un'], Wkv, h['kv'], B * (N + 1), 2 * E, cout, dt, label=pre + 'kv')
+        Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1)
+        h['q'] = self.act(pre + 'q', (B, E))
+        F.gemm(h['un'], Wq, h['q'], B, E, cout, dt, lda=(N + 1) * cout, label=pre + 'q')
+        h['ao'] = self.act(pre + 'ao', (B, E))
+        h['P'] = self.act(pre + 'P', (B, nh, N + 1), torch.float32)
+        h['scale'] = hd ** -0.5
+        F.class_attn_fwd(h['q'], h['kv'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
+        Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'])
+        bpr = self.buf('w.' + pre + 'bproj', (cout,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'attn.proj.bias'], P[pre + 'gamma_1'], None, bpr, cout, E)
+        dp = self.dp_scale.get(pre)
+        h['cls1'] = self.buf(pre + 'cls1', (B, cout))
+        F.gemm(h['ao'], Wpr, h['cls1'], B, cout, E, dt, bias=bpr, rowscale=dp, rows_per_scale=1, R=h['cls0'], ldr=cout,
+               label=pre + 'proj')
+        h['t'] = self.act(pre + 't', (B, cout))
+        h['m2'] = self.act(pre + 'm2', (B,), torch.float32)
+        h['r2'] = self.act(pre + 'r2', (B,), torch.float32)
+        F.layernorm_fwd(h['cls1'], P[pre + 'norm2.weight'], P[pre + 'norm2.bias'], h['t'], h['m2'], h['r2'], B, cout, 1e-5,
+                        dt, label=pre + 'ln2')
+        # GroupConvMlp: grouped fc1 -> GELU -> channel_shuffle -> grouped fc2; the shuffle is folded into the ROW
+        # ORDER of fc1's effective weights: hidden index n = gi*gc + ci  <-  fc1 output channel ci*mg + gi
+        Hd = 4 * cout
+        gc_ = Hd // mg
+        Nv = gc_ // mg          # rows per virtual group (fc1 input group is constant inside one)
+        cin = cout // mg
+        assert gc_ % mg == 0 and Nv % 8 == 0 and cin % 8 == 0
+        n_idx = torch.arange(Hd)
+        perm = ((n_idx % gc_) * mg + n_idx // gc_).to(torch.int32).to(self.dev)
+        h['perm'] = perm
+        Wm1 = self._w_plain(pre + 'mlp.fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
+        bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'mlp.fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
+        h['hm'] = self.act(pre + 'hm', (B, Hd))
+        F.gemm(h['t'], Wm1, h['hm'], B, Nv, cin, dt, lda=cout, batch=mg * mg, strideA=cin, a_batch_mod=mg,
+               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, label=pre + 'mlp.fc1')
+        Wm2 = self._w_plain(pre + 'mlp.fc2.weight', cin, gc_, 1, 1, groups=mg, rs=P[pre + 'gamma_2'])
+        bm2 = self.buf('w.' + pre + 'bm2', (cout,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma_2'], None, bm2, cout, gc_)
+        h['cls2'] = self.act(pre + 'cls2', (B, cout))
+        F.gemm(h['hm'], Wm2, h['cls2'], B, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
+               ldb=pad8(gc_), ldc=cout, strideC=cin, a_act=ACT_GELU, bias=bm2, strideBias=cin, rowscale=dp,
+               rows_per_scale=1, R=h['cls1'], ldr=cout, strideR=cin, label=pre + 'mlp.fc2')
+        h.update(Hd=Hd, mlp_gc=gc_, Nv=Nv, cin=cin)
+        # --- classifier
+        Wfc = self._w_plain(f'fc.{k}.weight', NC, cout, 1, 1)
+        F.gemm(h['cls2'], Wfc, self.logits[k], B, NC, cout, dt, bias=P[f'fc.{k}.bias'], c_f32=True, label=f'fc.{k}')
+        return h
+
+    def _head_bwd(self, h, dlog, dx4, first):
+        Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
+        k = h['k']
+        g, E, nh, mg, NC = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['num_classes']
+        groups = cfg['gram_groups']
+        cout = cfg['dims'][4]
+        M4 = dx4.shape[0]
+        HW = M4 // B
+        N = HW
+        hd = E // nh
+        Hd, gc_, Nv, cin = h['Hd'], h['mlp_gc'], h['Nv'], h['cin']
+        pre = f'ga.{k}.'
+        dp = self.dp_scale.get(pre)
+        # classifier
+        Bk.wgrad(dlog, h['cls2'], self.grad(f'fc.{k}.weight'), B, NC, cout, dt, dbias=self.grad(f'fc.{k}.bias'),
+                 label=f'fc.{k}.wg')
+        dcls2 = self.tmp('dcls2', (B, cout))
+        Bk.gemm(dlog, W[f'fc.{k}.weight.T'], dcls2, B, cout, NC, dt, ldb=pad8(NC), label=f'fc.{k}.dg')
+        dmz = dcls2
+        if dp is not None:
+            dmz = self.tmp('dmz', (B, cout))
+            Bk.rowscale(dcls2, dp, dmz, B * cout, cout, dt)
+        # mlp.fc2 (mg groups)
+        Gm2, gbm2 = self.gbuf((cout, gc_)), self.gbuf((cout,))
+        Bk.wgrad(dmz, h['hm'], Gm2, B, cin, gc_, dt, ldy=cout, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
+                 strideW=cin * gc_, x_act=ACT_GELU, dbias=gbm2, strideDbias=cin, label=pre + 'mlp.fc2.wg')
+        Bk.weight_unfold(Gm2, gc_, cout, gc_, gb=gbm2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
+                         rs=P[pre + 'gamma_2'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
+                         d_rs=self.grad(pre + 'gamma_2'), label=pre + 'mlp.fc2.unf')
+        dhm = self.tmp('dhm', (B, Hd))
+        gbm1 = self.gbuf((Hd,))
+        Bk.gemm(dmz, W[pre + 'mlp.fc2.weight.T'], dhm, B, gc_, cin, dt, lda=cout, batch=mg, strideA=cin,
+                strideB=gc_ * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=gc_, H=h['hm'], ldh=Hd, strideH=gc_, colsum=gbm1,
+                strideCol=gc_, label=pre + 'mlp.fc2.dg')
+        # mlp.fc1 (mg*mg virtual groups)
+        Gm1 = self.gbuf((Hd, cin))
+        Bk.wgrad(dhm, h['t'], Gm1, B, Nv, cin, dt, ldy=Hd, ldx=cout, ldw=cin, batch=mg * mg, strideY=Nv, strideX=cin,
+                 x_batch_mod=mg, strideW=Nv * cin, label=pre + 'mlp.fc1.wg')
+        Bk.weight_unfold(Gm1, cin, Hd, cin, gb=gbm1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'],
+                         row_perm=h['perm'], dW=self.grad(pre + 'mlp.fc1.weight'), db=self.grad(pre + 'mlp.fc1.bias'),
+                         label=pre + 'mlp.fc1.unf')
+        dtk = self.tmp('dt', (B, cout))
+        Wm1T = W[pre + 'mlp.fc1.weight.T']            # [mg*mg][cin][pad8(Nv)]
+        for gi in range(mg):
+            Bk.gemm(dhm[:, gi * gc_:], Wm1T[gi * mg * cin:], dtk, B, cin, Nv, dt, lda=Hd, batch=mg, strideA=Nv,
+                    strideB=cin * pad8(Nv), ldb=pad8(Nv), ldc=cout, strideC=cin, R=dtk if gi > 0 else None, ldr=cout,
+                    strideR=cin, label=pre + f'mlp.fc1.dg{gi}')
+        dcls1 = self.tmp('dcls1', (B, cout))
+        Bk.layernorm_bwd(dtk, h['cls1'], h['m2'], h['r2'], P[pre + 'norm2.weight'], dcls2, dcls1,
+                         self.grad(pre + 'norm2.weight'), self.grad(pre + 'norm2.bias'), B, cout, False, dt, label=pre + 'ln2b')
+        dpz = dcls1
+        if dp is not None:
+            dpz = self.tmp('dpz', (B, cout))
+            Bk.rowscale(dcls1, dp, dpz, B * cout, cout, dt)
+        # attention projection
+        Gp, gbp = self.gbuf((cout, E)), self.gbuf((cout,))
+        Bk.wgrad(dpz, h['ao'], Gp, B, cout, E, dt, dbias=gbp, label=pre + 'proj.wg')
+        Bk.weight_unfold(Gp, E, cout, E, gb=gbp, W=P[pre + 'attn.proj.weight'], b=P[pre + 'attn.proj.bias'],
+                         rs=P[pre + 'gamma_1'], dW=self.grad(pre + 'attn.proj.weight'), db=self.grad(pre + 'attn.proj.bias'),
+                         d_rs=self.grad(pre + 'gamma_1'), label=pre + 'proj.unf')
+        dao = self.tmp('dao', (B, E))
+        Bk.gemm(dpz, W[pre + 'attn.proj.weight.T'], dao, B, E, cout, dt, ldb=pad8(cout), label=pre + 'proj.dg')
+        dq = self.tmp('dq', (B, E))
+        dkv = self.tmp('dkv', (B * (N + 1), 2 * E))
+        Bk.class_attn_bwd(dao, h['q'], h['kv'], h['P'], dq, dkv, B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attnb')
+        # k, v are adjacent parameters -> their gradients form one [2E, cout] matrix in the flat gradient buffer
+        gk, gv = self.grad(pre + 'attn.k.weight'), self.grad(pre + 'attn.v.weight')
+        assert gv.data_ptr() == gk.data_ptr() + gk.numel() * 4, 'k/v gradients must be adjacent in the flat buffer'
+        Bk.wgrad(dkv, h['un'], gk, B * (N + 1), 2 * E, cout, dt, label=pre + 'kv.wg')
+        dun = self.tmp('dun', (B * (N + 1), cout))
+        Bk.gemm(dkv, h['WkvT'], dun, B * (N + 1), cout, 2 * E, dt, label=pre + 'kv.dg')
+        Bk.wgrad(dq, h['un'], self.grad(pre + 'attn.q.weight'), B, E, cout, dt, ldx=(N + 1) * cout, label=pre + 'q.wg')
+        Bk.gemm(dq, W[pre + 'attn.q.weight.T'], dun, B, cout, E, dt, ldb=pad8(E), ldc=(N + 1) * cout, R=dun,
+                ldr=(N + 1) * cout, label=pre + 'q.dg')
+        du = self.tmp('du_tok', (B * (N + 1), cout))
+        Bk.layernorm_bwd(dun, h['u'], h['m1'], h['r1'], P[pre + 'norm1.weight'], None, du, self.grad(pre + 'norm1.weight'),
+                         self.grad(pre + 'norm1.bias'), B * (N + 1), cout, False, dt, label=pre + 'ln1b')
+        # dcls0 = dcls1 + du[:,0];  dx4 (+)= du[:,1:]
+        Bk.token_split(du, dcls1, dx4, B, N, cout, True, not first, dt, label=pre + 'split')
+        # gram_embedding BN + grouped conv
+        pre = f'gram_embedding.{k}.'
+        cg = cout // groups
+        Kg, Kp = h['Kg'], h['Kp']
+        de = self.tmp('de', (B, cout))
+        self._bn_bwd(pre + '1.', h['bn_e'], dcls1, None, h['e'], de, B, cout)
+        gW = self.grad(pre + '0.weight')
+        Bk.wgrad(de, h['vec'], gW, B, cg, Kg, dt, ldy=cout, ldx=groups * Kp, ldw=Kg, batch=groups, strideY=cg, strideX=Kp,
+                 strideW=cg * Kg, dbias=self.grad(pre + '0.bias'), strideDbias=cg, label=pre + 'wg')
+        dvec = self.buf(f'gram.{k}.dvec', (B, groups * Kp), zero=True)   # pad columns stay zero
+        Bk.gemm(de, W[pre + '0.weight.T'], dvec, B, Kg, cg, dt, lda=cout, batch=groups, strideA=cg, strideB=Kg * pad8(cg),
+                ldb=pad8(cg), ldc=groups * Kp, strideC=Kp, label=pre + 'dg')
+        S = self.tmp('gramS', (B, g, g))
+        Bk.gram_pack_bwd(dvec, h['vec'], h['inv'], S, B, g, groups, Kp, dt, label=f'gram.{k}.packb')
+        dg1 = self.tmp('dg1', (M4, g))
+        Bk.gemm(h['g1'], S, dg1, HW, g, g, dt, batch=B, strideA=HW * g, strideB=g * g, strideC=HW * g, alpha=h['alpha'],
+                label=f'gram.{k}.dx')
+        dg0 = self.tmp('dg0', (M4, g))
+        self._block_bwd(h['blk'], dg1, dg0)
+        pre = f'gram_contraction.{k}.'
+        dgc = self.tmp('dgc', (M4, g))
+        self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], dgc, M4, g)
+        Bk.wgrad(dgc, self.bott['x4'], self.grad(pre + '0.weight'), M4, g, cout, dt, dbias=self.grad(pre + '0.bias'),
+                 label=pre + 'wg')
+        Bk.gemm(dgc, W[pre + '0.weight.T'], dx4, M4, cout, g, dt, ldb=pad8(g), R=dx4, ldr=cout, label=pre + 'dg')
+
+    # ------------------------------------------------------------------------------------------
+    # whole-network backward plan
+    # ------------------------------------------------------------------------------------------
+    def _build_backward(self, feats, taps, stage_in, x4, M4, ctot):
+        Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
+        d, dep = cfg['dims'], cfg['depths']
+        K, NC = cfg['branches'], cfg['num_classes']
+        self.dlogits = self.buf('dlogits', (K, B, NC))
+        Bk.zero(self.arena, label='zero.arena')
+        dx4 = self.tmp('dx4', (M4, d[4]))
+        for k in range(K):
+            self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
+        dcat = self.tmp('dcat', (M4, ctot))
+        self._bottleneck_bwd(dx4, dcat)
+        # aggregate backward -> gradient seeds of the stage outputs / taps
+        seeds = []
+        for src, hw, c, mode, off in self.agg_segs:
+            ds = self.buf(f'agg.d{off}', (B * hw * hw, c))
+            Bk.pool_concat_bwd(dcat, None, ds, B, hw, hw, c, 14, 14, ctot, off, mode, dt, label=f'agg.b{off}')
+            seeds.append(ds)
+        ntap = len(taps)
+        d_s0, d_s1 = seeds[0], seeds[1]
+        d_taps = seeds[2:2 + ntap]
+        d_s2, d_s3 = seeds[2 + ntap], seeds[3 + ntap]
+        seed = {0: d_s0, 1: d_s1, 2: d_s2, 3: d_s3}
+        tap_at = tap_indices(dep[2], cfg['naggre'])
+        dy = seed[3]
+        for i in (3, 2, 1, 0):
+            res = feats[i][1]
+            Mi = B * res * res
+            pp = [self.tmp(f'dxA{i}', (Mi, d[i])), self.tmp(f'dxB{i}', (Mi, d[i]))]
+            for j in reversed(range(dep[i])):
+                if i == 2 and j in tap_at:
+                    dtap = d_taps[tap_at.index(j)]
+                    Bk.affine_act(dy, None, None, dtap, dy, Mi, d[i], False, dt, label=f'tap.add.{j}')
+                dx = pp[0] if dy is not pp[0] else pp[1]
+                self._block_bwd(f'stages.{i}.blocks.{j}.', dy, dx)
+                dy = dx
+            if i > 0:
+                pre = f'stages.{i}.downsample.'
+                x_prev, Hp = stage_in[i - 1]
+                Mp = B * Hp * Hp
+                G = self.gbuf((d[i], 4 * d[i - 1]))
+                Bk.wgrad(dy, self.bufs[pre + 'ln'], G, Mi, d[i], 4 * d[i - 1], dt, x_kind=A_PATCH2,
+                         x_dims=(Hp, Hp, d[i - 1]), dbias=self.grad(pre + '1.bias'), label=pre + 'wg')
+                Bk.weight_unfold(G, 4 * d[i - 1], d[i], d[i - 1], 2, 2, dW=self.grad(pre + '1.weight'), label=pre + 'unf')
+                dln = self.tmp('dln', (Mp, d[i - 1]))
+                Bk.gemm(dy, W[pre + '1.weight.T'], dln, Mi, 4 * d[i - 1], d[i], dt, ldb=pad8(d[i]), c_kind=C_UNPATCH2,
+                        c_dims=(Hp, Hp, d[i - 1]), label=pre + 'dg')
+                dprev = self.tmp(f'dprev{i}', (Mp, d[i - 1]))
+                Bk.layernorm_bwd(dln, x_prev, self.bufs[pre + 'mean'], self.bufs[pre + 'rstd'], P[pre + '0.weight'],
+                                 seed[i - 1], dprev, self.grad(pre + '0.weight'), self.grad(pre + '0.bias'), Mp, d[i - 1],
+                                 False, dt, label=pre + 'lnb')
+                dy = dprev
+        # stem
+        M0 = dy.shape[0]
+        dpre = self.tmp('dstem', (M0, d[0]))
+        Bk.layernorm_bwd(dy, self.bufs['stem.pre'], self.bufs['stem.mean'], self.bufs['stem.rstd'], P['stem.1.weight'], None,
+                         dpre, self.grad('stem.1.weight'), self.grad('stem.1.bias'), M0, d[0], False, dt, label='stem.lnb')
+        Bk.wgrad(dpre, self.x_placeholder, self.grad('stem.0.weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
+                 x_dims=(self.img, self.img, 3), dbias=self.grad('stem.0.bias'), label='stem.wg')
+        self.input_descs.append(self._last_desc(Bk))
+
+    # ------------------------------------------------------------------------------------------
+    # run
+    # ------------------------------------------------------------------------------------------
+    def set_input(self, x):
+        assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.B, 3, self.img, self.img), \
+            f'input must be a float32 CUDA tensor of shape {(self.B, 3, self.img, self.img)}, got {tuple(x.shape)} {x.dtype}'
+        if not x.is_contiguous():
+            x = x.contiguous()   # channels_last callers (GA/train.py:729-730): the stem gather reads NCHW
+        self.x_ref = x
+        ptr = x.data_ptr()
+        fd = self.input_descs[0]
+        fd.A = ptr
+        if len(self.input_descs) > 1:
+            self.input_descs[1].X = ptr
+
+    def forward(self, x):
+        self.set_input(x)
+        if self.training or self.weights_dirty:
+            self.prep.run()
+            self.weights_dirty = False
+            if self.training:
+                for e in self.m._engines.values():
+                    if e is not self:
+                        e.weights_dirty = True
+        if self.training and self.dp_scale and not getattr(self, 'fixed_masks', False):
+            self.sample_drop_path()
+        self.fwd.run()
+        if self.training:
+            torch._foreach_add_(self._nbt, 1)
+        return self.logits.view_as(self.logits)
+
+    def backward(self, dlogits):
+        if dlogits.data_ptr() != self.dlogits.data_ptr():
+            if dlogits.dtype == self.tdt:
+                self.dlogits.copy_(dlogits)
+            else:
+                p = Plan(eager=True)
+                p.cast_from_f32(dlogits.contiguous().float(), self.dlogits, self.dlogits.numel(), self.dt)
+        self.bwd.run()

@@ -8,6 +8,7 @@ Every method records one call; `run()` enqueues them all.  `Plan(eager=True)` al
 recorded (used by the unit tests).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -35,8 +36,8 @@ def torch_dtype(ga):
 def _ptr(t):
     if t is None:
         return None
-    if isinstance(t, int):
-        return t
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'libgaext operand must be a torch.Tensor or None, got {type(t).__name__}: {t!r}')
     assert t.is_cuda, 'libgaext operands must live in device memory (no CPU fallback)'
     return t.data_ptr()
 
@@ -63,6 +64,12 @@ class Plan:
 
     def run(self, stream=None):
         s = current_stream_ptr() if stream is None else stream
+        if os.environ.get('GAEXT_SYNC_DEBUG'):   # localise a faulting launch: label printed before, sync after
+            for fn, args, label in self.calls:
+                print(f'[gaext] {self.name}:{label}', flush=True)
+                L.check(fn(*args, s), f'{self.name}:{label}')
+                torch.cuda.synchronize()
+            return
         for fn, args, label in self.calls:
             rc = fn(*args, s)
             if rc != 0:
@@ -96,11 +103,12 @@ class Plan:
 
     def wgrad(self, Y, X, dW, M, N, K, dtype, ldy=None, ldx=None, ldw=None, batch=1, strideY=0, strideX=0, strideW=0,
               x_kind=A_PLAIN, x_dims=(0, 0, 0), x_act=ACT_NONE, dbias=None, strideDbias=0, alpha=1.0, split_m=None,
-              accumulate=True, label=None):
+              accumulate=True, x_batch_mod=0, label=None):
         d = L.WgradDesc()
         d.M, d.N, d.K, d.batch, d.dtype = M, N, K, batch, dtype
         d.Y, d.ldy, d.strideY = _ptr(Y), (N if ldy is None else ldy), strideY
         d.X, d.ldx, d.strideX, d.x_kind = _ptr(X), (K if ldx is None else ldx), strideX, x_kind
+        d.x_batch_mod = x_batch_mod
         d.x_H, d.x_W, d.x_C = x_dims
         d.x_act = x_act
         d.dW, d.ldw, d.strideW = _ptr(dW), (K if ldw is None else ldw), strideW
@@ -112,23 +120,25 @@ class Plan:
         self._add('ga_wgrad', (C.byref(d),), label, keep=(d, Y, X, dW, dbias))
 
     def weight_prep(self, w, G, Co, Ci, KH, KW, dtype, out=None, ldo=0, outT=None, ldt=0, rs=None, cs=None, flip=False,
-                    stem=False, label=None):
+                    stem=False, row_perm=None, label=None):
         d = L.WprepDesc()
         d.w, d.G, d.Co, d.Ci, d.KH, d.KW = _ptr(w), G, Co, Ci, KH, KW
-        d.rs, d.cs, d.dtype = _ptr(rs), _ptr(cs), dtype
+        d.rs, d.cs, d.row_perm, d.dtype = _ptr(rs), _ptr(cs), _ptr(row_perm), dtype
         d.out, d.ldo, d.outT, d.ldt, d.flip, d.stem = _ptr(out), ldo, _ptr(outT), ldt, int(flip), int(stem)
-        self._add('ga_weight_prep', (C.byref(d),), label, keep=(d, w, out, outT, rs, cs))
+        self._add('ga_weight_prep', (C.byref(d),), label, keep=(d, w, out, outT, rs, cs, row_perm))
 
-    def bias_fold(self, W, b, rs, v, be, N, Cdim, label=None):
-        self._add('ga_bias_fold', (_ptr(W), _ptr(b), _ptr(rs), _ptr(v), _ptr(be), N, Cdim), label, keep=(W, b, rs, v, be))
+    def bias_fold(self, W, b, rs, v, be, N, Cdim, row_perm=None, label=None):
+        self._add('ga_bias_fold', (_ptr(W), _ptr(b), _ptr(rs), _ptr(v), _ptr(row_perm), _ptr(be), N, Cdim), label,
+                  keep=(W, b, rs, v, be, row_perm))
 
     def weight_unfold(self, G, ldg, N, Ci, KH=1, KW=1, gb=None, W=None, b=None, rs=None, cs=None, v=None, stem=False, dW=None,
-                      db=None, d_rs=None, d_cs=None, d_v=None, label=None):
+                      db=None, d_rs=None, d_cs=None, d_v=None, row_perm=None, label=None):
         d = L.WunfoldDesc()
         d.G, d.ldg, d.gb, d.W, d.b, d.rs, d.cs, d.v = _ptr(G), ldg, _ptr(gb), _ptr(W), _ptr(b), _ptr(rs), _ptr(cs), _ptr(v)
+        d.row_perm = _ptr(row_perm)
         d.N, d.Ci, d.KH, d.KW, d.stem = N, Ci, KH, KW, int(stem)
         d.dW, d.db, d.d_rs, d.d_cs, d.d_v = _ptr(dW), _ptr(db), _ptr(d_rs), _ptr(d_cs), _ptr(d_v)
-        self._add('ga_weight_unfold', (C.byref(d),), label, keep=(d, G, gb, W, b, rs, cs, v, dW, db, d_rs, d_cs, d_v))
+        self._add('ga_weight_unfold', (C.byref(d),), label, keep=(d, G, gb, W, b, rs, cs, v, dW, db, d_rs, d_cs, d_v, row_perm))
 
     # -- depthwise conv / norms ---------------------------------------------------------------------
     def dwconv7_fwd(self, x, w49, bias, y, B, H, W, Cdim, dtype, label=None):
@@ -158,18 +168,21 @@ class Plan:
                                      _ptr(mean_out), _ptr(rstd_out), _ptr(scale), _ptr(shift), Cdim, int(training)),
                   label, keep=(ssum, ssq, w, b, rmean, rvar, mean_out, rstd_out, scale, shift))
 
-    def affine_act(self, x, scale, shift, res, y, rows, Cdim, relu, dtype, label=None):
-        self._add('ga_affine_act', (_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y), rows, Cdim, int(relu), dtype),
-                  label, keep=(x, scale, shift, res, y))
+    def affine_act(self, x, scale, shift, res, y, rows, Cdim, relu, dtype, rowscale=None, rows_per_scale=1, label=None):
+        self._add('ga_affine_act', (_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(rowscale), rows_per_scale, _ptr(y),
+                                    rows, Cdim, int(relu), dtype), label, keep=(x, scale, shift, res, y, rowscale))
 
-    def bn_bwd_reduce(self, dy, y_relu, x, mean, rstd, s1, s2, rows, Cdim, dtype, label=None):
-        self._add('ga_bn_bwd_reduce', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2), rows,
-                                       Cdim, dtype), label, keep=(dy, y_relu, x, mean, rstd, s1, s2))
+    def bn_bwd_reduce(self, dy, y_relu, x, mean, rstd, s1, s2, rows, Cdim, dtype, rowscale=None, rows_per_scale=1,
+                      label=None):
+        self._add('ga_bn_bwd_reduce', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(rowscale),
+                                       rows_per_scale, _ptr(s1), _ptr(s2), rows, Cdim, dtype), label,
+                  keep=(dy, y_relu, x, mean, rstd, s1, s2, rowscale))
 
-    def bn_bwd_apply(self, dy, y_relu, x, mean, rstd, w, s1, s2, n, dx, rows, Cdim, dtype, label=None):
+    def bn_bwd_apply(self, dy, y_relu, x, mean, rstd, w, s1, s2, n, dx, rows, Cdim, dtype, rowscale=None,
+                     rows_per_scale=1, label=None):
         self._add('ga_bn_bwd_apply', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(s1), _ptr(s2),
-                                      n, _ptr(dx), rows, Cdim, dtype), label,
-                  keep=(dy, y_relu, x, mean, rstd, w, s1, s2, dx))
+                                      _ptr(rowscale), rows_per_scale, n, _ptr(dx), rows, Cdim, dtype), label,
+                  keep=(dy, y_relu, x, mean, rstd, w, s1, s2, dx, rowscale))
 
     # -- head ---------------------------------------------------------------------------------------
     def pool_concat_fwd(self, src, dst, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, mode, dtype, label=None):
@@ -187,8 +200,8 @@ class Plan:
         self._add('ga_se_mlp_fwd', (_ptr(s), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(hid), _ptr(gate), B, Cdim, R),
                   label, keep=(s, W1, b1, W2, b2, hid, gate))
 
-    def se_mlp_bwd(self, dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2, B, Cdim, R, label=None):
-        self._add('ga_se_mlp_bwd', (_ptr(dgate), _ptr(gate), _ptr(hid), _ptr(s), _ptr(W1), _ptr(W2), _ptr(ds), _ptr(dW1),
+    def se_mlp_bwd(self, dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2, B, Cdim, R, ds_scale=1.0, label=None):
+        self._add('ga_se_mlp_bwd', (_ptr(dgate), _ptr(gate), _ptr(hid), _ptr(s), _ptr(W1), _ptr(W2), _ptr(ds), ds_scale, _ptr(dW1),
                                     _ptr(db1), _ptr(dW2), _ptr(db2), B, Cdim, R), label,
                   keep=(dgate, gate, hid, s, W1, W2, ds, dW1, db1, dW2, db2))
 

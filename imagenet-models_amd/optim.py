@@ -1,0 +1,135 @@
+"""Fused flat optimizers (train.py:466,769): one kernel per weight-decay segment over the model's flat fp32
+parameter / gradient buffers.  torch.optim.SGD(nesterov) / torch.optim.AdamW arithmetic; timm's create_optimizer_v2
+weight-decay rule (no decay for ndim<=1 and *.bias) is baked into the flat layout ([decay | no-decay])."""
+import math
+
+import torch
+
+from .ops import Plan
+
+
+class _FlatOptimizer:
+    def __init__(self, model, lr, weight_decay):
+        st = model.flat_state()
+        self.model = model
+        self.p, self.g = st['params'], st['grads']
+        self.n_decay, self.total = st['n_decay'], st['total']
+        self.param_groups = [dict(lr=lr, weight_decay=weight_decay, initial_lr=lr)]
+        self.hp = torch.zeros(8, device=self.p.device)
+        self.steps = 0
+        self._hp_host = None
+
+    @property
+    def lr(self):
+        return self.param_groups[0]['lr']
+
+    def zero_grad(self, set_to_none=False):
+        self.g.zero_()
+
+    def _segments(self):
+        segs = []
+        if self.n_decay > 0:
+            segs.append((0, self.n_decay, 1.0))
+        if self.total > self.n_decay:
+            segs.append((self.n_decay, self.total - self.n_decay, 0.0))
+        return segs
+
+    def _push_hp(self, vals):
+        if vals != self._hp_host:
+            self.hp.copy_(torch.tensor(vals, dtype=torch.float32), non_blocking=True)
+            self._hp_host = vals
+
+    def _mark_dirty(self):
+        for e in self.model._engines.values():
+            e.weights_dirty = True
+
+
+class FusedSGD(_FlatOptimizer):
+    def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=0.0, nesterov=True):
+        super().__init__(model, lr, weight_decay)
+        self.momentum, self.nesterov = momentum, nesterov
+        self.buf = torch.zeros_like(self.p)
+        self.plan = Plan(name='sgd')
+        for off, n, mult in self._segments():
+            self.plan.sgd_step(self.p[off:], self.g[off:], self.buf[off:], self.hp, n, nesterov, mult)
+
+    def step(self):
+        g = self.param_groups[0]
+        self._push_hp([g['lr'], g['weight_decay'], self.momentum, 0.0, 0.0, 0.0, 0.0, 1.0 if self.steps == 0 else 0.0])
+        self.plan.run()
+        self.steps += 1
+        self._mark_dirty()
+
+    def state_dict(self):
+        return dict(kind='sgd', steps=self.steps, buf=self.buf.clone(), param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.steps = sd['steps']
+        self.buf.copy_(sd['buf'])
+        self.param_groups[0].update(sd['param_groups'][0])
+
+
+class FusedAdamW(_FlatOptimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(model, lr, weight_decay)
+        self.betas, self.eps = betas, eps
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.plan = Plan(name='adamw')
+        for off, n, mult in self._segments():
+            self.plan.adamw_step(self.p[off:], self.g[off:], self.m[off:], self.v[off:], self.hp, n, mult)
+
+    def step(self):
+        g = self.param_groups[0]
+        t = self.steps + 1
+        b1, b2 = self.betas
+        self._push_hp([g['lr'], g['weight_decay'], b1, b2, self.eps, 1 - b1 ** t, 1 - b2 ** t, 0.0])
+        self.plan.run()
+        self.steps = t
+        self._mark_dirty()
+
+    def state_dict(self):
+        return dict(kind='adamw', steps=self.steps, m=self.m.clone(), v=self.v.clone(),
+                    param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.steps = sd['steps']
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.param_groups[0].update(sd['param_groups'][0])
+
+
+def create_optimizer_v2(model, opt='sgd', lr=None, weight_decay=0., momentum=0.9, eps=None, betas=None, **_):
+    """timm.optim.create_optimizer_v2 surface for the optimizers the north-star names (sgd / momentum / nesterov / adamw)."""
+    opt = opt.lower()
+    if opt in ('sgd', 'nesterov'):
+        return FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
+    if opt == 'momentum':
+        return FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=False)
+    if opt == 'adamw':
+        return FusedAdamW(model, lr=lr, betas=betas or (0.9, 0.999), eps=eps or 1e-8, weight_decay=weight_decay)
+    raise ValueError(f'optimizer {opt!r} is not implemented on the HIP path yet (available: sgd, momentum, nesterov, adamw)')
+
+
+class CosineLRScheduler:
+    """timm cosine schedule stepped per epoch: linear warm-up from warmup_lr over warmup_epochs, then
+    lr = min_lr + 0.5 (base - min_lr)(1 + cos(pi t / T))."""
+
+    def __init__(self, optimizer, t_initial, lr_min=0.0, warmup_t=0, warmup_lr_init=0.0):
+        self.opt, self.T, self.lr_min, self.warmup_t, self.warmup_lr = optimizer, t_initial, lr_min, warmup_t, warmup_lr_init
+        self.base = [g['initial_lr'] for g in optimizer.param_groups]
+        if warmup_t:
+            for g in optimizer.param_groups:
+                g['lr'] = warmup_lr_init
+
+    def _lr(self, t, base):
+        if t < self.warmup_t:
+            return self.warmup_lr + t * (base - self.warmup_lr) / self.warmup_t
+        return self.lr_min + 0.5 * (base - self.lr_min) * (1 + math.cos(math.pi * min(t, self.T) / self.T))
+
+    def step(self, epoch, metric=None):
+        for g, base in zip(self.opt.param_groups, self.base):
+            g['lr'] = self._lr(epoch, base)
+
+    def step_update(self, num_updates, metric=None):
+        pass

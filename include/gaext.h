@@ -110,6 +110,7 @@ typedef struct {
     int64_t ldy, strideY;
     const void* X;
     int64_t ldx, strideX;
+    int x_batch_mod;       /* X batch index = z % x_batch_mod (0: = z) */
     int x_kind;            /* GA_A_* gather of X rows */
     int x_H, x_W, x_C;
     int x_act;             /* GA_ACT_GELU: X := gelu(X) while staging */
@@ -136,8 +137,9 @@ int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream);
 typedef struct {
     const float* w;
     int G, Co, Ci, KH, KW;
-    const float* rs;       /* [G*Co] or NULL */
+    const float* rs;       /* [G*Co] or NULL (indexed by the SOURCE row) */
     const float* cs;       /* [Ci] or NULL */
+    const int* row_perm;   /* [G*Co] or NULL: effective row n is master row row_perm[n] (channel_shuffle, ga_convnext.py:217,557) */
     int dtype;
     void* out;  int64_t ldo;   /* may be NULL */
     void* outT; int64_t ldt;   /* may be NULL */
@@ -145,9 +147,9 @@ typedef struct {
     int stem;
 } ga_wprep_desc;
 int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream);
-/* be[n] = rs[n] * (b[n] + sum_c W[n][c] * v[c])   (W fp32 [N][C]; b, rs, v may be NULL) */
-int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, float* be, int N, int C,
-                 ga_stream_t stream);
+/* be[n] = rs[m] * (b[m] + sum_c W[m][c] * v[c]), m = row_perm ? row_perm[n] : n   (W fp32 [N][C]; b, rs, v may be NULL) */
+int ga_bias_fold(const float* W, const float* b, const float* rs, const float* v, const int* row_perm, float* be, int N,
+                 int C, ga_stream_t stream);
 /* Inverse of the folding for gradients. G = d(effective weight) fp32 [N][ldg] with k=(ky,kx,ci); gb = d(effective bias),
  * where We = rs[n]*W*cs[ci] and be[n] = rs[n]*(b[n] + sum_c W[n][c]*v[c]):
  *   dW[n][ci][ky][kx] += rs[n]*(G*cs[ci] + gb[n]*v[ci]);  d_cs[ci] += sum rs[n]*G*W;
@@ -158,6 +160,7 @@ typedef struct {
     const float* gb;
     const float* W; const float* b;
     const float* rs; const float* cs; const float* v;
+    const int* row_perm;   /* rows of G / gb are effective rows; master row = row_perm[n] */
     int N, Ci, KH, KW;
     int stem;
     float* dW; float* db; float* d_rs; float* d_cs; float* d_v;
@@ -194,20 +197,22 @@ int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const floa
  * The column sums come from ga_gemm's colsum/colsumsq epilogue.
  *   finalize: mean/var (biased) -> scale = w*rstd, shift = b - mean*scale; running stats updated with the unbiased
  *             variance and `momentum`; training=0 builds scale/shift from the running stats instead.
- *   affine_act: y = x*scale[c] + shift[c] (+ res) (ReLU)             (scale/shift NULL: y = x + res)
- *   bwd_reduce: s1[c] += sum g, s2[c] += sum g*xhat, g = dy * (y_relu > 0 if given)
+ *   affine_act: y = (x*scale[c] + shift[c]) * rowscale[row/rows_per_scale] (+ res) (ReLU)   (scale/shift/rowscale NULL ok;
+ *               rowscale = the DropPath factor of the Bottleneck main branch, ga_convnext.py:310-311)
+ *   bwd_reduce: s1[c] += sum g, s2[c] += sum g*xhat, g = dy * (y_relu > 0 if given) * rowscale
  *   bwd_apply:  dx = w*rstd*(g - s1/n - xhat*s2/n)
  * ------------------------------------------------------------------------------------------------------------ */
 int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* w, const float* b, float eps,
                    float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
                    float* scale, float* shift, int C, int training, ga_stream_t stream);
-int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows, int C,
-                  int relu, int dtype, ga_stream_t stream);
-int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd, float* s1,
-                     float* s2, int64_t rows, int C, int dtype, ga_stream_t stream);
+int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* rowscale,
+                  int64_t rows_per_scale, void* y, int64_t rows, int C, int relu, int dtype, ga_stream_t stream);
+int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
+                     const float* rowscale, int64_t rows_per_scale, float* s1, float* s2, int64_t rows, int C, int dtype,
+                     ga_stream_t stream);
 int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
-                    const float* w, const float* s1, const float* s2, int64_t n, void* dx, int64_t rows, int C,
-                    int dtype, ga_stream_t stream);
+                    const float* w, const float* s1, const float* s2, const float* rowscale, int64_t rows_per_scale,
+                    int64_t n, void* dx, int64_t rows, int C, int dtype, ga_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-scale aggregate (ga_convnext.py:396-397,479-483): write pool(src) into channels [c_off, c_off+C) of the
@@ -222,15 +227,15 @@ int ga_pool_concat_bwd(const void* dcat, const void* dres, void* dsrc, int B, in
 /* Squeeze-excite (timm SEModule via create_attn('se'), ga_convnext.py:279,305):
  *   ga_spatial_sum: out[b][c] = scale * sum_hw a[b,hw,c] (* b2[b,hw,c] if given)      (fp32 [B][C])
  *   ga_se_mlp_fwd:  gate = sigmoid(W2 relu(W1 s + b1) + b2)  (W1 [R][C], W2 [C][R], fp32 master weights)
- *   ga_se_mlp_bwd:  ds = d(pooled mean), parameter gradients accumulated with atomics
+ *   ga_se_mlp_bwd:  ds = ds_scale * d(pooled mean), parameter gradients accumulated with atomics
  *   ga_chan_scale:  y[b,hw,c] = x*g[b][c] + add[b][c]   (g/add may be NULL) */
 int ga_spatial_sum(const void* a, const void* b2, float* out, int B, int HW, int C, float scale, int dtype,
                    ga_stream_t stream);
 int ga_se_mlp_fwd(const float* s, const float* W1, const float* b1, const float* W2, const float* b2, float* hid,
                   float* gate, int B, int C, int R, ga_stream_t stream);
 int ga_se_mlp_bwd(const float* dgate, const float* gate, const float* hid, const float* s, const float* W1,
-                  const float* W2, float* ds, float* dW1, float* db1, float* dW2, float* db2, int B, int C, int R,
-                  ga_stream_t stream);
+                  const float* W2, float* ds, float ds_scale, float* dW1, float* db1, float* dW2, float* db2, int B,
+                  int C, int R, ga_stream_t stream);
 int ga_chan_scale(const void* x, const float* g, const float* add, void* y, int B, int HW, int C, int dtype,
                   ga_stream_t stream);
 

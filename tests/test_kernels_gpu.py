@@ -472,9 +472,8 @@ def test_squeeze_excite(dt):
     ds = torch.empty(Bn, Cc, device='cuda')
     dW1 = torch.zeros(Rr, Cc, device='cuda'); db1 = torch.zeros(Rr, device='cuda')
     dW2 = torch.zeros(Cc, Rr, device='cuda'); db2 = torch.zeros(Cc, device='cuda')
-    P.se_mlp_bwd(dgate, gate, hid, s, W1.cuda(), W2.cuda(), ds, dW1, db1, dW2, db2, Bn, Cc, Rr)
+    P.se_mlp_bwd(dgate, gate, hid, s, W1.cuda(), W2.cuda(), ds, dW1, db1, dW2, db2, Bn, Cc, Rr, ds_scale=1.0 / HW)
     DX = torch.empty_like(X)
-    ds.mul_(1.0 / HW)
     P.chan_scale(DZ, gate, ds, DX, Bn, HW, Cc, ops.ga_dtype(dt))
     assert_close(DX, lx.grad, tol(dt, 2), 'se bwd dx')
     for got, leaf, nm in ((dW1, lW1, 'dW1'), (db1, lb1, 'db1'), (dW2, lW2, 'dW2'), (db2, lb2, 'db2')):

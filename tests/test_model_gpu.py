@@ -1,0 +1,235 @@
+"""GPU parity of the whole GA-ConvNeXt path (HIP kernels through the C ABI) against the oracle restatement and
+the committed golden vectors from the real reference.
+
+Tolerances (north_star: 1e-3 relative fp32, bit-exact top-k):
+  fp32 math mode: logits / loss 1e-3 relative to the tensor max, gradients 2e-2 under oracle.grad_errors
+  (the reference's own fp32 backward is 4e-3 from a float64 run), top-5 indices bit-exact;
+  bf16 mode: logits 6e-2, loss 2e-2, gradients 0.25 (reported, not the parity gate)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+V2 = dict(dims=(16, 32, 64, 128, 128), depths=(1, 1, 6, 1, 1), gram_dim=32, dim_embed=64, num_classes=40, naggre=2)
+
+
+def _oracle():
+    from oracle import ga_convnext_oracle as O
+    return O
+
+
+def build(cfg, mode, drop_path=0.0):
+    import imagenet_models_amd as A
+    m = A.GA_ConvNeXt(num_classes=cfg['num_classes'], depths=cfg['depths'], dims=cfg['dims'],
+                      gram_embedding_gropus=cfg['gram_groups'], dim_embed=cfg['dim_embed'], stage3_naggre=cfg['naggre'],
+                      gram_dim=cfg['gram_dim'], drop_path_rate=drop_path, math_mode=mode)
+    O = _oracle()
+    sd = O.fill_state(cfg)
+    m.load_state_dict(sd)
+    return m.cuda(), sd
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name))
+    cfg = json.loads(str(z['cfg']))
+    cfg['depths'], cfg['dims'] = tuple(cfg['depths']), tuple(cfg['dims'])
+    return z, cfg
+
+
+def test_state_dict_layout_and_registry():
+    import imagenet_models_amd as A
+    O = _oracle()
+    m = A.create_model('ga_convnext_tiny_768', pretrained=False, num_classes=1000, drop_rate=None, drop_path_rate=None)
+    shapes = O.state_shapes(O.make_cfg('ga_convnext_tiny_768'))
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    assert m.num_classes == 1000
+    m = m.cuda()
+    st = m.flat_state()
+    assert st['total'] == 54354584
+    # parameters and gradients alias the flat buffers
+    p = dict(m.named_parameters())['stages.2.blocks.0.conv_dw.weight']
+    assert p.data_ptr() >= st['params'].data_ptr() and p.grad.data_ptr() >= st['grads'].data_ptr()
+
+
+@pytest.mark.parametrize('mode,tol', [('fp32', 1e-3), ('bf16', 6e-2)])
+def test_v2_eval_logits_topk(mode, tol):
+    O = _oracle()
+    z, cfg = load_golden('v2_eval.npz')
+    m, sd = build(cfg, mode)
+    m.eval()
+    x = O.gen_input(int(z['batch']), seed=0)
+    with torch.no_grad():
+        outs = m(x.cuda())
+        ref = O.forward(sd, x, cfg, training=False)
+    assert len(outs) == 5 and outs[0].shape == (2, 40) and outs[0].dtype == torch.float32
+    err = max(rel(a, b) for a, b in zip(outs, ref))
+    gerr = rel(torch.stack(outs), torch.from_numpy(z['logits']))
+    print(f'[{mode}] eval logits rel err vs oracle {err:.3e}, vs reference golden {gerr:.3e}')
+    assert err < tol and gerr < tol
+    if mode == 'fp32':
+        import imagenet_models_amd as A
+        _, idx = A.heads_topk(outs, 5)
+        assert np.array_equal(idx.cpu().numpy(), z['top5'])      # bit-exact vs the reference
+
+
+def _train_compare(mode, batch, golden, tol_out, tol_loss, tol_grad, drop_path=0.0):
+    import imagenet_models_amd as A
+    O = _oracle()
+    z, cfg = load_golden(golden)
+    cfg['drop_path_rate'] = drop_path
+    m, sd = build(cfg, mode, drop_path)
+    m.train()
+    x = O.gen_input(batch, seed=1)
+    target = torch.from_numpy(z['target'])[:batch] if batch <= len(z['target']) else None
+    lam = float(z['lam'])
+    masks = None
+    if drop_path > 0:
+        eng = m.engine(batch, True)
+        g = torch.Generator().manual_seed(5)
+        masks = {}
+        for pre in eng.dp_scale:
+            keep = 1 - eng.dp_rates[pre]
+            masks[pre] = (torch.rand(batch, generator=g) < keep).float() / keep
+        eng.set_drop_path_masks(masks)
+        eng.fixed_masks = True
+    m.zero_grad()
+    outs = m(x.cuda())
+    loss = A.ga_loss(outs, target.cuda(), lam)
+    loss.backward()
+    oloss, oouts, ograds, ostats = O.train_step_grads(sd, x, target, cfg, lam=lam, dp_masks=masks)
+    e_out = max(rel(a, b) for a, b in zip(outs, oouts))
+    e_loss = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    errs = O.grad_errors(grads, ograds)
+    if mode == 'bf16':
+        # parameters whose true gradient is analytically zero (biases feeding a train-mode BatchNorm) only hold
+        # rounding noise, which bf16 activations at B=4 amplify through the tiny batch variance: not informative
+        gmax = max(float(g.abs().max()) for g in ograds.values())
+        errs = {n: e for n, e in errs.items() if float(ograds[n].abs().max()) >= 1e-4 * gmax}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    new_sd = m.state_dict()
+    e_bn = max(rel(new_sd[n], ostats[n].float()) for n in ostats if not n.endswith('num_batches_tracked'))
+    print(f'[{mode} B={batch} dp={drop_path}] logits {e_out:.2e} loss {e_loss:.2e} bn {e_bn:.2e} worst grads {worst}')
+    assert e_out < tol_out and e_loss < tol_loss
+    assert worst[0][1] < tol_grad, worst
+    assert e_bn < max(tol_out, 2e-3)
+    assert int(new_sd['stages.4.bn1.num_batches_tracked']) == 1
+    return z, outs, loss, grads
+
+
+def test_v2_train_step_fp32_vs_oracle_and_reference():
+    z, outs, loss, grads = _train_compare('fp32', 4, 'v2_train_b4.npz', 1e-3, 1e-3, 2e-2)
+    # and against the REAL reference's numbers (golden): logits, loss, per-parameter gradient norms
+    assert rel(torch.stack(outs), torch.from_numpy(z['logits'])) < 1e-3
+    assert abs(float(loss) - float(z['loss'])) / abs(float(z['loss'])) < 1e-3
+    names = [str(n) for n in z['grad_names']]
+    gmax = float(np.abs(z['grad_head']).max())
+    for i, n in enumerate(names):
+        ref_norm = float(z['grad_norm'][i])
+        if ref_norm > 1e-2 * gmax:
+            assert abs(float(grads[n].double().norm()) - ref_norm) / ref_norm < 2e-2, n
+
+
+def test_v2_train_step_fp32_b128_fp32_gram_branch():
+    _train_compare('fp32', 128, 'v2_train_b128.npz', 1e-3, 1e-3, 3e-2)
+
+
+def test_v2_train_step_fp32_with_drop_path_masks():
+    _train_compare('fp32', 4, 'v2_train_b4.npz', 1e-3, 1e-3, 2e-2, drop_path=0.3)
+
+
+def test_v2_train_step_bf16():
+    _train_compare('bf16', 4, 'v2_train_b4.npz', 6e-2, 2e-2, 0.35)
+
+
+def test_t768_eval_fp32_vs_reference_golden():
+    import imagenet_models_amd as A
+    O = _oracle()
+    z, cfg = load_golden('t768_eval.npz')
+    m = A.create_model('ga_convnext_tiny_768', math_mode='fp32')
+    sd = O.fill_state(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    assert sum(p.numel() for p in m.parameters()) == int(z['param_count'])
+    x = O.gen_input(int(z['batch']), seed=0)
+    with torch.no_grad():
+        outs = m(x.cuda())
+    got = torch.stack(outs)[:, :, :16]
+    err = rel(got, torch.from_numpy(z['logits']))
+    print(f'[t768 fp32] eval logits rel err vs reference golden {err:.3e}')
+    assert err < 1e-3
+    _, idx = A.heads_topk(outs, 5)
+    assert np.array_equal(idx.cpu().numpy(), z['top5'])
+
+
+def test_t768_train_step_fp32_vs_reference_golden():
+    import imagenet_models_amd as A
+    O = _oracle()
+    z, cfg = load_golden('t768_train_b4.npz')
+    m = A.create_model('ga_convnext_tiny_768', math_mode='fp32')
+    m.load_state_dict(O.fill_state(cfg))
+    m = m.cuda().train()
+    x = O.gen_input(4, seed=1)
+    target = torch.from_numpy(z['target'])
+    m.zero_grad()
+    outs = m(x.cuda())
+    loss = A.ga_loss(outs, target.cuda(), float(z['lam']))
+    loss.backward()
+    assert rel(torch.stack(outs)[:, :, :40], torch.from_numpy(z['logits'])) < 1e-3
+    assert abs(float(loss) - float(z['loss'])) / abs(float(z['loss'])) < 1e-3
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    names = [str(n) for n in z['grad_names']]
+    gmax = float(np.abs(z['grad_head']).max())
+    bad = []
+    for i, n in enumerate(names):
+        ref_norm = float(z['grad_norm'][i])
+        if ref_norm > 1e-2 * gmax:
+            e = abs(float(grads[n].double().norm()) - ref_norm) / ref_norm
+            if e > 2e-2:
+                bad.append((n, e))
+        head = grads[n].reshape(-1)[:16].numpy()
+        ref_head = z['grad_head'][i][:head.size]
+        if np.abs(head - ref_head).max() > 2e-2 * max(np.abs(ref_head).max(), 1e-2 * gmax):
+            bad.append((n, 'head'))
+    assert not bad, bad[:10]
+
+
+def test_optimizer_step_on_flat_buffers():
+    import imagenet_models_amd as A
+    O = _oracle()
+    cfg = O.make_cfg(**V2)
+    for kind in ('sgd', 'adamw'):
+        m, sd = build(cfg, 'fp32')
+        opt = A.create_optimizer_v2(m, opt=kind, lr=0.05, weight_decay=0.05, momentum=0.9)
+        st = m.flat_state()
+        g = torch.Generator().manual_seed(1)
+        st['grads'].copy_(torch.randn(st['total'], generator=g).cuda())
+        params = {n: p.detach().cpu().clone() for n, p in m.named_parameters()}
+        grads = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+        opt.step()
+        if kind == 'sgd':
+            want, _ = O.sgd_nesterov_step(params, grads, {}, 0.05, 0.9, 0.05, first=True)
+        else:
+            want, _, _ = O.adamw_step(params, grads, {}, {}, 1, 0.05, (0.9, 0.999), 1e-8, 0.05)
+        for n, p in m.named_parameters():
+            assert torch.allclose(p.detach().cpu(), want[n], atol=2e-6, rtol=1e-5), (kind, n)
+
+
+def test_no_cpu_fallback():
+    import imagenet_models_amd as A
+    m = A.create_model('ga_convnext_tiny_768')
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(torch.zeros(1, 3, 224, 224))
