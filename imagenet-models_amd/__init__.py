@@ -14,3 +14,4 @@ from . import ga_convnext  # noqa: E402,F401  (registers the ga_convnext_* entry
 from .ga_convnext import GA_ConvNeXt  # noqa: E402,F401
 from .loss import ga_loss, heads_topk, accuracy_from_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, CosineLRScheduler  # noqa: E402,F401
+from .trainer import TrainStep  # noqa: E402,F401

@@ -94,11 +94,26 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
 // ----------------------------------------------------------------------------------------------
 // activations
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU default, ga_convnext.py:94) through Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7):
+// one v_rcp + one v_exp + ~12 FMAs instead of the libm erff call, since GELU / GELU' are RE-COMPUTED inside the
+// GEMM operand loader and epilogue instead of being stored.  E = exp(-x^2/2) is shared by GELU'.
+__device__ __forceinline__ float gelu_cdf_f(float x, float* e_out) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-z * z);           // exp(-x^2/2)
+    const float half_erfc = 0.5f * p * t * e; // 0.5 * erfc(|x|/sqrt2)
+    if (e_out) *e_out = e;
+    return x >= 0.f ? 1.0f - half_erfc : half_erfc;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * gelu_cdf_f(x, nullptr); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float e;
+    const float cdf = gelu_cdf_f(x, &e);
+    return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -15,15 +15,23 @@
 //    transposing LDS read, on a [rows][128] image whose 32-byte pieces are XOR-swizzled conflict-free.
 //  * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous chunk of the tile list so that
 //    workgroups sharing an operand panel hit the same L2.
+#include <algorithm>
 #include "common.h"
 
 namespace {
 
-constexpr int kBM = 128, kBN = 128, kThreads = 256;
+int num_cus() {
+    static int n = [] {
+        int c = 256;
+        ga_device_info(&c, nullptr, nullptr);
+        return c;
+    }();
+    return n;
+}
+
+constexpr int kBM = 128, kThreads = 256;
 constexpr int kRowBytes = 128;          // bytes of K per LDS row (NT kernel)
 constexpr int kTileBytes = kBM * kRowBytes;  // 16 KiB per operand per buffer
-constexpr int kLdc = 132;               // padded fp32 row stride of the staged C tile
-constexpr int kSmemNT = kBM * kLdc * 4; // 67584 B >= 4 * kTileBytes
 
 // bijective XCD-aware remap of a linear workgroup id (guide T1): blocks b, b+8, b+16.. share an XCD
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -149,21 +157,36 @@ template <typename T> __device__ __forceinline__ uint4 act_chunk(uint4 v, int ac
 }
 
 // ================================================================================================
-// NT kernel
+// NT kernel.  Tile = 128 rows x BN columns (BN = 32*TNW = 64 / 96 / 128), 256 threads = 4 waves as 2(M) x 2(N),
+// each wave 64 x 16*TNW.  One 128-byte K slab of A and B lives in LDS (single buffer, <= 32 KiB) while the NEXT
+// slab is already in flight in registers; the fp32 result tile is staged through the same LDS in two 64-row
+// halves (<= 34 KiB).  Small LDS + <= 128 VGPRs (TNW <= 3) give 4 resident workgroups per CU, i.e. >= 100 KiB of
+// loads in flight per CU -- these GEMMs (K, N <= 3072, M ~ 10^6) are HBM-latency bound, not MFMA bound.
 // ================================================================================================
-template <typename T>
-__global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const ga_gemm_desc d) {
+template <int TNW> struct NTCfg {
+    static constexpr int BN = 32 * TNW;
+    static constexpr int LDCS = BN + 4;                       // padded fp32 row stride of the staged half tile
+    static constexpr int SMEM_AB = kTileBytes + BN * kRowBytes;
+    static constexpr int SMEM_C = 64 * LDCS * 4;
+    static constexpr int SMEM = SMEM_AB > SMEM_C ? SMEM_AB : SMEM_C;
+    static constexpr int P8 = BN / 8;                         // 8-column pieces per row
+    static constexpr int RG = kThreads / P8;                  // row groups in the coalesced store phase
+};
+
+template <typename T, int TNW, bool PLAIN>
+__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d) {
+    using CF = NTCfg<TNW>;
     constexpr int EPC = elt<T>::EPC;
     constexpr int BK = kRowBytes / (int)sizeof(T);
+    constexpr int BN = CF::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + kTileBytes;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (d.N + kBN - 1) / kBN, tiles_m = (d.M + kBM - 1) / kBM;
+    const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + kBM - 1) / kBM;
     const int nwg = tiles_n * tiles_m;
-    const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * kBM, n0 = tile_n * kBN;
     const int z = blockIdx.z;
     const int za = d.a_batch_mod > 0 ? z % d.a_batch_mod : z;
 
@@ -171,234 +194,266 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nt_kernel(const ga_gemm_desc
                               (d.a_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * za * d.strideA;
     const T* Bb = reinterpret_cast<const T*>(d.B) + z * d.strideB;
 
-    // ---- staging roles: thread stages rows r0+32*i (i=0..3), chunk column kc, of both operands
+    // ---- staging roles: thread stages rows r0+32*i of A (i<4) and of B (i<TNW), chunk column kc
     const int kc = tid & 7, r0 = tid >> 3;
-    RowCtx arow[4];
-    long brow[4];
-    bool bval[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        arow[i] = make_row(d.a_kind, (long)m0 + r0 + 32 * i, d.M, d.lda, d.a_H, d.a_W, d.a_C);
-        const int n = n0 + r0 + 32 * i;
-        bval[i] = n < d.N;
-        brow[i] = (long)n * d.ldb;
-    }
     const int nk = (d.K + BK - 1) / BK;
-
-    uint4 ra[4], rb[4];
-    auto g_load = [&](int kt) {
-        const int k = kt * BK + kc * EPC;
-        const KCtx kx = make_k(d.a_kind, k, d.K, d.a_H, d.a_W, d.a_C);
+    RowCtx arow[PLAIN ? 1 : 4];   // gather kinds keep a full context per staged row; PLAIN only needs m0
+    int m0 = 0, n0 = 0;
+    // PERSISTENT over output tiles: workgroup b takes tiles b, b+G, b+2G, ... (through the XCD-aware remap, so
+    // the workgroups of one XCD walk neighbouring tiles and share A panels in its L2); the first K slab of the
+    // NEXT tile is already in flight while the current tile's epilogue runs.
+    auto set_tile = [&](int vt) {
+        const int bid = xcd_remap(vt, nwg);
+        const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+        m0 = tile_m * kBM;
+        n0 = tile_n * BN;
+        if constexpr (!PLAIN) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = load_chunk<T>(d.a_kind, Ab, arow[i], kx, d.a_H, d.a_W, d.a_C);
-        const bool kv = k < d.K;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            rb[i] = (kv && bval[i]) ? *reinterpret_cast<const uint4*>(Bb + brow[i] + k) : make_uint4(0, 0, 0, 0);
-    };
-    auto s_store = [&](int buf) {
-        unsigned char* As = smem + buf * 2 * kTileBytes;
-        unsigned char* Bs = As + kTileBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = r0 + 32 * i;
-            const int off = row * kRowBytes + ((kc ^ (row & 7)) << 4);
-            *reinterpret_cast<uint4*>(As + off) = act_chunk<T>(ra[i], d.a_act);
-            *reinterpret_cast<uint4*>(Bs + off) = rb[i];
+            for (int i = 0; i < 4; ++i)
+                arow[i] = make_row(d.a_kind, (long)m0 + r0 + 32 * i, d.M, d.lda, d.a_H, d.a_W, d.a_C);
         }
     };
 
-    f32x4_t acc[4][4];  // [tn][tm]
+    uint4 ra[4], rb[TNW];
+    auto g_load = [&](int kt) {
+        const int k = kt * BK + kc * EPC;
+        const bool kv = k < d.K;
+        if constexpr (PLAIN) {
+            const T* Ap = reinterpret_cast<const T*>(Ab) + k;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                const long m = (long)m0 + r0 + 32 * i;
+                ra[i] = (kv && m < d.M) ? *reinterpret_cast<const uint4*>(Ap + m * d.lda) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+            const KCtx kx = make_k(d.a_kind, k, d.K, d.a_H, d.a_W, d.a_C);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = load_chunk<T>(d.a_kind, Ab, arow[i], kx, d.a_H, d.a_W, d.a_C);
+        }
+#pragma unroll
+        for (int i = 0; i < TNW; ++i) {
+            const long n = (long)n0 + r0 + 32 * i;
+            rb[i] = (kv && n < d.N) ? *reinterpret_cast<const uint4*>(Bb + n * d.ldb + k) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto s_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(As + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = act_chunk<T>(ra[i], d.a_act);
+        }
+#pragma unroll
+        for (int i = 0; i < TNW; ++i) {
+            const int row = r0 + 32 * i;
+            *reinterpret_cast<uint4*>(Bs + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = rb[i];
+        }
+    };
+
+    const T* Hb = d.H ? reinterpret_cast<const T*>(d.H) + z * d.strideH : nullptr;
+    const T* Rb = d.R ? reinterpret_cast<const T*>(d.R) + z * d.strideR : nullptr;
+    float* Cs = reinterpret_cast<float*>(smem);
+    const int c8 = tid % CF::P8, rg = tid / CF::P8;   // this thread's 8-column piece / first row of the half
+    const bool t_active = rg < CF::RG;
+
+    int vt = blockIdx.x;
+    set_tile(vt);
+    g_load(0);
+    for (; vt < nwg; ) {
+    const int cm0 = m0, cn0 = n0;   // the tile being computed (m0/n0 move on to the prefetched tile below)
+    f32x4_t acc[TNW][4];  // [tn][tm]
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    g_load(0);
-    s_store(0);
+    s_store();
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
         if (kt + 1 < nk) g_load(kt + 1);
-        const unsigned char* As = smem + cur * 2 * kTileBytes;
-        const unsigned char* Bs = As + kTileBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + (lane >> 4);
-            uint4 af[4], bf[4];
+            uint4 af[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ra_ = wm * 64 + t * 16 + (lane & 15);
                 af[t] = *reinterpret_cast<const uint4*>(As + ra_ * kRowBytes + ((chunk ^ (ra_ & 7)) << 4));
-                const int rb_ = wn * 64 + t * 16 + (lane & 15);
-                bf[t] = *reinterpret_cast<const uint4*>(Bs + rb_ * kRowBytes + ((chunk ^ (rb_ & 7)) << 4));
             }
-            if constexpr (sizeof(T) == 2) {
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn)
+            for (int tn = 0; tn < TNW; ++tn) {
+                const int rb_ = wn * (16 * TNW) + tn * 16 + (lane & 15);
+                const uint4 bf = *reinterpret_cast<const uint4*>(Bs + rb_ * kRowBytes + ((chunk ^ (rb_ & 7)) << 4));
+                if constexpr (sizeof(T) == 2) {
 #pragma unroll
                     for (int tm = 0; tm < 4; ++tm)
                         acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            *reinterpret_cast<const bf16x8_t*>(&bf[tn]), *reinterpret_cast<const bf16x8_t*>(&af[tm]),
+                            *reinterpret_cast<const bf16x8_t*>(&bf), *reinterpret_cast<const bf16x8_t*>(&af[tm]),
                             acc[tn][tm], 0, 0, 0);
-            } else {
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn)
+                    for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int tm = 0; tm < 4; ++tm)
                             acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                reinterpret_cast<const float*>(&bf[tn])[j], reinterpret_cast<const float*>(&af[tm])[j],
+                                reinterpret_cast<const float*>(&bf)[j], reinterpret_cast<const float*>(&af[tm])[j],
                                 acc[tn][tm], 0, 0, 0);
+                }
             }
         }
-        if (kt + 1 < nk) s_store(cur ^ 1);
-        __syncthreads();
+        __syncthreads();  // every wave is done reading this slab
+        if (kt + 1 < nk) {
+            s_store();
+            __syncthreads();
+        }
+    }
+    // start fetching the next tile's first slab; it lands while this tile's epilogue runs
+    vt += gridDim.x;
+    if (vt < nwg) {
+        set_tile(vt);
+        g_load(0);
     }
 
-    // ---- stage the fp32 tile through LDS: Cs[m][n], lane holds 4 consecutive n of one m
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) {
-            const int m = wm * 64 + tm * 16 + (lane & 15);
-            const int n = wn * 64 + tn * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<f32x4_t*>(Cs + m * kLdc + n) = acc[tn][tm];
-        }
-    __syncthreads();
-
-    // ---- fused epilogue on 8-column pieces; thread owns column group c8 and rows (tid>>4) + 16*i
-    const int c8 = tid & 15;
-    const int n = n0 + c8 * 8;
+    // ---- fused epilogue, two 64-row halves staged through LDS as fp32 [64][BN+4]
+    const int n = cn0 + c8 * 8;
+    const bool n_ok = t_active && n < d.N;
     const bool full = n + 8 <= d.N;
     float bias[8], csum[8], csq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        bias[j] = (d.bias && n + j < d.N) ? d.bias[z * d.strideBias + n + j] : 0.f;
+        bias[j] = (d.bias && n_ok && n + j < d.N) ? d.bias[z * d.strideBias + n + j] : 0.f;
         csum[j] = csq[j] = 0.f;
     }
-    const T* Hb = d.H ? reinterpret_cast<const T*>(d.H) + z * d.strideH : nullptr;
-    const T* Rb = d.R ? reinterpret_cast<const T*>(d.R) + z * d.strideR : nullptr;
-    // scatter target decomposition (UNPATCH2): n -> (tap, c)
     long c_off = 0;
-    if (d.c_kind == GA_C_UNPATCH2 && n < d.N) {
+    if (d.c_kind == GA_C_UNPATCH2 && n_ok) {
         const int tap = n / d.c_C, ch = n - tap * d.c_C;
         c_off = ((long)(tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch;
     }
-    if (n < d.N) {
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        if (half) __syncthreads();  // previous half fully read
+        if (wm == half) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = (tid >> 4) + 16 * i;
-            const long m = (long)m0 + row;
-            if (m >= d.M) break;
-            float v[8];
-            {
-                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Cs + row * kLdc + c8 * 8);
-                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Cs + row * kLdc + c8 * 8 + 4);
-                v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-                v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-            }
+            for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha + bias[j];
-            if (d.act == GA_ACT_GELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-            } else if (d.act == GA_ACT_RELU) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (Hb) {
-                float h[8];
-                if (full) {
-                    load8(Hb + m * d.ldh + n, h);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
+                for (int tm = 0; tm < 4; ++tm)
+                    *reinterpret_cast<f32x4_t*>(Cs + (tm * 16 + (lane & 15)) * CF::LDCS + wn * (16 * TNW) + tn * 16 +
+                                                (lane >> 4) * 4) = acc[tn][tm];
+        }
+        __syncthreads();
+        if (n_ok) {
+            for (int row = rg; row < 64; row += CF::RG) {
+                const long m = (long)cm0 + half * 64 + row;
+                if (m >= d.M) break;
+                float v[8];
+                {
+                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Cs + row * CF::LDCS + c8 * 8);
+                    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Cs + row * CF::LDCS + c8 * 8 + 4);
+                    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+                    v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
-            }
-            if (d.rowscale) {
-                const float s = d.rowscale[m / d.rows_per_scale];
+                for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha + bias[j];
+                if (d.act == GA_ACT_GELU) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] *= s;
-            }
-            if (Rb) {
-                float r[8];
-                if (full) {
-                    load8(Rb + m * d.ldr + n, r);
-                } else {
+                    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                } else if (d.act == GA_ACT_RELU) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) r[j] = n + j < d.N ? elt<T>::ld(Rb + m * d.ldr + n + j) : 0.f;
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
+                if (Hb) {
+                    float h[8];
+                    if (full) {
+                        load8(Hb + m * d.ldh + n, h);
+                    } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += r[j];
-            }
-            if (d.relu_after) {
+                        for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
+                    }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-            }
-            if (d.colsum) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    csum[j] += v[j];
-                    csq[j] += v[j] * v[j];
+                    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
                 }
-            }
-            // ---- store
-            long off;
-            if (d.c_kind == GA_C_UNPATCH2) {
-                const int OW = d.c_W >> 1, OH = d.c_H >> 1;
-                const int ox = (int)(m % OW);
-                const long t = m / OW;
-                const int oy = (int)(t % OH);
-                const long b = t / OH;
-                off = ((b * d.c_H + 2 * oy) * d.c_W + 2 * ox) * (long)d.c_C + c_off;
-            } else {
-                off = z * d.strideC + m * d.ldc + n;
-            }
-            if (d.c_f32) {
-                float* Cp = reinterpret_cast<float*>(d.C) + off;
-                if (full) {
-                    store8(Cp, v);
-                } else {
+                if (d.rowscale) {
+                    const float s = d.rowscale[m / d.rows_per_scale];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (n + j < d.N) Cp[j] = v[j];
+                    for (int j = 0; j < 8; ++j) v[j] *= s;
                 }
-            } else {
-                T* Cp = reinterpret_cast<T*>(d.C) + off;
-                if (full) {
-                    store8(Cp, v);
-                } else {
+                if (Rb) {
+                    float r[8];
+                    if (full) {
+                        load8(Rb + m * d.ldr + n, r);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (n + j < d.N) elt<T>::st(Cp + j, v[j]);
+                        for (int j = 0; j < 8; ++j) r[j] = n + j < d.N ? elt<T>::ld(Rb + m * d.ldr + n + j) : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += r[j];
+                }
+                if (d.relu_after) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                }
+                if (d.colsum) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        csum[j] += v[j];
+                        csq[j] += v[j] * v[j];
+                    }
+                }
+                long off;
+                if (d.c_kind == GA_C_UNPATCH2) {
+                    const int OW = d.c_W >> 1, OH = d.c_H >> 1;
+                    const int ox = (int)(m % OW);
+                    const long t = m / OW;
+                    const int oy = (int)(t % OH);
+                    const long b = t / OH;
+                    off = ((b * d.c_H + 2 * oy) * d.c_W + 2 * ox) * (long)d.c_C + c_off;
+                } else {
+                    off = z * d.strideC + m * d.ldc + n;
+                }
+                if (d.c_f32) {
+                    float* Cp = reinterpret_cast<float*>(d.C) + off;
+                    if (full) {
+                        store8(Cp, v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (n + j < d.N) Cp[j] = v[j];
+                    }
+                } else {
+                    T* Cp = reinterpret_cast<T*>(d.C) + off;
+                    if (full) {
+                        store8(Cp, v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (n + j < d.N) elt<T>::st(Cp + j, v[j]);
+                    }
                 }
             }
         }
     }
-    if (d.colsum) {  // workgroup-level column reduction, then one atomic per column
+    if (d.colsum) {  // workgroup-level column reduction over the RG row groups, then one atomic per column
         __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);  // [2][16][128]
+        float* red = reinterpret_cast<float*>(smem);  // [2][RG][BN]
+        if (t_active) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            red[(tid >> 4) * 128 + c8 * 8 + j] = csum[j];
-            red[2048 + (tid >> 4) * 128 + c8 * 8 + j] = csq[j];
+            for (int j = 0; j < 8; ++j) {
+                red[rg * BN + c8 * 8 + j] = csum[j];
+                red[CF::RG * BN + rg * BN + c8 * 8 + j] = csq[j];
+            }
         }
         __syncthreads();
-        const int col = tid & 127, which = tid >> 7;
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s += red[which * 2048 + r * 128 + col];
-        if (n0 + col < d.N) {
-            if (which == 0) atomicAdd(d.colsum + z * d.strideCol + n0 + col, s);
-            else if (d.colsumsq) atomicAdd(d.colsumsq + z * d.strideCol + n0 + col, s);
+        for (int i = tid; i < 2 * BN; i += kThreads) {
+            const int which = i / BN, col = i - which * BN;
+            if (cn0 + col < d.N && (which == 0 || d.colsumsq)) {
+                float s = 0.f;
+                for (int r = 0; r < CF::RG; ++r) s += red[which * CF::RG * BN + r * BN + col];
+                atomicAdd((which ? d.colsumsq : d.colsum) + z * d.strideCol + cn0 + col, s);
+            }
         }
     }
+    __syncthreads();  // LDS (C staging / reduction scratch) is free for the next tile's slab
+    }  // persistent tile loop
 }
 
 // ================================================================================================
@@ -614,23 +669,31 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
     // vector stores need an 8-element aligned leading dimension; otherwise every piece takes the scalar path,
     // which the kernel selects per piece only at the N edge -> require it here.
     GA_REQUIRE(d->c_kind != GA_C_PLAIN || d->ldc % 8 == 0, "ga_gemm: ldc=%ld must be a multiple of 8", (long)d->ldc);
-    const int tiles = cdiv(d->M, kBM) * cdiv(d->N, kBN);
-    dim3 grid(tiles, 1, d->batch), block(kThreads);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const bool attr_ok = [] {  // > 64 KiB of dynamic LDS has to be opted into once per kernel
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<bf16_t>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSmemNT) == hipSuccess &&
-               hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<float>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSmemNT) == hipSuccess;
-    }();
-    if (!attr_ok) {
-        ga_set_error("ga_gemm: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", kSmemNT);
-        return GA_ERR_HIP;
+    // N-tile width: 128 when it divides N, else 96 (stage-0 C = 96, concat 2208 = 23*96), else 64; ragged N -> least waste
+    int tnw;
+    if (d->N % 128 == 0) tnw = 4;
+    else if (d->N % 96 == 0) tnw = 3;
+    else if (d->N % 64 == 0) tnw = 2;
+    else {
+        const long w4 = (long)cdiv(d->N, 128) * 128, w3 = (long)cdiv(d->N, 96) * 96, w2 = (long)cdiv(d->N, 64) * 64;
+        tnw = (w4 <= w3 && w4 <= w2) ? 4 : (w3 <= w2 ? 3 : 2);
     }
-    if (d->dtype == GA_BF16)
-        hipLaunchKernelGGL(gemm_nt_kernel<bf16_t>, grid, block, kSmemNT, s, *d);
-    else
-        hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, kSmemNT, s, *d);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool bf = d->dtype == GA_BF16, plain = d->a_kind == GA_A_PLAIN;
+#define GA_LAUNCH_NT(TNW)                                                                                   \
+    do {                                                                                                    \
+        const int tiles_ = cdiv(d->M, kBM) * cdiv(d->N, 32 * TNW);                                          \
+        const int cap_ = std::max(8, (4 * num_cus() / d->batch) / 8 * 8);                                   \
+        dim3 grid(std::min(tiles_, cap_), 1, d->batch), block(kThreads);                                    \
+        if (bf && plain) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, TNW, true>), grid, block, NTCfg<TNW>::SMEM, s, *d);  \
+        else if (bf) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, TNW, false>), grid, block, NTCfg<TNW>::SMEM, s, *d);     \
+        else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<float, TNW, true>), grid, block, NTCfg<TNW>::SMEM, s, *d);    \
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, TNW, false>), grid, block, NTCfg<TNW>::SMEM, s, *d);              \
+    } while (0)
+    if (tnw == 4) GA_LAUNCH_NT(4);
+    else if (tnw == 3) GA_LAUNCH_NT(3);
+    else GA_LAUNCH_NT(2);
+#undef GA_LAUNCH_NT
     return ga_check_launch("ga_gemm");
 }
 

@@ -699,6 +699,7 @@ class GAEngine:
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
+        Bk.mark('heads')      # every gradient of stages.4 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
         seeds = []
         for src, hw, c, mode, off in self.agg_segs:
@@ -739,6 +740,7 @@ class GAEngine:
                                  seed[i - 1], dprev, self.grad(pre + '0.weight'), self.grad(pre + '0.bias'), Mp, d[i - 1],
                                  False, dt, label=pre + 'lnb')
                 dy = dprev
+            Bk.mark(f'stage{i}')  # gradients of stages.i (incl. its downsample) are final
         # stem
         M0 = dy.shape[0]
         dpre = self.tmp('dstem', (M0, d[0]))
@@ -778,6 +780,27 @@ class GAEngine:
         if self.training:
             torch._foreach_add_(self._nbt, 1)
         return self.logits.view_as(self.logits)
+
+    def build_loss(self, lam, kind=0, smoothing=0.0, grad_scale=1.0):
+        """fused GA loss writing d(loss)/d(logits) * grad_scale straight into the backward plan's input buffer"""
+        K, B, NC = self.logits.shape
+        self.loss_buf = self.buf('loss', (1,), torch.float32)
+        self.target_buf = self.buf('target', (B,), torch.int64)
+        lp = Plan(name='loss')
+        lp.zero(self.loss_buf)
+        lp.loss_fwd_bwd(self.logits, self.target_buf, self.loss_buf, self.dlogits, K, B, NC, float(lam), int(kind),
+                        float(smoothing), float(grad_scale), self.dt)
+        self.loss_plan = lp
+        self.loss_cfg = (lam, kind, smoothing, grad_scale)
+
+    def forward_loss(self, x, target, lam, kind=0, smoothing=0.0, grad_scale=1.0):
+        """forward + loss (+ dlogits) without autograd; follow with backward_range()/bwd.run(). Returns the loss buffer."""
+        if getattr(self, 'loss_cfg', None) != (lam, kind, smoothing, grad_scale):
+            self.build_loss(lam, kind, smoothing, grad_scale)
+        self.forward(x)
+        self.target_buf.copy_(target, non_blocking=True)
+        self.loss_plan.run()
+        return self.loss_buf
 
     def backward(self, dlogits):
         if dlogits.data_ptr() != self.dlogits.data_ptr():

@@ -53,6 +53,7 @@ class Plan:
         self.keep = []       # tensors / descriptors kept alive
         self.eager = eager
         self.name = name
+        self.marks = {}
 
     # -- core ---------------------------------------------------------------------------------------
     def _add(self, fname, args, label=None, keep=()):
@@ -77,6 +78,17 @@ class Plan:
 
     def __len__(self):
         return len(self.calls)
+
+    def mark(self, name):
+        """remember the current position (used to run a plan in segments, e.g. to start a gradient all-reduce early)"""
+        self.marks[name] = len(self.calls)
+
+    def run_range(self, start, end, stream=None):
+        s = current_stream_ptr() if stream is None else stream
+        for fn, args, label in self.calls[start:end]:
+            rc = fn(*args, s)
+            if rc != 0:
+                L.check(rc, f'{self.name}:{label}')
 
     # -- GEMM family --------------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, dtype, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, strideC=0,
