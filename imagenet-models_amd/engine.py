@@ -73,11 +73,14 @@ class GAEngine:
         self.img = 224
         # DropPath schedule (ga_convnext.py:362,376,413)
         self.dp_rates = self._drop_path_rates()
-        self.dp_scale = {}   # block prefix -> fp32 [B] (mask / keep)
+        self.dp_scale = {}   # block prefix -> fp32 [B] (mask / keep): rows of ONE (n_sites, B) tensor
         if training:
-            for pre, r in self.dp_rates.items():
-                if r > 0:
-                    self.dp_scale[pre] = torch.ones(batch, device=self.dev)
+            sites = [pre for pre, r in self.dp_rates.items() if r > 0]
+            if sites:
+                self.dp_all = torch.ones(len(sites), batch, device=self.dev)
+                self.dp_keep = torch.tensor([1.0 - self.dp_rates[p] for p in sites], device=self.dev).unsqueeze(1)
+                for i, pre in enumerate(sites):
+                    self.dp_scale[pre] = self.dp_all[i]
         # scratch arena for effective-weight gradients (zeroed once per backward)
         self.arena = None
         self.arena_off = 0
@@ -144,9 +147,9 @@ class GAEngine:
 
     def sample_drop_path(self, generator=None):
         """fresh per-sample Bernoulli(keep)/keep factors for every stochastic-depth site (timm DropPath)"""
-        for pre, t in self.dp_scale.items():
-            keep = 1.0 - self.dp_rates[pre]
-            t.copy_((torch.rand(self.B, device=self.dev, generator=generator) < keep).float() / keep)
+        if self.dp_scale:
+            r = torch.rand(self.dp_all.shape, device=self.dev, generator=generator)
+            torch.div((r < self.dp_keep).float(), self.dp_keep, out=self.dp_all)
 
     def set_drop_path_masks(self, masks):
         for pre, t in self.dp_scale.items():
