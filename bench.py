@@ -54,7 +54,7 @@ def kernel_family(label):
     return 'gemm_nt'
 
 
-def time_plan_calls(plan, fams):
+def time_plan_calls(plan, fams, per_call=None):
     """run the plan once with a HIP event pair around EVERY launch (on the launch stream); accumulate per family"""
     from imagenet_models_amd import _lib as L
     s = torch.cuda.current_stream().cuda_stream
@@ -76,6 +76,10 @@ def time_plan_calls(plan, fams):
             fam, flops = 'gemm_nt', 2.0 * d.M * d.N * d.K * d.batch
         else:
             fam = kernel_family(label)
+        if per_call is not None:
+            shape = f'M{d.M} N{d.N} K{d.K} b{d.batch}' if d is not None and hasattr(d, 'M') else ''
+            per_call.append(dict(label=f'{plan.name}:{label}', fam=fam, ms=round(ms, 4), shape=shape,
+                                 tflops=round(flops / ms / 1e9, 1) if flops and ms > 0 else None))
         f = fams.setdefault(fam, dict(ms=0.0, flops=0.0, launches=0))
         f['ms'] += ms
         f['flops'] += flops
@@ -174,13 +178,13 @@ def main():
 
     if rank == 0 and not a.no_kernel_times:
         eng = step.eng
-        fams = {}
+        fams, calls = {}, []
         eng.set_input(x)
-        time_plan_calls(eng.prep, fams)
-        time_plan_calls(eng.fwd, fams)
-        time_plan_calls(eng.loss_plan, fams)
-        time_plan_calls(eng.bwd, fams)
-        time_plan_calls(opt.plan, fams)
+        time_plan_calls(eng.prep, fams, calls)
+        time_plan_calls(eng.fwd, fams, calls)
+        time_plan_calls(eng.loss_plan, fams, calls)
+        time_plan_calls(eng.bwd, fams, calls)
+        time_plan_calls(opt.plan, fams, calls)
         opt.zero_grad()
         total_ms = sum(f['ms'] for f in fams.values())
         dom = max(fams.items(), key=lambda kv: kv[1]['ms'])
@@ -201,7 +205,8 @@ def main():
         out['kernel_families_ms'] = {k: v['ms'] for k, v in table.items()}
         if a.kernel_table:
             with open(a.kernel_table, 'w') as fh:
-                json.dump(dict(total_ms=total_ms, families=table), fh, indent=1)
+                json.dump(dict(total_ms=total_ms, families=table,
+                               top_calls=sorted(calls, key=lambda c: -c['ms'])[:150]), fh, indent=1)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -23,9 +23,9 @@ class GemmDesc(C.Structure):
         ('a_H', i32), ('a_W', i32), ('a_C', i32), ('a_act', i32),
         ('B', vp), ('ldb', i64), ('strideB', i64),
         ('C', vp), ('ldc', i64), ('strideC', i64), ('c_kind', i32),
-        ('c_H', i32), ('c_W', i32), ('c_C', i32), ('c_f32', i32),
+        ('c_H', i32), ('c_W', i32), ('c_C', i32), ('c_f32', i32), ('C2', vp), ('c2_mode', i32),
         ('alpha', f32), ('bias', vp), ('strideBias', i64), ('act', i32),
-        ('H', vp), ('ldh', i64), ('strideH', i64),
+        ('H', vp), ('ldh', i64), ('strideH', i64), ('h_is_deriv', i32),
         ('rowscale', vp), ('rows_per_scale', i32),
         ('R', vp), ('ldr', i64), ('strideR', i64), ('relu_after', i32),
         ('colsum', vp), ('colsumsq', vp), ('strideCol', i64),

@@ -60,6 +60,12 @@ __device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
     v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
     v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
 }
+__device__ __forceinline__ void unpack8(const uint4& a, float v[8]) {   // 8 bf16 held in a uint4
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
     return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
@@ -110,6 +116,13 @@ __device__ __forceinline__ float gelu_cdf_f(float x, float* e_out) {
     return x >= 0.f ? 1.0f - half_erfc : half_erfc;
 }
 __device__ __forceinline__ float gelu_f(float x) { return x * gelu_cdf_f(x, nullptr); }
+// gelu(x) and gelu'(x) from ONE erf/exp evaluation (the fc1 epilogue stores both)
+__device__ __forceinline__ void gelu_both_f(float x, float& act, float& grad) {
+    float e;
+    const float cdf = gelu_cdf_f(x, &e);
+    act = x * cdf;
+    grad = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
     float e;
     const float cdf = gelu_cdf_f(x, &e);

@@ -22,7 +22,8 @@ int num_cus() {
     return n;
 }
 
-constexpr int kCS = 64;   // channels per slice
+constexpr int kCSF = 32;  // channels per slice, forward / backward-data kernel (LDS 32 KiB -> 4-5 workgroups per CU)
+constexpr int kCSW = 64;  // channels per slice, backward-weight kernel (224 of 256 threads hold accumulators)
 constexpr int kCG = 4;    // channels per work item
 
 template <typename T> struct vec4;  // 4 channels of T
@@ -35,22 +36,39 @@ __device__ __forceinline__ void cvt4(const uint2& v, float f[4]) {
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
 }
 
-// stage a (TH+6)x(TW+6) x cs tile (zero outside the image) of NHWC tensor `src` into LDS [pix][kCS]
-template <typename T, int TH, int TW>
+// stage a (TH+6)x(TW+6) x cs tile (zero outside the image) of NHWC tensor `src` into LDS [pix][CS];
+// 16-byte global loads (8 bf16 / 4 fp32 channels per thread), constant-divisor index math
+template <typename T, int TH, int TW, int CS>
 __device__ __forceinline__ void stage_halo(const T* src, T* lds, long img_base, int H, int W, int C, int y0, int x0,
                                            int c0, int cs, int tid, int nthreads) {
     constexpr int PW = TW + 6, PH = TH + 6;
-    const int cgs = cs / kCG;
-    for (int i = tid; i < PH * PW * cgs; i += nthreads) {
-        const int cg = i % cgs, p = i / cgs;
-        const int py = p / PW, px = p - py * PW;
-        const int y = y0 + py - 3, x = x0 + px - 3;
-        typename vec4<T>::type v;
-        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-            v = *reinterpret_cast<const typename vec4<T>::type*>(src + (img_base + (long)y * W + x) * C + c0 + cg * kCG);
-        else
-            memset(&v, 0, sizeof(v));
-        *reinterpret_cast<typename vec4<T>::type*>(lds + p * kCS + cg * kCG) = v;
+    constexpr int EPC = 16 / (int)sizeof(T);          // channels per 16-byte piece
+    constexpr int PPP = CS / EPC;                     // pieces per pixel (full slice)
+    if (cs % EPC == 0) {
+        const int npp = cs / EPC;
+        for (int i = tid; i < PH * PW * PPP; i += nthreads) {
+            const int pc = i % PPP, p = i / PPP;
+            if (pc >= npp) continue;
+            const int py = p / PW, px = p - py * PW;
+            const int y = y0 + py - 3, x = x0 + px - 3;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const uint4*>(src + (img_base + (long)y * W + x) * C + c0 + pc * EPC);
+            *reinterpret_cast<uint4*>(lds + p * CS + pc * EPC) = v;
+        }
+    } else {   // ragged slice (cs multiple of 4 only): 4-channel pieces
+        const int cgs = cs / kCG;
+        for (int i = tid; i < PH * PW * cgs; i += nthreads) {
+            const int cg = i % cgs, p = i / cgs;
+            const int py = p / PW, px = p - py * PW;
+            const int y = y0 + py - 3, x = x0 + px - 3;
+            typename vec4<T>::type v;
+            if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                v = *reinterpret_cast<const typename vec4<T>::type*>(src + (img_base + (long)y * W + x) * C + c0 + cg * kCG);
+            else
+                memset(&v, 0, sizeof(v));
+            *reinterpret_cast<typename vec4<T>::type*>(lds + p * CS + cg * kCG) = v;
+        }
     }
 }
 
@@ -61,23 +79,25 @@ __global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, co
                                                      T* __restrict__ y, int H, int W, int C, int flip) {
     constexpr int PW = TW + 6, PH = TH + 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* xs = reinterpret_cast<T*>(smem);                                    // [PH*PW][kCS]
-    float* ws = reinterpret_cast<float*>(smem + PH * PW * kCS * sizeof(T)); // [49][kCS]
+    T* xs = reinterpret_cast<T*>(smem);                                    // [PH*PW][kCSF]
+    float* ws = reinterpret_cast<float*>(smem + PH * PW * kCSF * sizeof(T)); // [49][kCSF]
     const int tid = threadIdx.x;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
-    int t = blockIdx.x;
+    // channel slice fastest: the slices of one spatial tile run together and share the tile's cache lines in L2
+    const int slices = (C + kCSF - 1) / kCSF;
+    int t = blockIdx.x / slices;
+    const int c0 = (blockIdx.x - t * slices) * kCSF;
     const int tx = t % tiles_x; t /= tiles_x;
     const int ty = t % tiles_y;
     const long b = t / tiles_y;
-    const int c0 = blockIdx.y * kCS;
-    const int cs = min(kCS, C - c0);
+    const int cs = min(kCSF, C - c0);
     const int y0 = ty * TH, x0 = tx * TW;
     const long img = b * H * W;
 
-    stage_halo<T, TH, TW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
+    stage_halo<T, TH, TW, kCSF>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
     for (int i = tid; i < 49 * cs; i += NT) {
         const int tap = i / cs, c = i - tap * cs;
-        ws[tap * kCS + c] = w49[(flip ? 48 - tap : tap) * C + c0 + c];
+        ws[tap * kCSF + c] = w49[(flip ? 48 - tap : tap) * C + c0 + c];
     }
     __syncthreads();
 
@@ -102,12 +122,12 @@ __global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, co
 #pragma unroll 1
         for (int ky = 0; ky < 7; ++ky) {
             float in[13][4];
-            const T* rowp = xs + ((oy + ky) * PW + ox0) * kCS + cg * kCG;
+            const T* rowp = xs + ((oy + ky) * PW + ox0) * kCSF + cg * kCG;
 #pragma unroll
-            for (int i = 0; i < 13; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCS), in[i]);
+            for (int i = 0; i < 13; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCSF), in[i]);
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                const float4 wv = *reinterpret_cast<const float4*>(ws + (ky * 7 + kx) * kCS + cg * kCG);
+                const float4 wv = *reinterpret_cast<const float4*>(ws + (ky * 7 + kx) * kCSF + cg * kCG);
 #pragma unroll
                 for (int o = 0; o < 7; ++o) {
                     acc[o][0] = fmaf(in[o + kx][0], wv.x, acc[o][0]);
@@ -146,13 +166,13 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
     constexpr int PW = TW + 6, PH = TH + 6;
     constexpr int RS = TH / 7;  // row groups of 7 output rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T* xs = reinterpret_cast<T*>(smem);                                   // [PH*PW][kCS]
-    T* ds = reinterpret_cast<T*>(smem + PH * PW * kCS * sizeof(T));       // [TH*TW][kCS]
+    T* xs = reinterpret_cast<T*>(smem);                                   // [PH*PW][kCSW]
+    T* ds = reinterpret_cast<T*>(smem + PH * PW * kCSW * sizeof(T));       // [TH*TW][kCSW]
     const int tid = threadIdx.x;
     const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
     const long ntiles = (long)B * tiles_x * tiles_y;
-    const int c0 = blockIdx.y * kCS;
-    const int cs = min(kCS, C - c0);
+    const int c0 = blockIdx.y * kCSW;
+    const int cs = min(kCSW, C - c0);
     const int cgs = cs / kCG;
     // item = (cg, ky, row group): keeps acc[7 kx][4 ch] (+ 4 bias sums) in registers across tiles
     const int nitems = cgs * 7 * RS;
@@ -176,7 +196,7 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
         const int y0 = ty * TH, x0 = tx * TW;
         const long img = b * H * W;
         __syncthreads();  // previous tile fully consumed
-        stage_halo<T, TH, TW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
+        stage_halo<T, TH, TW, kCSW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
         for (int i = tid; i < TH * TW * cgs; i += NT) {
             const int g = i % cgs, p = i / cgs;
             const int py = p / TW, px = p - py * TW;
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
                 v = *reinterpret_cast<const typename vec4<T>::type*>(dy + (img + (long)yy * W + xx) * C + c0 + g * kCG);
             else
                 memset(&v, 0, sizeof(v));
-            *reinterpret_cast<typename vec4<T>::type*>(ds + p * kCS + g * kCG) = v;
+            *reinterpret_cast<typename vec4<T>::type*>(ds + p * kCSW + g * kCG) = v;
         }
         __syncthreads();
         if (active) {
@@ -196,13 +216,13 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
 #pragma unroll 1
                 for (int xs0 = 0; xs0 < TW; xs0 += 7) {
                     float in[13][4], g[7][4];
-                    const T* rowp = xs + ((oy + ky) * PW + xs0) * kCS + cg * kCG;
+                    const T* rowp = xs + ((oy + ky) * PW + xs0) * kCSW + cg * kCG;
 #pragma unroll
                     for (int i = 0; i < 13; ++i)
-                        cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCS), in[i]);
-                    const T* dp = ds + (oy * TW + xs0) * kCS + cg * kCG;
+                        cvt4(*reinterpret_cast<const typename vec4<T>::type*>(rowp + i * kCSW), in[i]);
+                    const T* dp = ds + (oy * TW + xs0) * kCSW + cg * kCG;
 #pragma unroll
-                    for (int i = 0; i < 7; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(dp + i * kCS), g[i]);
+                    for (int i = 0; i < 7; ++i) cvt4(*reinterpret_cast<const typename vec4<T>::type*>(dp + i * kCSW), g[i]);
 #pragma unroll
                     for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
@@ -234,10 +254,10 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s) {
-    const int slices = cdiv(C, kCS);
+    const int slices = cdiv(C, kCSF);
     if (H % 14 == 0 && W % 14 == 0) {
         constexpr int TH = 14, TW = 14, NT = 256;
-        const size_t lds = (TH + 6) * (TW + 6) * kCS * sizeof(T) + 49 * kCS * 4;
+        const size_t lds = (TH + 6) * (TW + 6) * kCSF * sizeof(T) + 49 * kCSF * 4;
         auto k = dwconv7_kernel<T, TH, TW, NT>;
         static bool once = false;
         if (!once) {
@@ -248,12 +268,12 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             }
             once = true;
         }
-        dim3 grid(B * (H / TH) * (W / TW), slices);
+        dim3 grid(B * (H / TH) * (W / TW) * slices);
         hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, (const T*)x, w49, bias, (const T*)res, (T*)y, H, W, C, flip);
     } else {
         constexpr int TH = 7, TW = 7, NT = 128;
-        const size_t lds = (TH + 6) * (TW + 6) * kCS * sizeof(T) + 49 * kCS * 4;
-        dim3 grid(B * cdiv(H, TH) * cdiv(W, TW), slices);
+        const size_t lds = (TH + 6) * (TW + 6) * kCSF * sizeof(T) + 49 * kCSF * 4;
+        dim3 grid(B * cdiv(H, TH) * cdiv(W, TW) * slices);
         hipLaunchKernelGGL((dwconv7_kernel<T, TH, TW, NT>), grid, dim3(NT), lds, s, (const T*)x, w49, bias,
                            (const T*)res, (T*)y, H, W, C, flip);
     }
@@ -263,11 +283,11 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
 template <typename T>
 int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
                         hipStream_t s) {
-    const int slices = cdiv(C, kCS);
+    const int slices = cdiv(C, kCSW);
     const int num_cu = num_cus();
     if (H % 14 == 0 && W % 14 == 0) {
         constexpr int TH = 14, TW = 14, NT = 256;
-        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCS * sizeof(T);
+        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCSW * sizeof(T);
         auto k = dwconv7_wgrad_kernel<T, TH, TW, NT>;
         static bool once = false;
         if (!once) {
@@ -283,7 +303,7 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
         hipLaunchKernelGGL(k, dim3(gx, slices), dim3(NT), lds, s, (const T*)dy, (const T*)x, dw49, dbias, B, H, W, C);
     } else {
         constexpr int TH = 7, TW = 7, NT = 128;
-        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCS * sizeof(T);
+        const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCSW * sizeof(T);
         const long ntiles = (long)B * cdiv(H, TH) * cdiv(W, TW);
         const int gx = (int)std::min<long>(ntiles, std::max(1, 4 * num_cu / slices));
         hipLaunchKernelGGL((dwconv7_wgrad_kernel<T, TH, TW, NT>), dim3(gx, slices), dim3(NT), lds, s, (const T*)dy,

@@ -173,7 +173,7 @@ template <int TNW> struct NTCfg {
     static constexpr int RG = kThreads / P8;                  // row groups in the coalesced store phase
 };
 
-template <typename T, int TNW, bool PLAIN>
+template <typename T, int TNW, bool PLAIN, bool PRE>
 __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d) {
     using CF = NTCfg<TNW>;
     constexpr int EPC = elt<T>::EPC;
@@ -255,11 +255,24 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     const int c8 = tid % CF::P8, rg = tid / CF::P8;   // this thread's 8-column piece / first row of the half
     const bool t_active = rg < CF::RG;
 
+    // Epilogue operand prefetch (bf16): the GELU'-source H (dgrad) or the residual R (forward) pieces this thread
+    // will need are requested at the START of the last K slab, so their HBM latency hides under the MFMAs and the
+    // LDS staging instead of being paid once per row in the store loop.
+    constexpr int NR = (64 + CF::RG - 1) / CF::RG;
+    constexpr bool kPre = PRE && sizeof(T) == 2;
+    uint4 pre[kPre ? 2 : 1][kPre ? NR : 1];
+    const T* Pb = Hb ? Hb : Rb;
+    const long ldp = Hb ? d.ldh : d.ldr;
+
     int vt = blockIdx.x;
     set_tile(vt);
     g_load(0);
     for (; vt < nwg; ) {
     const int cm0 = m0, cn0 = n0;   // the tile being computed (m0/n0 move on to the prefetched tile below)
+    const int n = cn0 + c8 * 8;
+    const bool n_ok = t_active && n < d.N;
+    const bool full = n + 8 <= d.N;
+    const bool use_pre = kPre && Pb != nullptr && n_ok && full;
     f32x4_t acc[TNW][4];  // [tn][tm]
 #pragma unroll
     for (int i = 0; i < TNW; ++i)
@@ -271,6 +284,18 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
 
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) g_load(kt + 1);
+        if constexpr (kPre) {
+            if (kt == nk - 1 && use_pre) {
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int it = 0; it < NR; ++it) {
+                        const int row = rg + it * CF::RG;
+                        const long m = (long)cm0 + hf * 64 + row;
+                        if (row < 64 && m < d.M) pre[hf][it] = *reinterpret_cast<const uint4*>(Pb + m * ldp + n);
+                    }
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int chunk = ks * 4 + (lane >> 4);
@@ -315,9 +340,6 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     }
 
     // ---- fused epilogue, two 64-row halves staged through LDS as fp32 [64][BN+4]
-    const int n = cn0 + c8 * 8;
-    const bool n_ok = t_active && n < d.N;
-    const bool full = n + 8 <= d.N;
     float bias[8], csum[8], csq[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -342,7 +364,10 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
         }
         __syncthreads();
         if (n_ok) {
-            for (int row = rg; row < 64; row += CF::RG) {
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int row = rg + it * CF::RG;
+                if (row >= 64) break;
                 const long m = (long)cm0 + half * 64 + row;
                 if (m >= d.M) break;
                 float v[8];
@@ -354,7 +379,32 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha + bias[j];
-                if (d.act == GA_ACT_GELU) {
+                if (d.C2) {   // second output: pre-activation (mode 1) or GELU'(pre-activation) (mode 2)
+                    float w[8];
+                    if (d.c2_mode == 2 && d.act == GA_ACT_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gelu_both_f(v[j], v[j], w[j]);   // v := gelu, w := gelu'
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) w[j] = d.c2_mode == 2 ? gelu_grad_f(v[j]) : v[j];
+                        if (d.act == GA_ACT_GELU) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                        }
+                    }
+                    if (d.act == GA_ACT_RELU) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                    }
+                    T* C2p = reinterpret_cast<T*>(d.C2) + z * d.strideC + m * d.ldc + n;
+                    if (full) {
+                        store8(C2p, w);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (n + j < d.N) elt<T>::st(C2p + j, w[j]);
+                    }
+                } else if (d.act == GA_ACT_GELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
                 } else if (d.act == GA_ACT_RELU) {
@@ -363,14 +413,21 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                 }
                 if (Hb) {
                     float h[8];
-                    if (full) {
+                    if (use_pre) {
+                        if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], h);
+                    } else if (full) {
                         load8(Hb + m * d.ldh + n, h);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
                     }
+                    if (d.h_is_deriv) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
+                        for (int j = 0; j < 8; ++j) v[j] *= h[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
+                    }
                 }
                 if (d.rowscale) {
                     const float s = d.rowscale[m / d.rows_per_scale];
@@ -379,7 +436,9 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                 }
                 if (Rb) {
                     float r[8];
-                    if (full) {
+                    if (use_pre && !Hb) {
+                        if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], r);
+                    } else if (full) {
                         load8(Rb + m * d.ldr + n, r);
                     } else {
 #pragma unroll
@@ -633,6 +692,28 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
+// rounded down to a multiple of 8 so every XCD gets the same share of the tile walk
+template <typename T, int TNW, bool PLAIN, bool PRE>
+void launch_nt_(const ga_gemm_desc* d, int tiles, hipStream_t s) {
+    static const int per_cu = [] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, PLAIN, PRE>, kThreads,
+                                                         NTCfg<TNW>::SMEM) != hipSuccess || n < 1)
+            n = 2;
+        return n;
+    }();
+    const int cap = std::max(8, (per_cu * num_cus() / d->batch) / 8 * 8);
+    dim3 grid(std::min(tiles, cap), 1, d->batch), block(kThreads);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, PLAIN, PRE>), grid, block, NTCfg<TNW>::SMEM, s, *d);
+}
+template <typename T, int TNW, bool PLAIN>
+void launch_nt(const ga_gemm_desc* d, int tiles, hipStream_t s) {
+    // the epilogue-operand prefetch costs 32 VGPRs: only the launches that read H or R take that variant
+    if (sizeof(T) == 2 && (d->H || d->R)) launch_nt_<T, TNW, PLAIN, true>(d, tiles, s);
+    else launch_nt_<T, TNW, PLAIN, false>(d, tiles, s);
+}
+
 }  // namespace
 
 extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
@@ -664,6 +745,8 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         GA_REQUIRE(d->c_kind == GA_C_PLAIN, "ga_gemm: bad c_kind");
     }
     if (d->H) GA_REQUIRE(aligned16(d->H) && d->ldh % 8 == 0, "ga_gemm: H alignment");
+    if (d->C2) GA_REQUIRE(aligned16(d->C2) && d->c_kind == GA_C_PLAIN && !d->c_f32 && (d->c2_mode == 1 || d->c2_mode == 2),
+                          "ga_gemm: C2 needs a plain, dtype-typed C and c2_mode 1|2");
     if (d->R) GA_REQUIRE(aligned16(d->R) && d->ldr % 8 == 0, "ga_gemm: R alignment");
     if (d->rowscale) GA_REQUIRE(d->rows_per_scale > 0, "ga_gemm: rows_per_scale");
     // vector stores need an 8-element aligned leading dimension; otherwise every piece takes the scalar path,
@@ -683,12 +766,10 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
 #define GA_LAUNCH_NT(TNW)                                                                                   \
     do {                                                                                                    \
         const int tiles_ = cdiv(d->M, kBM) * cdiv(d->N, 32 * TNW);                                          \
-        const int cap_ = std::max(8, (4 * num_cus() / d->batch) / 8 * 8);                                   \
-        dim3 grid(std::min(tiles_, cap_), 1, d->batch), block(kThreads);                                    \
-        if (bf && plain) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, TNW, true>), grid, block, NTCfg<TNW>::SMEM, s, *d);  \
-        else if (bf) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, TNW, false>), grid, block, NTCfg<TNW>::SMEM, s, *d);     \
-        else if (plain) hipLaunchKernelGGL((gemm_nt_kernel<float, TNW, true>), grid, block, NTCfg<TNW>::SMEM, s, *d);    \
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, TNW, false>), grid, block, NTCfg<TNW>::SMEM, s, *d);              \
+        if (bf && plain) launch_nt<bf16_t, TNW, true>(d, tiles_, s);                                        \
+        else if (bf) launch_nt<bf16_t, TNW, false>(d, tiles_, s);                                           \
+        else if (plain) launch_nt<float, TNW, true>(d, tiles_, s);                                          \
+        else launch_nt<float, TNW, false>(d, tiles_, s);                                                    \
     } while (0)
     if (tnw == 4) GA_LAUNCH_NT(4);
     else if (tnw == 3) GA_LAUNCH_NT(3);

@@ -10,7 +10,7 @@ Data layout in HBM (bf16 mode; fp32 mode is identical with 4-byte elements):
   * gradients: fp32, ONE flat buffer aliased by every param.grad; the wgrad kernels atomically accumulate either
     directly into it or into a zeroed scratch arena of effective-weight gradients that ga_weight_unfold maps back.
 What is saved for backward per ConvNeXt block: xhat (LN output, no affine), rstd, h (pre-GELU hidden) and the
-block output; GELU / GELU' are recomputed inside the GEMM loader / epilogue.
+block output of fc1 as a = gelu(h) and g = gelu'(h) (both written by the fc1 epilogue), and the block output.
 
 Reference semantics restated here: /root/reference/GA/ga_convnext.py:98-112 (block), :139-150 (stage + taps),
 :294-318 (Bottleneck), :452-467 (get_gram), :153-248 (class attention block), :469-505 (forward).
@@ -299,12 +299,16 @@ class GAEngine:
         xn = self.blk_act(pre + 'xn', (M, C))
         rstd = self.blk_act(pre + 'rstd', (M,), torch.float32)
         F.layernorm_fwd(u, None, None, xn, None, rstd, M, C, 1e-6, dt, label=pre + 'ln')
-        h = self.blk_act(pre + 'h', (M, 4 * C))
-        F.gemm(xn, W[pre + 'mlp.fc1.weight'], h, M, 4 * C, C, dt, bias=W[pre + 'b1e'], label=pre + 'fc1')
+        # fc1 stores a = gelu(h) and, when training, g = gelu'(h): backward never re-evaluates erf, and neither the
+        # fc2 operand loader nor the wgrad loader has to (they used to, once per N tile)
+        a = self.blk_act(pre + 'a', (M, 4 * C))
+        g = self.buf(pre + 'g', (M, 4 * C)) if self.training else None
+        F.gemm(xn, W[pre + 'mlp.fc1.weight'], a, M, 4 * C, C, dt, bias=W[pre + 'b1e'], act=ACT_GELU, C2=g,
+               c2_mode=2 if g is not None else 0, label=pre + 'fc1')
         y = self.buf(pre + 'y', (M, C))
-        F.gemm(h, W[pre + 'mlp.fc2.weight'], y, M, C, 4 * C, dt, a_act=ACT_GELU, bias=W[pre + 'b2e'],
+        F.gemm(a, W[pre + 'mlp.fc2.weight'], y, M, C, 4 * C, dt, bias=W[pre + 'b2e'],
                rowscale=self.dp_scale.get(pre), rows_per_scale=res * res, R=x, ldr=C, label=pre + 'fc2')
-        self.blocks[pre] = dict(x=x, xn=xn, rstd=rstd, h=h, y=y, res=res, C=C)
+        self.blocks[pre] = dict(x=x, xn=xn, rstd=rstd, a=a, g=g, y=y, res=res, C=C)
         return y
 
     def _block_bwd(self, pre, dy, dx):
@@ -319,10 +323,11 @@ class GAEngine:
             dyz = self.tmp('dyz', (M, C))
             Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
         G2, gb2 = self.gbuf((C, 4 * C)), self.gbuf((C,))
-        Bk.wgrad(dyz, b['h'], G2, M, C, 4 * C, dt, x_act=ACT_GELU, dbias=gb2, label=pre + 'wg2')
+        Bk.wgrad(dyz, b['a'], G2, M, C, 4 * C, dt, dbias=gb2, label=pre + 'wg2')
         dh = self.tmp('dh', (M, 4 * C))
         gb1 = self.gbuf((4 * C,))
-        Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['h'], ldh=4 * C, colsum=gb1, label=pre + 'dg2')
+        Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['g'], ldh=4 * C, h_is_deriv=True, colsum=gb1,
+                label=pre + 'dg2')
         G1 = self.gbuf((4 * C, C))
         Bk.wgrad(dh, b['xn'], G1, M, 4 * C, C, dt, label=pre + 'wg1')
         g = self.tmp('g', (M, C))
@@ -567,15 +572,17 @@ class GAEngine:
         Wm1 = self._w_plain(pre + 'mlp.fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
         bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'mlp.fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
-        h['hm'] = self.act(pre + 'hm', (B, Hd))
-        F.gemm(h['t'], Wm1, h['hm'], B, Nv, cin, dt, lda=cout, batch=mg * mg, strideA=cin, a_batch_mod=mg,
-               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, label=pre + 'mlp.fc1')
+        h['am'] = self.act(pre + 'am', (B, Hd))                      # gelu(hidden), shuffled order
+        h['gm'] = self.act(pre + 'gm', (B, Hd)) if T else None       # gelu'(hidden)
+        F.gemm(h['t'], Wm1, h['am'], B, Nv, cin, dt, lda=cout, batch=mg * mg, strideA=cin, a_batch_mod=mg,
+               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ACT_GELU,
+               C2=h['gm'], c2_mode=2 if T else 0, label=pre + 'mlp.fc1')
         Wm2 = self._w_plain(pre + 'mlp.fc2.weight', cin, gc_, 1, 1, groups=mg, rs=P[pre + 'gamma_2'])
         bm2 = self.buf('w.' + pre + 'bm2', (cout,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma_2'], None, bm2, cout, gc_)
         h['cls2'] = self.act(pre + 'cls2', (B, cout))
-        F.gemm(h['hm'], Wm2, h['cls2'], B, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
-               ldb=pad8(gc_), ldc=cout, strideC=cin, a_act=ACT_GELU, bias=bm2, strideBias=cin, rowscale=dp,
+        F.gemm(h['am'], Wm2, h['cls2'], B, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
+               ldb=pad8(gc_), ldc=cout, strideC=cin, bias=bm2, strideBias=cin, rowscale=dp,
                rows_per_scale=1, R=h['cls1'], ldr=cout, strideR=cin, label=pre + 'mlp.fc2')
         h.update(Hd=Hd, mlp_gc=gc_, Nv=Nv, cin=cin)
         # --- classifier
@@ -607,16 +614,16 @@ class GAEngine:
             Bk.rowscale(dcls2, dp, dmz, B * cout, cout, dt)
         # mlp.fc2 (mg groups)
         Gm2, gbm2 = self.gbuf((cout, gc_)), self.gbuf((cout,))
-        Bk.wgrad(dmz, h['hm'], Gm2, B, cin, gc_, dt, ldy=cout, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
-                 strideW=cin * gc_, x_act=ACT_GELU, dbias=gbm2, strideDbias=cin, label=pre + 'mlp.fc2.wg')
+        Bk.wgrad(dmz, h['am'], Gm2, B, cin, gc_, dt, ldy=cout, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
+                 strideW=cin * gc_, dbias=gbm2, strideDbias=cin, label=pre + 'mlp.fc2.wg')
         Bk.weight_unfold(Gm2, gc_, cout, gc_, gb=gbm2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
                          rs=P[pre + 'gamma_2'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
                          d_rs=self.grad(pre + 'gamma_2'), label=pre + 'mlp.fc2.unf')
         dhm = self.tmp('dhm', (B, Hd))
         gbm1 = self.gbuf((Hd,))
         Bk.gemm(dmz, W[pre + 'mlp.fc2.weight.T'], dhm, B, gc_, cin, dt, lda=cout, batch=mg, strideA=cin,
-                strideB=gc_ * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=gc_, H=h['hm'], ldh=Hd, strideH=gc_, colsum=gbm1,
-                strideCol=gc_, label=pre + 'mlp.fc2.dg')
+                strideB=gc_ * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=gc_, H=h['gm'], ldh=Hd, strideH=gc_, h_is_deriv=True,
+                colsum=gbm1, strideCol=gc_, label=pre + 'mlp.fc2.dg')
         # mlp.fc1 (mg*mg virtual groups)
         Gm1 = self.gbuf((Hd, cin))
         Bk.wgrad(dhm, h['t'], Gm1, B, Nv, cin, dt, ldy=Hd, ldx=cout, ldw=cin, batch=mg * mg, strideY=Nv, strideX=cin,

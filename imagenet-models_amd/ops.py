@@ -95,7 +95,7 @@ class Plan:
              a_batch_mod=0, a_kind=A_PLAIN, a_dims=(0, 0, 0), a_act=ACT_NONE, c_kind=C_PLAIN, c_dims=(0, 0, 0),
              c_f32=False, alpha=1.0, bias=None, strideBias=0, act=ACT_NONE, H=None, ldh=0, strideH=0, rowscale=None,
              rows_per_scale=1, R=None, ldr=0, strideR=0, relu_after=False, colsum=None, colsumsq=None, strideCol=0,
-             label=None):
+             C2=None, c2_mode=0, h_is_deriv=False, label=None):
         d = L.GemmDesc()
         d.M, d.N, d.K, d.batch, d.dtype = M, N, K, batch, dtype
         d.A, d.lda, d.strideA, d.a_batch_mod, d.a_kind = _ptr(A), (K if lda is None else lda), strideA, a_batch_mod, a_kind
@@ -105,13 +105,15 @@ class Plan:
         d.C, d.ldc, d.strideC, d.c_kind = _ptr(Cout), (N if ldc is None else ldc), strideC, c_kind
         d.c_H, d.c_W, d.c_C = c_dims
         d.c_f32 = int(c_f32)
+        d.C2, d.c2_mode = _ptr(C2), c2_mode
+        d.h_is_deriv = int(h_is_deriv)
         d.alpha = alpha
         d.bias, d.strideBias, d.act = _ptr(bias), strideBias, act
         d.H, d.ldh, d.strideH = _ptr(H), ldh, strideH
         d.rowscale, d.rows_per_scale = _ptr(rowscale), rows_per_scale
         d.R, d.ldr, d.strideR, d.relu_after = _ptr(R), ldr, strideR, int(relu_after)
         d.colsum, d.colsumsq, d.strideCol = _ptr(colsum), _ptr(colsumsq), strideCol
-        self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq))
+        self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq, C2))
 
     def wgrad(self, Y, X, dW, M, N, K, dtype, ldy=None, ldx=None, ldw=None, batch=1, strideY=0, strideX=0, strideW=0,
               x_kind=A_PLAIN, x_dims=(0, 0, 0), x_act=ACT_NONE, dbias=None, strideDbias=0, alpha=1.0, split_m=None,

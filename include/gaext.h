@@ -54,7 +54,7 @@ int ga_device_info(int* num_cu, int* lds_bytes, int* wave_size);
  * replaces: nn.Linear / 1x1, 2x2-s2, 4x4-s4 and 3x3 nn.Conv2d forward AND their data-gradients
  *           (ga_convnext.py:94,127,163-167,202-205,259-283,357,407,418,422) -- dgrad uses the transposed
  *           weight copy made by ga_weight_prep, so it is the same NT product.
- * epilogue order: v = alpha*acc; v += bias[n]; v = act(v); v *= dact(H[m][n]) (GELU'); v *= rowscale[m / rows_per_scale];
+ * epilogue order: v = alpha*acc; v += bias[n]; (C2 store); v = act(v); v *= dact(H[m][n]) (GELU'); v *= rowscale[m / rows_per_scale];
  *                 v += R[m][n]; if (relu_after) v = max(v,0); colsum[n] += v; colsumsq[n] += v*v; store.
  * ------------------------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -77,6 +77,9 @@ typedef struct {
     int c_kind;            /* GA_C_* */
     int c_H, c_W, c_C;     /* NHWC dims of the scatter target (GA_C_UNPATCH2) */
     int c_f32;             /* 1: C is fp32 regardless of dtype */
+    void* C2;              /* optional second output (dtype, layout of C): see c2_mode */
+    int c2_mode;           /* 1: the pre-activation value (alpha*acc + bias); 2: act'(pre-activation) (GELU') -- lets the
+                              forward fc1 store gelu(h) AND gelu'(h) so that backward never re-evaluates erf */
     /* epilogue */
     float alpha;
     const float* bias;     /* [N] or NULL */
@@ -84,6 +87,7 @@ typedef struct {
     int act;               /* GA_ACT_* */
     const void* H;         /* GELU-backward: multiply by gelu'(H[m][n]) (dtype), or NULL */
     int64_t ldh, strideH;
+    int h_is_deriv;        /* 1: H already holds the derivative (stored by c2_mode 2): multiply by H[m][n] itself */
     const float* rowscale; /* per-sample scale (DropPath mask / keep) or NULL */
     int rows_per_scale;
     const void* R;         /* residual (dtype) or NULL */

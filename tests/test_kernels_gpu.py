@@ -90,6 +90,18 @@ def test_gemm_epilogue_fusions(dt):
     hh = h.clone().requires_grad_(True)
     F.gelu(hh).sum().backward()
     assert_close(C32, (a @ b.t()) * hh.grad, tol(dt), 'gelu-bwd')
+    # fc1-style double output: C = gelu(pre), C2 = gelu'(pre); then multiply-by-stored-derivative (dgrad2 style)
+    Ca = torch.empty(M, N, dtype=dt, device='cuda'); Cg = torch.empty(M, N, dtype=dt, device='cuda')
+    ops.Plan(eager=True).gemm(A, B, Ca, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), act=ops.ACT_GELU, C2=Cg, c2_mode=2)
+    pre = (a @ b.t() + bias).requires_grad_(True)
+    act = F.gelu(pre)
+    act.sum().backward()
+    assert_close(Ca, act, tol(dt), 'fc1 act')
+    assert_close(Cg, pre.grad, tol(dt), "fc1 gelu'")
+    ops.Plan(eager=True).gemm(A, B, C32, M, N, K, ops.ga_dtype(dt), H=Cg, ldh=N, h_is_deriv=True, c_f32=True)
+    assert_close(C32, (a @ b.t()) * Cg.float().cpu(), tol(dt), 'mul by stored derivative')
+    ops.Plan(eager=True).gemm(A, B, Ca, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), act=ops.ACT_RELU, C2=Cg, c2_mode=1)
+    assert_close(Cg, a @ b.t() + bias, tol(dt), 'pre-activation copy')
     # GELU applied to A while staging
     ops.Plan(eager=True).gemm(A, B, C32, M, N, K, ops.ga_dtype(dt), a_act=ops.ACT_GELU, c_f32=True)
     ag = F.gelu(a).to(dt).float() if dt == torch.bfloat16 else F.gelu(a)

@@ -58,6 +58,12 @@ for stage, (C, res) in enumerate([(96, 56), (192, 28), (384, 14), (768, 7)]):
     e = 2
     p = ops.Plan(); p.gemm(x, W1, h, M, 4 * C, C, dt, bias=b1)
     report(f's{stage} fc1 fwd', timeit(p), fl, e * M * 5 * C)
+    h2 = rnd(M, 4 * C)
+    p = ops.Plan(); p.gemm(x, W1, h, M, 4 * C, C, dt, bias=b1, act=ops.ACT_GELU, C2=h2, c2_mode=2)
+    report(f's{stage} fc1 fwd(+gelu,+gelu\')', timeit(p), fl, e * M * 9 * C)
+    p = ops.Plan(); p.gemm(y, W2T, h, M, 4 * C, C, dt, H=h2, ldh=4 * C, h_is_deriv=True, colsum=gb)
+    report(f's{stage} dgrad2(*g)', timeit(p), fl, e * M * 9 * C)
+    del h2
     p = ops.Plan(); p.gemm(h, W2, y, M, C, 4 * C, dt, a_act=ops.ACT_GELU, bias=b2, R=x, ldr=C)
     report(f's{stage} fc2 fwd(gelu,res)', timeit(p), fl, e * M * 6 * C)
     p = ops.Plan(); p.gemm(h, W2, y, M, C, 4 * C, dt, bias=b2, R=x, ldr=C)
