@@ -60,6 +60,11 @@ class WunfoldDesc(C.Structure):
     ]
 
 
+class SmallDesc(C.Structure):
+    _fields_ = [('kind', i32), ('y', vp), ('x', vp), ('a', f32), ('n', i64), ('R', i32), ('C', i32), ('accumulate', i32),
+                ('b', vp), ('rs', vp), ('v', vp), ('row_perm', vp)]
+
+
 _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
@@ -94,6 +99,9 @@ _SIGS = {
     'ga_heads_topk': ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
     'ga_sgd_step': ([vp, vp, vp, vp, i64, i32, f32, vp], i32),
     'ga_adamw_step': ([vp, vp, vp, vp, vp, i64, f32, vp], i32),
+    'ga_weight_prep_batch': ([vp, i32, vp], i32),
+    'ga_weight_unfold_batch': ([vp, i32, vp], i32),
+    'ga_small_batch': ([vp, i32, vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),

@@ -173,8 +173,26 @@ template <int TNW> struct NTCfg {
     static constexpr int RG = kThreads / P8;                  // row groups in the coalesced store phase
 };
 
-template <typename T, int TNW, bool PLAIN, bool PRE>
+// EPI >= 0 fixes the epilogue at compile time (dead paths are not even emitted: the all-runtime generic kernel is
+// ~14k instructions, most of them never executed by the hot launches, and thrashes the instruction cache):
+//   0 plain (bias, optional column sums)      1 fc1: bias + GELU, second output GELU'
+//   2 fc2: bias (+ DropPath row scale) + residual      3 dgrad2: multiply by the stored GELU' (+ column sums)
+enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_FC1 = 1, EPI_FC2 = 2, EPI_DG2 = 3 };
+
+template <typename T, int TNW, bool PLAIN, bool PRE, int EPI>
 __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d) {
+#define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
+#define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
+#define F_C2 (EPI < 0 ? d.C2 != nullptr : EPI == EPI_FC1)
+#define F_H (EPI < 0 ? Hb != nullptr : EPI == EPI_DG2)
+#define F_HDERIV (EPI < 0 ? d.h_is_deriv != 0 : true)
+#define F_RS (EPI < 0 ? d.rowscale != nullptr : (EPI == EPI_FC2 && d.rowscale != nullptr))
+#define F_R (EPI < 0 ? Rb != nullptr : EPI == EPI_FC2)
+#define F_RELUA (EPI < 0 ? d.relu_after != 0 : false)
+#define F_CSUM (EPI < 0 ? d.colsum != nullptr : ((EPI == EPI_DG2 || EPI == EPI_PLAIN) && d.colsum != nullptr))
+#define F_UNPATCH (EPI < 0 ? d.c_kind == GA_C_UNPATCH2 : false)
+#define F_CF32 (EPI < 0 ? d.c_f32 != 0 : false)
+#define F_AACT (EPI < 0 ? d.a_act : GA_ACT_NONE)
     using CF = NTCfg<TNW>;
     constexpr int EPC = elt<T>::EPC;
     constexpr int BK = kRowBytes / (int)sizeof(T);
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = r0 + 32 * i;
-            *reinterpret_cast<uint4*>(As + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = act_chunk<T>(ra[i], d.a_act);
+            *reinterpret_cast<uint4*>(As + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = act_chunk<T>(ra[i], F_AACT);
         }
 #pragma unroll
         for (int i = 0; i < TNW; ++i) {
@@ -261,8 +279,8 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     constexpr int NR = (64 + CF::RG - 1) / CF::RG;
     constexpr bool kPre = PRE && sizeof(T) == 2;
     uint4 pre[kPre ? 2 : 1][kPre ? NR : 1];
-    const T* Pb = Hb ? Hb : Rb;
-    const long ldp = Hb ? d.ldh : d.ldr;
+    const T* Pb = F_H ? Hb : Rb;
+    const long ldp = F_H ? d.ldh : d.ldr;
 
     int vt = blockIdx.x;
     set_tile(vt);
@@ -347,7 +365,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
         csum[j] = csq[j] = 0.f;
     }
     long c_off = 0;
-    if (d.c_kind == GA_C_UNPATCH2 && n_ok) {
+    if (F_UNPATCH && n_ok) {
         const int tap = n / d.c_C, ch = n - tap * d.c_C;
         c_off = ((long)(tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch;
     }
@@ -378,10 +396,10 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
                 }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = v[j] * d.alpha + bias[j];
-                if (d.C2) {   // second output: pre-activation (mode 1) or GELU'(pre-activation) (mode 2)
+                for (int j = 0; j < 8; ++j) v[j] = (EPI < 0 ? v[j] * d.alpha : v[j]) + bias[j];
+                if (F_C2) {   // second output: pre-activation (mode 1) or GELU'(pre-activation) (mode 2)
                     float w[8];
-                    if (d.c2_mode == 2 && d.act == GA_ACT_GELU) {
+                    if (EPI >= 0 || (d.c2_mode == 2 && d.act == GA_ACT_GELU)) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) gelu_both_f(v[j], v[j], w[j]);   // v := gelu, w := gelu'
                     } else {
@@ -392,7 +410,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                             for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
                         }
                     }
-                    if (d.act == GA_ACT_RELU) {
+                    if (F_RELU) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                     }
@@ -404,14 +422,14 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                         for (int j = 0; j < 8; ++j)
                             if (n + j < d.N) elt<T>::st(C2p + j, w[j]);
                     }
-                } else if (d.act == GA_ACT_GELU) {
+                } else if (F_GELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-                } else if (d.act == GA_ACT_RELU) {
+                } else if (F_RELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
-                if (Hb) {
+                if (F_H) {
                     float h[8];
                     if (use_pre) {
                         if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], h);
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
                     }
-                    if (d.h_is_deriv) {
+                    if (F_HDERIV) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= h[j];
                     } else {
@@ -429,14 +447,14 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                         for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(h[j]);
                     }
                 }
-                if (d.rowscale) {
-                    const float s = d.rowscale[m / d.rows_per_scale];
+                if (F_RS) {
+                    const float s = d.rowscale[(unsigned)m / (unsigned)d.rows_per_scale];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] *= s;
                 }
-                if (Rb) {
+                if (F_R) {
                     float r[8];
-                    if (use_pre && !Hb) {
+                    if (use_pre && !F_H) {
                         if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], r);
                     } else if (full) {
                         load8(Rb + m * d.ldr + n, r);
@@ -447,11 +465,11 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += r[j];
                 }
-                if (d.relu_after) {
+                if (F_RELUA) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
-                if (d.colsum) {
+                if (F_CSUM) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         csum[j] += v[j];
@@ -459,17 +477,17 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                     }
                 }
                 long off;
-                if (d.c_kind == GA_C_UNPATCH2) {
-                    const int OW = d.c_W >> 1, OH = d.c_H >> 1;
-                    const int ox = (int)(m % OW);
-                    const long t = m / OW;
-                    const int oy = (int)(t % OH);
+                if (F_UNPATCH) {
+                    const unsigned OW = d.c_W >> 1, OH = d.c_H >> 1;
+                    const unsigned ox = (unsigned)m % OW;
+                    const unsigned t = (unsigned)m / OW;
+                    const unsigned oy = t % OH;
                     const long b = t / OH;
                     off = ((b * d.c_H + 2 * oy) * d.c_W + 2 * ox) * (long)d.c_C + c_off;
                 } else {
                     off = z * d.strideC + m * d.ldc + n;
                 }
-                if (d.c_f32) {
+                if (F_CF32) {
                     float* Cp = reinterpret_cast<float*>(d.C) + off;
                     if (full) {
                         store8(Cp, v);
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
             }
         }
     }
-    if (d.colsum) {  // workgroup-level column reduction over the RG row groups, then one atomic per column
+    if (F_CSUM) {  // workgroup-level column reduction over the RG row groups, then one atomic per column
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);  // [2][RG][BN]
         if (t_active) {
@@ -513,6 +531,18 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     }
     __syncthreads();  // LDS (C staging / reduction scratch) is free for the next tile's slab
     }  // persistent tile loop
+#undef F_GELU
+#undef F_RELU
+#undef F_C2
+#undef F_H
+#undef F_HDERIV
+#undef F_RS
+#undef F_R
+#undef F_RELUA
+#undef F_CSUM
+#undef F_UNPATCH
+#undef F_CF32
+#undef F_AACT
 }
 
 // ================================================================================================
@@ -536,14 +566,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int tiles_k = (d.K + 127) / 128;
-    const int tile_n = blockIdx.x / tiles_k, tile_k = blockIdx.x - tile_n * tiles_k;
+    // 1-D grid over (row split, output tile), walked XCD-aware: the output tiles of ONE row split re-read the same
+    // Y / X row panels, so they are given to workgroups of one XCD (ids b, b+8, ...) and share them in its L2.
+    const int tiles_k = (d.K + 127) / 128, tiles_n = (d.N + 127) / 128;
+    const int ntiles = tiles_k * tiles_n;
+    const int bid = xcd_remap(blockIdx.x, ntiles * d.split_m);
+    const int split = bid / ntiles, tile = bid - split * ntiles;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const int z = blockIdx.z;
     // m range of this split, in whole slabs
     const long slabs = (d.M + P::ROWS - 1) / P::ROWS;
     const long per = (slabs + d.split_m - 1) / d.split_m;
-    const long s_begin = (long)blockIdx.y * per;
+    const long s_begin = (long)split * per;
     const long s_end = s_begin + per < slabs ? s_begin + per : slabs;
     if (s_begin >= s_end) return;
 
@@ -694,24 +729,49 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
 // rounded down to a multiple of 8 so every XCD gets the same share of the tile walk
-template <typename T, int TNW, bool PLAIN, bool PRE>
+template <typename T, int TNW, bool PLAIN, bool PRE, int EPI>
 void launch_nt_(const ga_gemm_desc* d, int tiles, hipStream_t s) {
     static const int per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, PLAIN, PRE>, kThreads,
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, PLAIN, PRE, EPI>, kThreads,
                                                          NTCfg<TNW>::SMEM) != hipSuccess || n < 1)
             n = 2;
         return n;
     }();
     const int cap = std::max(8, (per_cu * num_cus() / d->batch) / 8 * 8);
     dim3 grid(std::min(tiles, cap), 1, d->batch), block(kThreads);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, PLAIN, PRE>), grid, block, NTCfg<TNW>::SMEM, s, *d);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, PLAIN, PRE, EPI>), grid, block, NTCfg<TNW>::SMEM, s, *d);
 }
-template <typename T, int TNW, bool PLAIN>
+
+// pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
+int classify_epilogue(const ga_gemm_desc* d) {
+    if (d->a_kind != GA_A_PLAIN || d->a_act != GA_ACT_NONE || d->alpha != 1.0f || d->c_kind != GA_C_PLAIN || d->c_f32 ||
+        d->relu_after)
+        return EPI_GENERIC;
+    const bool act0 = d->act == GA_ACT_NONE;
+    if (d->act == GA_ACT_GELU && d->C2 && d->c2_mode == 2 && !d->H && !d->R && !d->rowscale && !d->colsum) return EPI_FC1;
+    if (act0 && !d->C2 && !d->H && d->R && !d->colsum) return EPI_FC2;
+    if (act0 && !d->C2 && d->H && d->h_is_deriv && !d->R && !d->rowscale) return EPI_DG2;
+    if (act0 && !d->C2 && !d->H && !d->R && !d->rowscale) return EPI_PLAIN;
+    return EPI_GENERIC;
+}
+
+template <typename T, int TNW>
 void launch_nt(const ga_gemm_desc* d, int tiles, hipStream_t s) {
-    // the epilogue-operand prefetch costs 32 VGPRs: only the launches that read H or R take that variant
-    if (sizeof(T) == 2 && (d->H || d->R)) launch_nt_<T, TNW, PLAIN, true>(d, tiles, s);
-    else launch_nt_<T, TNW, PLAIN, false>(d, tiles, s);
+    constexpr bool BF = sizeof(T) == 2;   // the epilogue-operand prefetch exists for bf16 only (32 extra VGPRs)
+    if (d->a_kind != GA_A_PLAIN) {
+        launch_nt_<T, TNW, false, false, EPI_GENERIC>(d, tiles, s);
+        return;
+    }
+    switch (classify_epilogue(d)) {
+        case EPI_PLAIN: launch_nt_<T, TNW, true, false, EPI_PLAIN>(d, tiles, s); break;
+        case EPI_FC1: launch_nt_<T, TNW, true, false, EPI_FC1>(d, tiles, s); break;
+        case EPI_FC2: launch_nt_<T, TNW, true, BF, EPI_FC2>(d, tiles, s); break;
+        case EPI_DG2: launch_nt_<T, TNW, true, BF, EPI_DG2>(d, tiles, s); break;
+        default:
+            if (BF && (d->H || d->R)) launch_nt_<T, TNW, true, BF, EPI_GENERIC>(d, tiles, s);
+            else launch_nt_<T, TNW, true, false, EPI_GENERIC>(d, tiles, s);
+    }
 }
 
 }  // namespace
@@ -762,14 +822,12 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         tnw = (w4 <= w3 && w4 <= w2) ? 4 : (w3 <= w2 ? 3 : 2);
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool bf = d->dtype == GA_BF16, plain = d->a_kind == GA_A_PLAIN;
-#define GA_LAUNCH_NT(TNW)                                                                                   \
-    do {                                                                                                    \
-        const int tiles_ = cdiv(d->M, kBM) * cdiv(d->N, 32 * TNW);                                          \
-        if (bf && plain) launch_nt<bf16_t, TNW, true>(d, tiles_, s);                                        \
-        else if (bf) launch_nt<bf16_t, TNW, false>(d, tiles_, s);                                           \
-        else if (plain) launch_nt<float, TNW, true>(d, tiles_, s);                                          \
-        else launch_nt<float, TNW, false>(d, tiles_, s);                                                    \
+    const bool bf = d->dtype == GA_BF16;
+#define GA_LAUNCH_NT(TNW)                                              \
+    do {                                                               \
+        const int tiles_ = cdiv(d->M, kBM) * cdiv(d->N, 32 * TNW);     \
+        if (bf) launch_nt<bf16_t, TNW>(d, tiles_, s);                  \
+        else launch_nt<float, TNW>(d, tiles_, s);                      \
     } while (0)
     if (tnw == 4) GA_LAUNCH_NT(4);
     else if (tnw == 3) GA_LAUNCH_NT(3);
@@ -799,7 +857,7 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
     } else {
         GA_REQUIRE(false, "ga_wgrad: bad x_kind %d", d->x_kind);
     }
-    dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128), d->split_m, d->batch), block(kThreads);
+    dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128) * d->split_m, 1, d->batch), block(kThreads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->dtype == GA_BF16)
         hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, s, *d);

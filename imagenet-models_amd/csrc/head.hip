@@ -241,10 +241,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void chan_scale_kernel(const T* __restrict__ x, const float* __restrict__ g,
                                                          const float* __restrict__ add, T* __restrict__ y, long n8,
                                                          int HW, int C) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const long e = i * 8;
-        const int c = (int)(e % C);
-        const long b = e / ((long)HW * C);
+    const unsigned P = (unsigned)C >> 3, PB = P * (unsigned)HW;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
+        const long e = (long)i * 8;
+        const int c = (int)(i % P) << 3;
+        const long b = i / PB;
         float v[8];
         load8(x + e, v);
 #pragma unroll

@@ -201,10 +201,13 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
                                                          const float* __restrict__ shift, const T* __restrict__ res,
                                                          const float* __restrict__ rowscale, long elems_per_scale,
                                                          T* __restrict__ y, long n8, int C, int relu) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const long e = i * 8;
-        const int c = (int)(e % C);
-        const float rsc = rowscale ? rowscale[e / elems_per_scale] : 1.f;
+    // 32-bit index math (n8 < 2^31 for every tensor of this model): 64-bit div/mod costs more than the 16 B it moves
+    const unsigned P = (unsigned)C >> 3, rps = (unsigned)(elems_per_scale / C);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
+        const long e = (long)i * 8;
+        const unsigned row = i / P;
+        const int c = (int)(i - row * P) << 3;
+        const float rsc = rowscale ? rowscale[row / rps] : 1.f;
         float v[8], r[8];
         load8(x + e, v);
         if (res) load8(res + e, r);
@@ -289,10 +292,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
                                                            const float* __restrict__ rowscale, long elems_per_scale,
                                                            float inv_n, T* __restrict__ dx, long n8, int C) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const long e = i * 8;
-        const int c = (int)(e % C);
-        const float rsc = rowscale ? rowscale[e / elems_per_scale] : 1.f;
+    const unsigned P = (unsigned)C >> 3, rps = (unsigned)(elems_per_scale / C);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
+        const long e = (long)i * 8;
+        const unsigned row = i / P;
+        const int c = (int)(i - row * P) << 3;
+        const float rsc = rowscale ? rowscale[row / rps] : 1.f;
         float g[8], xv[8], yv[8];
         load8(dy + e, g);
         load8(x + e, xv);
@@ -376,7 +381,8 @@ extern "C" int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, c
 extern "C" int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res,
                              const float* rowscale, int64_t rows_per_scale, void* y, int64_t rows, int C, int relu,
                              int dtype, ga_stream_t stream) {
-    GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)), "ga_affine_act: bad args");
+    GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)) &&
+                   rows * C / 8 < (1L << 31), "ga_affine_act: bad args");
     const long n8 = rows * C / 8;
     dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -409,7 +415,8 @@ extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x
                                const float* w, const float* s1, const float* s2, const float* rowscale,
                                int64_t rows_per_scale, int64_t n, void* dx, int64_t rows, int C, int dtype,
                                ga_stream_t stream) {
-    GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0, "ga_bn_bwd_apply: bad args");
+    GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0 && rows * C / 8 < (1L << 31),
+               "ga_bn_bwd_apply: bad args");
     const long n8 = rows * C / 8;
     dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -187,9 +187,10 @@ __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, co
 template <typename T>
 __global__ __launch_bounds__(256) void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ s,
                                                        T* __restrict__ y, long n8, long elems_per_scale) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-        const long e = i * 8;
-        const float sc = s[e / elems_per_scale];
+    const unsigned eps8 = (unsigned)(elems_per_scale >> 3);
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
+        const long e = (long)i * 8;
+        const float sc = s[i / eps8];
         float v[8];
         load8(x + e, v);
 #pragma unroll
@@ -206,6 +207,145 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
 template <typename T>
 __global__ __launch_bounds__(256) void uncast_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = elt<T>::ld(src + i);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Batched variants: ONE launch walks a device-resident array of job descriptors (blockIdx.y = job).  A training
+// step has ~120 weight-prep, ~90 un-fold and ~60 tiny axpy/transpose jobs of a few KB..MB each; as separate
+// launches they cost ~3 ms of pure launch latency per step.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ void wprep_job(const ga_wprep_desc& d, int nblk, int blk) {
+    const int KK = d.Ci * d.KH * d.KW;
+    if (d.out) {
+        T* out = reinterpret_cast<T*>(d.out);
+        const long total = (long)d.G * d.Co * d.ldo;
+        for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
+            const int no = (int)(i / d.ldo), kcol = (int)(i - (long)no * d.ldo);
+            const int n = d.row_perm ? d.row_perm[no] : no;
+            float v = 0.f;
+            if (kcol < KK) {
+                int ci;
+                v = d.w[w_index(n, kcol, d.Ci, d.KH, d.KW, d.stem, &ci)];
+                if (d.rs) v *= d.rs[n];
+                if (d.cs) v *= d.cs[ci];
+            }
+            elt<T>::st(out + i, v);
+        }
+    }
+    if (d.outT) {
+        T* outT = reinterpret_cast<T*>(d.outT);
+        const int trows = d.flip ? d.Ci : KK;
+        const long total = (long)d.G * trows * d.ldt;
+        for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
+            const int col = (int)(i % d.ldt);
+            const long t = i / d.ldt;
+            const int r = (int)(t % trows), g = (int)(t / trows);
+            float v = 0.f;
+            if (!d.flip) {
+                if (col < d.Co) {
+                    const int n = d.row_perm ? d.row_perm[g * d.Co + col] : g * d.Co + col;
+                    int ci;
+                    v = d.w[w_index(n, r, d.Ci, d.KH, d.KW, d.stem, &ci)];
+                    if (d.rs) v *= d.rs[n];
+                    if (d.cs) v *= d.cs[ci];
+                }
+            } else if (col < d.KH * d.KW * d.Co) {
+                const int tapf = col / d.Co, co = col - tapf * d.Co;
+                const int tap = d.KH * d.KW - 1 - tapf;
+                const int n = d.row_perm ? d.row_perm[g * d.Co + co] : g * d.Co + co;
+                v = d.w[((long)n * d.Ci + r) * (d.KH * d.KW) + tap];
+                if (d.rs) v *= d.rs[n];
+                if (d.cs) v *= d.cs[r];
+            }
+            elt<T>::st(outT + i, v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wprep_batch_kernel(const ga_wprep_desc* __restrict__ jobs) {
+    const ga_wprep_desc d = jobs[blockIdx.y];
+    if (d.dtype == GA_BF16) wprep_job<bf16_t>(d, gridDim.x, blockIdx.x);
+    else wprep_job<float>(d, gridDim.x, blockIdx.x);
+}
+
+// small fp32 jobs: kind 0 axpy (y += a*x), 1 transpose (out[c][r] (+)= in[r][c]), 2 bias fold
+__global__ __launch_bounds__(256) void small_batch_kernel(const ga_small_desc* __restrict__ jobs) {
+    const ga_small_desc d = jobs[blockIdx.y];
+    if (d.kind == 0) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long)gridDim.x * 256) d.y[i] += d.a * d.x[i];
+    } else if (d.kind == 1) {
+        const long total = (long)d.R * d.C;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int c = (int)(i / d.R), r = (int)(i - (long)c * d.R);
+            const float v = d.x[(long)r * d.C + c];
+            d.y[i] = d.accumulate ? d.y[i] + v : v;
+        }
+    } else {   // bias fold: y[n] = rs[m]*(b[m] + sum_c W[m][c] v[c]), one wave per row
+        const int lane = threadIdx.x & 63;
+        for (int no = blockIdx.x * 4 + (threadIdx.x >> 6); no < d.R; no += gridDim.x * 4) {
+            const int n = d.row_perm ? d.row_perm[no] : no;
+            float s = 0.f;
+            if (d.v)
+                for (int c = lane; c < d.C; c += 64) s += d.x[(long)n * d.C + c] * d.v[c];
+            s = wave_sum(s);
+            if (lane == 0) d.y[no] = (d.rs ? d.rs[n] : 1.f) * ((d.b ? d.b[n] : 0.f) + s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void unfold_batch_kernel(const ga_wunfold_desc* __restrict__ jobs) {
+    const ga_wunfold_desc d = jobs[blockIdx.y];
+    const int KK = d.Ci * d.KH * d.KW;
+    if (d.dW) {
+        const long total = (long)d.N * KK;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+            const int no = (int)(i / KK), kcol = (int)(i - (long)no * KK);
+            const int n = d.row_perm ? d.row_perm[no] : no;
+            int ci;
+            const long wi = w_index(n, kcol, d.Ci, d.KH, d.KW, d.stem, &ci);
+            float val = d.G[(long)no * d.ldg + kcol];
+            if (d.cs) val *= d.cs[ci];
+            if (d.gb && d.v) val += d.gb[no] * d.v[ci];
+            if (d.rs) val *= d.rs[n];
+            d.dW[wi] += val;
+        }
+    }
+    if (d.d_rs || (d.db && d.gb)) {   // per-row part, one wave per row
+        const int lane = threadIdx.x & 63;
+        for (int no = blockIdx.x * 4 + (threadIdx.x >> 6); no < d.N; no += gridDim.x * 4) {
+            const int n = d.row_perm ? d.row_perm[no] : no;
+            if (d.d_rs) {
+                float s = 0.f;
+                for (int k = lane; k < KK; k += 64) {
+                    int ci;
+                    const long wi = w_index(n, k, d.Ci, d.KH, d.KW, d.stem, &ci);
+                    s += d.G[(long)no * d.ldg + k] * d.W[wi] * (d.cs ? d.cs[ci] : 1.f);
+                    if (d.gb && d.v) s += d.gb[no] * d.W[wi] * d.v[ci];
+                }
+                s = wave_sum(s);
+                if (lane == 0) d.d_rs[n] += s + ((d.gb && d.b) ? d.gb[no] * d.b[n] : 0.f);
+            }
+            if (d.db && d.gb && lane == 0) d.db[n] += (d.rs ? d.rs[n] : 1.f) * d.gb[no];
+        }
+    }
+    if (d.d_cs || d.d_v) {            // per-column part (1x1 weights): thread = column, block = slice of rows
+        const int rows_per_blk = (d.N + gridDim.x - 1) / gridDim.x;
+        const int r0 = blockIdx.x * rows_per_blk, r1 = min(d.N, r0 + rows_per_blk);
+        for (int c = threadIdx.x; c < d.Ci; c += 256) {
+            float a = 0.f, bs = 0.f;
+            for (int n = r0; n < r1; ++n) {
+                const float wv = d.W[(long)n * d.Ci + c] * (d.rs ? d.rs[n] : 1.f);
+                a += d.G[(long)n * d.ldg + c] * wv;
+                if (d.gb) bs += d.gb[n] * wv;
+            }
+            if (r1 > r0) {
+                if (d.d_cs) atomicAdd(d.d_cs + c, a);
+                if (d.d_v) atomicAdd(d.d_v + c, bs);
+            }
+        }
+    }
 }
 
 int nblocks(long n, int cap = 4096) { return (int)std::max<long>(1, std::min<long>(cap, (n + 255) / 256)); }
@@ -314,4 +454,22 @@ extern "C" int ga_cast_to_f32(const void* src, float* dst, int64_t n, int dtype,
     else
         hipLaunchKernelGGL(uncast_kernel<float>, dim3(nblocks(n)), dim3(256), 0, st, (const float*)src, dst, (long)n);
     return ga_check_launch("ga_cast_to_f32");
+}
+
+extern "C" int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_stream_t stream) {
+    GA_REQUIRE(jobs_dev && n > 0, "ga_weight_prep_batch: bad args");
+    hipLaunchKernelGGL(wprep_batch_kernel, dim3(48, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    return ga_check_launch("ga_weight_prep_batch");
+}
+
+extern "C" int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t stream) {
+    GA_REQUIRE(jobs_dev && n > 0, "ga_small_batch: bad args");
+    hipLaunchKernelGGL(small_batch_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    return ga_check_launch("ga_small_batch");
+}
+
+extern "C" int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream) {
+    GA_REQUIRE(jobs_dev && n > 0, "ga_weight_unfold_batch: bad args");
+    hipLaunchKernelGGL(unfold_batch_kernel, dim3(32, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    return ga_check_launch("ga_weight_unfold_batch");
 }

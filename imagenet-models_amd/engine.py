@@ -87,9 +87,12 @@ class GAEngine:
         if training:
             self.arena = torch.zeros(int(flat['total'] * 1.15) + (1 << 20), device=self.dev)
         self._nbt = [t for n, t in self.Bf.items() if n.endswith('num_batches_tracked')]
-        self.prep = Plan(name='prep')
+        self.prep = Plan(name='prep', defer_small=True)
         self.fwd = Plan(name='fwd')
-        self.bwd = Plan(name='bwd') if training else None
+        self.bwd = Plan(name='bwd', defer_small=True) if training else None
+        # BatchNorm column-sum accumulators live in one pool that the forward plan zeroes with a single memset
+        self.bn_pool = torch.zeros(1 << 16, device=self.dev)
+        self.bn_pool_off = 0
         self._build()
 
     # ------------------------------------------------------------------------------------------
@@ -167,6 +170,8 @@ class GAEngine:
         self.x_in = None
         # ---------------- stem ----------------
         M0 = B * S0 * S0
+        if T:
+            F.zero(self.bn_pool, label='zero.bn_sums')
         Wst = self._w_plain('stem.0.weight', d[0], 3, 4, 4, stem=True, need_T=False)
         stem_pre = self.act('stem.pre', (M0, d[0]))
         self.x_placeholder = torch.zeros(8, device=self.dev)  # patched by set_input
@@ -233,6 +238,8 @@ class GAEngine:
         # ---------------- backward ----------------
         if T:
             self._build_backward(feats, taps, stage_in, x4, M4, ctot)
+            self.bwd.flush('end.')
+        self.prep.flush('prep.')
 
     @staticmethod
     def _last_desc(plan):
@@ -349,8 +356,14 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     # BatchNorm helper (stats come from the producing GEMM's colsum epilogue)
     # ------------------------------------------------------------------------------------------
+    def _bn_pool(self, C):
+        off = (self.bn_pool_off + 63) // 64 * 64
+        assert off + C <= self.bn_pool.numel()
+        self.bn_pool_off = off + C
+        return self.bn_pool[off:off + C]
+
     def _bn_bufs(self, pre, C):
-        return dict(s=self.buf(pre + 's', (C,), torch.float32, zero=True), q=self.buf(pre + 'q', (C,), torch.float32, zero=True),
+        return dict(s=self._bn_pool(C), q=self._bn_pool(C),
                     mean=self.buf(pre + 'bmean', (C,), torch.float32), rstd=self.buf(pre + 'brstd', (C,), torch.float32),
                     scale=self.buf(pre + 'scale', (C,), torch.float32), shift=self.buf(pre + 'shift', (C,), torch.float32))
 
@@ -383,8 +396,6 @@ class GAEngine:
         def conv_bn(name, bnname, A, Wt, N, Kdim, bias=None, **kw):
             c = self.act(pre + name + '.out', (M4, N))
             bn = self._bn_bufs(pre + bnname + '.', N)
-            if stats:
-                F.zero(bn['s']); F.zero(bn['q'])
             F.gemm(A, Wt, c, M4, N, Kdim, dt, bias=bias, colsum=bn['s'] if stats else None,
                    colsumsq=bn['q'] if stats else None, label=pre + name, **kw)
             self._bn_finalize(pre + bnname + '.', bn, M4, N)
@@ -481,8 +492,6 @@ class GAEngine:
         Wgc = self._w_plain(pre + '0.weight', g, cout, 1, 1)
         h['gc'] = self.act(pre + 'out', (M4, g))
         h['bn_gc'] = self._bn_bufs(pre + '1.', g)
-        if T:
-            F.zero(h['bn_gc']['s']); F.zero(h['bn_gc']['q'])
         F.gemm(x4, Wgc, h['gc'], M4, g, cout, dt, bias=P[pre + '0.bias'], colsum=h['bn_gc']['s'] if T else None,
                colsumsq=h['bn_gc']['q'] if T else None, label=pre + 'conv')
         self._bn_finalize(pre + '1.', h['bn_gc'], M4, g)
@@ -511,8 +520,6 @@ class GAEngine:
         Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp)
         h['e'] = self.act(pre + 'out', (B, cout))
         h['bn_e'] = self._bn_bufs(pre + '1.', cout)
-        if T:
-            F.zero(h['bn_e']['s']); F.zero(h['bn_e']['q'])
         F.gemm(h['vec'], Wemb, h['e'], B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
                ldc=cout, strideC=cg, bias=P[pre + '0.bias'], strideBias=cg, colsum=h['bn_e']['s'] if T else None,
                colsumsq=h['bn_e']['q'] if T else None, strideCol=cg, label=pre + 'conv')
@@ -709,6 +716,7 @@ class GAEngine:
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
+        Bk.flush('heads.')
         Bk.mark('heads')      # every gradient of stages.4 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
         seeds = []
@@ -750,6 +758,7 @@ class GAEngine:
                                  seed[i - 1], dprev, self.grad(pre + '0.weight'), self.grad(pre + '0.bias'), Mp, d[i - 1],
                                  False, dt, label=pre + 'lnb')
                 dy = dprev
+            Bk.flush(f'stage{i}.')
             Bk.mark(f'stage{i}')  # gradients of stages.i (incl. its downsample) are final
         # stem
         M0 = dy.shape[0]

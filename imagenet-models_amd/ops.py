@@ -47,13 +47,34 @@ def current_stream_ptr():
 
 
 class Plan:
-    def __init__(self, eager=False, name=''):
+    def __init__(self, eager=False, name='', defer_small=False):
         self.lib = L.load()
         self.calls = []      # (cfunc, args tuple, label)
         self.keep = []       # tensors / descriptors kept alive
         self.eager = eager
         self.name = name
         self.marks = {}
+        # defer_small: weight-prep / un-fold / bias-fold / transpose / axpy jobs are collected and emitted by flush()
+        # as ONE batched launch per kind over a device-resident descriptor array
+        self.defer = defer_small and not eager
+        self._pend = {'wprep': [], 'small': [], 'unfold': []}
+
+    def flush(self, label=''):
+        for kind, fname, cls in (('wprep', 'ga_weight_prep_batch', L.WprepDesc), ('small', 'ga_small_batch', L.SmallDesc),
+                                 ('unfold', 'ga_weight_unfold_batch', L.WunfoldDesc)):
+            lst = self._pend[kind]
+            if not lst:
+                continue
+            arr = (cls * len(lst))(*lst)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+            self._add(fname, (dev.data_ptr(), len(lst)), f'{label}{kind}.batch[{len(lst)}]', keep=(dev, arr))
+            self._pend[kind] = []
+
+    def _small(self, **kw):
+        d = L.SmallDesc()
+        for k, v in kw.items():
+            setattr(d, k, v)
+        self._pend['small'].append(d)
 
     # -- core ---------------------------------------------------------------------------------------
     def _add(self, fname, args, label=None, keep=()):
@@ -139,9 +160,17 @@ class Plan:
         d.w, d.G, d.Co, d.Ci, d.KH, d.KW = _ptr(w), G, Co, Ci, KH, KW
         d.rs, d.cs, d.row_perm, d.dtype = _ptr(rs), _ptr(cs), _ptr(row_perm), dtype
         d.out, d.ldo, d.outT, d.ldt, d.flip, d.stem = _ptr(out), ldo, _ptr(outT), ldt, int(flip), int(stem)
+        if self.defer:
+            self._pend['wprep'].append(d)
+            self.keep.extend((w, out, outT, rs, cs, row_perm))
+            return
         self._add('ga_weight_prep', (C.byref(d),), label, keep=(d, w, out, outT, rs, cs, row_perm))
 
     def bias_fold(self, W, b, rs, v, be, N, Cdim, row_perm=None, label=None):
+        if self.defer:
+            self._small(kind=2, y=_ptr(be), x=_ptr(W), R=N, C=Cdim, b=_ptr(b), rs=_ptr(rs), v=_ptr(v), row_perm=_ptr(row_perm))
+            self.keep.extend((W, b, rs, v, be, row_perm))
+            return
         self._add('ga_bias_fold', (_ptr(W), _ptr(b), _ptr(rs), _ptr(v), _ptr(row_perm), _ptr(be), N, Cdim), label,
                   keep=(W, b, rs, v, be, row_perm))
 
@@ -152,6 +181,10 @@ class Plan:
         d.row_perm = _ptr(row_perm)
         d.N, d.Ci, d.KH, d.KW, d.stem = N, Ci, KH, KW, int(stem)
         d.dW, d.db, d.d_rs, d.d_cs, d.d_v = _ptr(dW), _ptr(db), _ptr(d_rs), _ptr(d_cs), _ptr(d_v)
+        if self.defer:
+            self._pend['unfold'].append(d)
+            self.keep.extend((G, gb, W, b, rs, cs, v, dW, db, d_rs, d_cs, d_v, row_perm))
+            return
         self._add('ga_weight_unfold', (C.byref(d),), label, keep=(d, G, gb, W, b, rs, cs, v, dW, db, d_rs, d_cs, d_v, row_perm))
 
     # -- depthwise conv / norms ---------------------------------------------------------------------
@@ -264,9 +297,17 @@ class Plan:
 
     # -- utilities ----------------------------------------------------------------------------------
     def transpose_f32(self, src, dst, R, Cdim, accumulate=False, label=None):
+        if self.defer:
+            self._small(kind=1, y=_ptr(dst), x=_ptr(src), R=R, C=Cdim, accumulate=int(accumulate))
+            self.keep.extend((src, dst))
+            return
         self._add('ga_transpose_f32', (_ptr(src), _ptr(dst), R, Cdim, int(accumulate)), label, keep=(src, dst))
 
     def axpy_f32(self, y, x, a, n, label=None):
+        if self.defer:
+            self._small(kind=0, y=_ptr(y), x=_ptr(x), a=a, n=n)
+            self.keep.extend((y, x))
+            return
         self._add('ga_axpy_f32', (_ptr(y), _ptr(x), a, n), label, keep=(y, x))
 
     def rowscale(self, x, s, y, n, elems_per_scale, dtype, label=None):

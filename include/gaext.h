@@ -281,6 +281,19 @@ int ga_sgd_step(float* p, const float* g, float* buf, const float* hp, int64_t n
 int ga_adamw_step(float* p, const float* g, float* m, float* v, const float* hp, int64_t n, float wd_mult,
                   ga_stream_t stream);
 
+/* Batched variants: `jobs_dev` is a DEVICE-resident array of n descriptors (same structs as above); one launch
+ * processes them all (grid.y = job).  Used for the ~270 small per-parameter jobs of a training step. */
+typedef struct {
+    int kind;              /* 0: y[i] += a*x[i] (n elems); 1: y[c][r] (+)= x[r][c] (x is [R][C]); 2: bias fold (R rows, C cols):
+                              y[n] = rs[m]*(b[m] + sum_c x[m][c]*v[c]), m = row_perm ? row_perm[n] : n */
+    float* y; const float* x; float a; int64_t n;
+    int R, C, accumulate;
+    const float* b; const float* rs; const float* v; const int* row_perm;
+} ga_small_desc;
+int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_stream_t stream);
+int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream);
+int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
