@@ -206,7 +206,7 @@ def main():
         if a.kernel_table:
             with open(a.kernel_table, 'w') as fh:
                 json.dump(dict(total_ms=total_ms, families=table,
-                               top_calls=sorted(calls, key=lambda c: -c['ms'])[:150]), fh, indent=1)
+                               top_calls=sorted(calls, key=lambda c: -c["ms"])), fh, indent=1)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline()
     if rank == 0:

@@ -15,6 +15,7 @@
 //    transposing LDS read, on a [rows][128] image whose 32-byte pieces are XOR-swizzled conflict-free.
 //  * blockIdx -> tile mapping is XCD-aware: the 8 XCDs each take a contiguous chunk of the tile list so that
 //    workgroups sharing an operand panel hit the same L2.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -29,9 +30,8 @@ int num_cus() {
     return n;
 }
 
-constexpr int kBM = 128, kThreads = 256;
+constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;          // bytes of K per LDS row (NT kernel)
-constexpr int kTileBytes = kBM * kRowBytes;  // 16 KiB per operand per buffer
 
 // bijective XCD-aware remap of a linear workgroup id (guide T1): blocks b, b+8, b+16.. share an XCD
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -163,14 +163,20 @@ template <typename T> __device__ __forceinline__ uint4 act_chunk(uint4 v, int ac
 // halves (<= 34 KiB).  Small LDS + <= 128 VGPRs (TNW <= 3) give 4 resident workgroups per CU, i.e. >= 100 KiB of
 // loads in flight per CU -- these GEMMs (K, N <= 3072, M ~ 10^6) are HBM-latency bound, not MFMA bound.
 // ================================================================================================
-template <int TNW> struct NTCfg {
+template <int TNW, int NWM> struct NTCfg {
+    static constexpr int NTHR = 128 * NWM;                    // NWM x 2 waves
+    static constexpr int BM = 64 * NWM;                       // 128 (4 waves) or 256 (8 waves: 2.7x less operand traffic per FLOP)
     static constexpr int BN = 32 * TNW;
-    static constexpr int LDCS = BN + 4;                       // padded fp32 row stride of the staged half tile
-    static constexpr int SMEM_AB = kTileBytes + BN * kRowBytes;
+    static constexpr int A_BYTES = BM * kRowBytes;
+    static constexpr int RSTEP = NTHR / 8;                    // rows staged per pass of the workgroup
+    static constexpr int NB = BN * 8 / NTHR;                  // B chunks per thread per slab
+    static_assert((BN * 8) % NTHR == 0, "B slab must split evenly over the threads");
+    static constexpr int LDCS = BN + 4;                       // padded fp32 row stride of the staged 64-row piece
+    static constexpr int SMEM_AB = A_BYTES + BN * kRowBytes;
     static constexpr int SMEM_C = 64 * LDCS * 4;
     static constexpr int SMEM = SMEM_AB > SMEM_C ? SMEM_AB : SMEM_C;
     static constexpr int P8 = BN / 8;                         // 8-column pieces per row
-    static constexpr int RG = kThreads / P8;                  // row groups in the coalesced store phase
+    static constexpr int RG = NTHR / P8;                      // row groups in the coalesced store phase
 };
 
 // EPI >= 0 fixes the epilogue at compile time (dead paths are not even emitted: the all-runtime generic kernel is
@@ -179,8 +185,8 @@ template <int TNW> struct NTCfg {
 //   2 fc2: bias (+ DropPath row scale) + residual      3 dgrad2: multiply by the stored GELU' (+ column sums)
 enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_FC1 = 1, EPI_FC2 = 2, EPI_DG2 = 3 };
 
-template <typename T, int TNW, bool PLAIN, bool PRE, int EPI>
-__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d) {
+template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI>
+__global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d) {
 #define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
 #define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
 #define F_C2 (EPI < 0 ? d.C2 != nullptr : EPI == EPI_FC1)
@@ -193,17 +199,17 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
 #define F_UNPATCH (EPI < 0 ? d.c_kind == GA_C_UNPATCH2 : false)
 #define F_CF32 (EPI < 0 ? d.c_f32 != 0 : false)
 #define F_AACT (EPI < 0 ? d.a_act : GA_ACT_NONE)
-    using CF = NTCfg<TNW>;
+    using CF = NTCfg<TNW, NWM>;
     constexpr int EPC = elt<T>::EPC;
     constexpr int BK = kRowBytes / (int)sizeof(T);
     constexpr int BN = CF::BN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Bs = smem + kTileBytes;
+    unsigned char* Bs = smem + CF::A_BYTES;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + kBM - 1) / kBM;
+    const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + CF::BM - 1) / CF::BM;
     const int nwg = tiles_n * tiles_m;
     const int z = blockIdx.z;
     const int za = d.a_batch_mod > 0 ? z % d.a_batch_mod : z;
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                               (d.a_kind == GA_A_STEM4_NCHW ? 4 : (long)sizeof(T)) * za * d.strideA;
     const T* Bb = reinterpret_cast<const T*>(d.B) + z * d.strideB;
 
-    // ---- staging roles: thread stages rows r0+32*i of A (i<4) and of B (i<TNW), chunk column kc
+    // ---- staging roles: thread stages rows r0+RSTEP*i of A (i<4) and of B (i<NB), chunk column kc
     const int kc = tid & 7, r0 = tid >> 3;
     const int nk = (d.K + BK - 1) / BK;
     RowCtx arow[PLAIN ? 1 : 4];   // gather kinds keep a full context per staged row; PLAIN only needs m0
@@ -223,16 +229,16 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     auto set_tile = [&](int vt) {
         const int bid = xcd_remap(vt, nwg);
         const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
-        m0 = tile_m * kBM;
+        m0 = tile_m * CF::BM;
         n0 = tile_n * BN;
         if constexpr (!PLAIN) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                arow[i] = make_row(d.a_kind, (long)m0 + r0 + 32 * i, d.M, d.lda, d.a_H, d.a_W, d.a_C);
+                arow[i] = make_row(d.a_kind, (long)m0 + r0 + CF::RSTEP * i, d.M, d.lda, d.a_H, d.a_W, d.a_C);
         }
     };
 
-    uint4 ra[4], rb[TNW];
+    uint4 ra[4], rb[CF::NB];
     auto g_load = [&](int kt) {
         const int k = kt * BK + kc * EPC;
         const bool kv = k < d.K;
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
             const T* Ap = reinterpret_cast<const T*>(Ab) + k;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const long m = (long)m0 + r0 + 32 * i;
+                const long m = (long)m0 + r0 + CF::RSTEP * i;
                 ra[i] = (kv && m < d.M) ? *reinterpret_cast<const uint4*>(Ap + m * d.lda) : make_uint4(0, 0, 0, 0);
             }
         } else {
@@ -249,20 +255,20 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
             for (int i = 0; i < 4; ++i) ra[i] = load_chunk<T>(d.a_kind, Ab, arow[i], kx, d.a_H, d.a_W, d.a_C);
         }
 #pragma unroll
-        for (int i = 0; i < TNW; ++i) {
-            const long n = (long)n0 + r0 + 32 * i;
+        for (int i = 0; i < CF::NB; ++i) {
+            const long n = (long)n0 + r0 + CF::RSTEP * i;
             rb[i] = (kv && n < d.N) ? *reinterpret_cast<const uint4*>(Bb + n * d.ldb + k) : make_uint4(0, 0, 0, 0);
         }
     };
     auto s_store = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = r0 + 32 * i;
+            const int row = r0 + CF::RSTEP * i;
             *reinterpret_cast<uint4*>(As + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = act_chunk<T>(ra[i], F_AACT);
         }
 #pragma unroll
-        for (int i = 0; i < TNW; ++i) {
-            const int row = r0 + 32 * i;
+        for (int i = 0; i < CF::NB; ++i) {
+            const int row = r0 + CF::RSTEP * i;
             *reinterpret_cast<uint4*>(Bs + row * kRowBytes + ((kc ^ (row & 7)) << 4)) = rb[i];
         }
     };
@@ -278,9 +284,11 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
     // LDS staging instead of being paid once per row in the store loop.
     constexpr int NR = (64 + CF::RG - 1) / CF::RG;
     constexpr bool kPre = PRE && sizeof(T) == 2;
-    uint4 pre[kPre ? 2 : 1][kPre ? NR : 1];
+    uint4 pre[kPre ? NWM : 1][kPre ? NR : 1];
     const T* Pb = F_H ? Hb : Rb;
     const long ldp = F_H ? d.ldh : d.ldr;
+
+    auto pre_sel = [&](int hf, int it) -> const uint4& { return pre[kPre ? hf : 0][kPre ? it : 0]; };
 
     int vt = blockIdx.x;
     set_tile(vt);
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
         if constexpr (kPre) {
             if (kt == nk - 1 && use_pre) {
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+                for (int hf = 0; hf < NWM; ++hf)
 #pragma unroll
                     for (int it = 0; it < NR; ++it) {
                         const int row = rg + it * CF::RG;
@@ -369,8 +377,8 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
         const int tap = n / d.c_C, ch = n - tap * d.c_C;
         c_off = ((long)(tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch;
     }
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int half = 0; half < NWM; ++half) {
         if (half) __syncthreads();  // previous half fully read
         if (wm == half) {
 #pragma unroll
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                 if (F_H) {
                     float h[8];
                     if (use_pre) {
-                        if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], h);
+                        if constexpr (kPre) unpack8(pre_sel(half, it), h);
                     } else if (full) {
                         load8(Hb + m * d.ldh + n, h);
                     } else {
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
                 if (F_R) {
                     float r[8];
                     if (use_pre && !F_H) {
-                        if constexpr (kPre) unpack8(half == 0 ? pre[0][it] : pre[1][it], r);
+                        if constexpr (kPre) unpack8(pre_sel(half, it), r);
                     } else if (full) {
                         load8(Rb + m * d.ldr + n, r);
                     } else {
@@ -520,7 +528,7 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const ga_gemm_desc d)
             }
         }
         __syncthreads();
-        for (int i = tid; i < 2 * BN; i += kThreads) {
+        for (int i = tid; i < 2 * BN; i += CF::NTHR) {
             const int which = i / BN, col = i - which * BN;
             if (cn0 + col < d.N && (which == 0 || d.colsumsq)) {
                 float s = 0.f;
@@ -729,18 +737,20 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
 // rounded down to a multiple of 8 so every XCD gets the same share of the tile walk
-template <typename T, int TNW, bool PLAIN, bool PRE, int EPI>
-void launch_nt_(const ga_gemm_desc* d, int tiles, hipStream_t s) {
+template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI>
+void launch_nt_(const ga_gemm_desc* d, hipStream_t s) {
+    using CF = NTCfg<TNW, NWM>;
     static const int per_cu = [] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, PLAIN, PRE, EPI>, kThreads,
-                                                         NTCfg<TNW>::SMEM) != hipSuccess || n < 1)
-            n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, NWM, PLAIN, PRE, EPI>, CF::NTHR,
+                                                         CF::SMEM) != hipSuccess || n < 1)
+            n = 1;
         return n;
     }();
+    const int tiles = cdiv(d->M, CF::BM) * cdiv(d->N, CF::BN);
     const int cap = std::max(8, (per_cu * num_cus() / d->batch) / 8 * 8);
-    dim3 grid(std::min(tiles, cap), 1, d->batch), block(kThreads);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, PLAIN, PRE, EPI>), grid, block, NTCfg<TNW>::SMEM, s, *d);
+    dim3 grid(std::min(tiles, cap), 1, d->batch), block(CF::NTHR);
+    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, NWM, PLAIN, PRE, EPI>), grid, block, CF::SMEM, s, *d);
 }
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
@@ -756,21 +766,35 @@ int classify_epilogue(const ga_gemm_desc* d) {
     return EPI_GENERIC;
 }
 
-template <typename T, int TNW>
-void launch_nt(const ga_gemm_desc* d, int tiles, hipStream_t s) {
+// 256-row tiles (8 waves, one workgroup per CU) for the two epilogues that carry a prefetched epilogue operand
+// (fc2: + shortcut, dgrad2: * gelu'): their 4-wave form sits at 160-170 VGPRs = 2 workgroups per CU, and the wide
+// tile reads the weight slab once per 256 rows.  Measured on MI355X (tools/gemm_bench.py): dgrad2 1.35-1.45x,
+// fc2 1.1-1.2x; the plain / fc1 epilogues (120 VGPRs, 4 workgroups per CU) are 5-15 % SLOWER with it.
+bool want_big_tile(const ga_gemm_desc* d, int epi) {
+    static const int force = [] {
+        const char* e = getenv("GAEXT_NT_BIG");   // 0 / 1 override for experiments; unset = heuristic
+        return e ? atoi(e) : -1;
+    }();
+    if (d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || (epi != EPI_FC2 && epi != EPI_DG2)) return false;
+    if (force >= 0) return force != 0;
+    return (long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch >= 2L * num_cus();
+}
+
+template <typename T, int TNW, int NWM>
+void launch_nt(const ga_gemm_desc* d, hipStream_t s) {
     constexpr bool BF = sizeof(T) == 2;   // the epilogue-operand prefetch exists for bf16 only (32 extra VGPRs)
     if (d->a_kind != GA_A_PLAIN) {
-        launch_nt_<T, TNW, false, false, EPI_GENERIC>(d, tiles, s);
+        launch_nt_<T, TNW, NWM, false, false, EPI_GENERIC>(d, s);
         return;
     }
     switch (classify_epilogue(d)) {
-        case EPI_PLAIN: launch_nt_<T, TNW, true, false, EPI_PLAIN>(d, tiles, s); break;
-        case EPI_FC1: launch_nt_<T, TNW, true, false, EPI_FC1>(d, tiles, s); break;
-        case EPI_FC2: launch_nt_<T, TNW, true, BF, EPI_FC2>(d, tiles, s); break;
-        case EPI_DG2: launch_nt_<T, TNW, true, BF, EPI_DG2>(d, tiles, s); break;
+        case EPI_PLAIN: launch_nt_<T, TNW, NWM, true, false, EPI_PLAIN>(d, s); break;
+        case EPI_FC1: launch_nt_<T, TNW, NWM, true, false, EPI_FC1>(d, s); break;
+        case EPI_FC2: launch_nt_<T, TNW, NWM, true, BF, EPI_FC2>(d, s); break;
+        case EPI_DG2: launch_nt_<T, TNW, NWM, true, BF, EPI_DG2>(d, s); break;
         default:
-            if (BF && (d->H || d->R)) launch_nt_<T, TNW, true, BF, EPI_GENERIC>(d, tiles, s);
-            else launch_nt_<T, TNW, true, false, EPI_GENERIC>(d, tiles, s);
+            if (BF && (d->H || d->R)) launch_nt_<T, TNW, NWM, true, BF, EPI_GENERIC>(d, s);
+            else launch_nt_<T, TNW, NWM, true, false, EPI_GENERIC>(d, s);
     }
 }
 
@@ -823,15 +847,24 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool bf = d->dtype == GA_BF16;
-#define GA_LAUNCH_NT(TNW)                                              \
-    do {                                                               \
-        const int tiles_ = cdiv(d->M, kBM) * cdiv(d->N, 32 * TNW);     \
-        if (bf) launch_nt<bf16_t, TNW>(d, tiles_, s);                  \
-        else launch_nt<float, TNW>(d, tiles_, s);                      \
+#define GA_LAUNCH_NT(TNW, NWM)                          \
+    do {                                               \
+        if (bf) launch_nt<bf16_t, TNW, NWM>(d, s);     \
+        else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
-    if (tnw == 4) GA_LAUNCH_NT(4);
-    else if (tnw == 3) GA_LAUNCH_NT(3);
-    else GA_LAUNCH_NT(2);
+    if (tnw == 4) {
+        const int epi = classify_epilogue(d);
+        if (want_big_tile(d, epi)) {
+            if (epi == EPI_FC2) launch_nt_<bf16_t, 4, 4, true, true, EPI_FC2>(d, s);
+            else launch_nt_<bf16_t, 4, 4, true, true, EPI_DG2>(d, s);
+        } else {
+            GA_LAUNCH_NT(4, 2);
+        }
+    } else if (tnw == 3) {
+        GA_LAUNCH_NT(3, 2);
+    } else {
+        GA_LAUNCH_NT(2, 2);
+    }
 #undef GA_LAUNCH_NT
     return ga_check_launch("ga_gemm");
 }
