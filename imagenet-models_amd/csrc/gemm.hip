@@ -17,6 +17,7 @@
 //    workgroups sharing an operand panel hit the same L2.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -733,6 +734,193 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
     }
 }
 
+// ================================================================================================
+// TN kernel, wide form (bf16, plain operands, M % 64 == 0): 256 x 256 output tile, 8 waves (2 over n x 4 over k,
+// 128 x 64 per wave), operands brought in by LDS-DMA (global_load_lds_dwordx4) into two 64 KiB stage buffers:
+// the loads of stage s+1 are in flight while stage s is multiplied, one barrier per stage.
+// A stage = 64 reduction rows x {Y0, Y1, X0, X1}, each a [64][256 B] image in the same XOR layout as the narrow
+// kernel (the DMA writes LDS lane-linearly, so the swizzle is applied to the SOURCE chunk each lane fetches).
+// vs the 128 x 128 form: half the operand bytes per FLOP from L2 and no staging registers / ds_writes.
+// Column sums of Y (bias gradient) ride along as one extra MFMA per fragment against a constant ones operand.
+// ================================================================================================
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB) (dst is
+// wave-uniform, carried in M0).  Written as asm so that hipcc does not count it: a builtin glds makes every later
+// ds_read wait vmcnt(0) (possible alias), which would drain the prefetch it exists for.  The kernel waits itself.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+constexpr int kTn2Threads = 512, kTn2Stage = 65536, kTn2Smem = 2 * kTn2Stage;
+
+__global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_desc d, const int split_m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform roles stay in SGPRs
+    const int wn = wave >> 2, wk = wave & 3;
+    const int tiles_k = (d.K + 255) / 256, tiles_n = (d.N + 255) / 256;
+    const int ntiles = tiles_k * tiles_n;
+    const int bid = xcd_remap(blockIdx.x, ntiles * split_m);
+    const int split = bid / ntiles, tile = bid - split * ntiles;
+    const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
+    const int n0 = tile_n * 256, k0 = tile_k * 256;
+    const int z = blockIdx.z;
+    const int stages = d.M / 64;
+    const int per = (stages + split_m - 1) / split_m;
+    const int s_begin = split * per;
+    const int s_end = s_begin + per < stages ? s_begin + per : stages;
+    if (s_begin >= s_end) return;
+
+    // ---- DMA role: wave w fills sub-image w>>1 (0,1 = Y halves; 2,3 = X halves), rows 32*(w&1) + 4*i + (lane>>4)
+    const int sub = wave >> 1;
+    const bool is_y = sub < 2;
+    const int ncols = is_y ? d.N : d.K;
+    const int col0 = (is_y ? n0 : k0) + (sub & 1) * 128;          // first column of the sub-image
+    const bool sub_live = col0 < ncols;                            // wholly out of range: never fetched, never used
+    const long ld = is_y ? d.ldy : d.ldx;
+    const int zx = d.x_batch_mod > 0 ? z % d.x_batch_mod : z;
+    const bf16_t* gsrc = is_y ? reinterpret_cast<const bf16_t*>(d.Y) + z * d.strideY
+                              : reinterpret_cast<const bf16_t*>(d.X) + zx * d.strideX;
+    const int lrow = 32 * (wave & 1) + (lane >> 4);                // + 4*i
+    const int pc = lane & 15;
+    // source chunk for i even / odd pairs: swizzle = ((row&3)<<1) | (((row>>3)&1)<<3), row&3 = (lane>>4)&3, row bit 3 = (i>>1)&1
+    const int sw_lo = ((lane >> 4) & 3) << 1;
+    long goff[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        int c = col0 + ((pc ^ (sw_lo | (b << 3))) << 3);
+        if (c >= ncols) c = 0;                                     // feeds output columns that are never written
+        goff[b] = (long)lrow * ld + c;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto stage_load = [&](int s, int buf) {
+        if (!sub_live) return;
+        const bf16_t* g = gsrc + (long)s * 64 * ld;
+        const unsigned dst = lds0 + buf * kTn2Stage + sub * 16384 + (wave & 1) * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) glds16(g + goff[(i >> 1) & 1] + (long)(4 * i) * ld, dst + i * 1024);
+    };
+
+    // ---- MFMA role
+    int nv = (d.N - n0 - wn * 128 + 15) / 16; nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);   // live n fragments of this wave
+    int kv = (d.K - k0 - wk * 64 + 15) / 16;  kv = kv < 0 ? 0 : (kv > 4 ? 4 : kv);   // live k fragments
+    const bool do_bias = d.dbias != nullptr && tile_k == 0 && wk == 0;
+    f32x4_t acc[8][4];
+    float bsum[8];                             // column sums of Y over this lane's share of the reduction rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        bsum[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
+
+    const unsigned y_img = wn * 16384, x_img = 32768 + (wk >> 1) * 16384;
+    const int xc0 = (wk & 1) * 8;                                  // first chunk of this wave's 64 X columns
+    // fragment addresses: the XOR term depends on the lane only (row & 3 and bit 3 of the row are the same for both
+    // 4-row halves and both k-steps), so one address per fragment column + immediates for half / k-step / buffer
+    unsigned yaddr[8], xaddr[4];
+    {
+        const int row = 8 * (lane >> 4) + ((lane & 15) >> 2);
+        const int sw = tn_swz(row);
+        const unsigned rb = row * 256 + 8 * (lane & 1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) yaddr[t] = y_img + rb + (((2 * t + ((lane & 3) >> 1)) ^ sw) << 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) xaddr[t] = x_img + rb + (((xc0 + 2 * t + ((lane & 3) >> 1)) ^ sw) << 4);
+    }
+    // one stage = 2 k-steps of 32 reduction rows.  Fragments beyond N / K are multiplied too (their inputs are
+    // clamped loads, their outputs are never written): no predicates in the loop.
+    auto compute = [&](int cur) {
+        const unsigned char* st = smem + cur * kTn2Stage;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x4_t yf[8][2], xf[4][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    xf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(st + xaddr[t] + ks * 8192 + hf * 1024));
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    yf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4_t*)(st + yaddr[t] + ks * 8192 + hf * 1024));
+            }
+#pragma unroll
+            for (int tn = 0; tn < 8; ++tn) {
+                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]);
+#pragma unroll
+                for (int tk = 0; tk < 4; ++tk)
+                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        a, *reinterpret_cast<const bf16x8_t*>(&xf[tk][0]), acc[tn][tk], 0, 0, 0);
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int tn = 0; tn < 8; ++tn) {
+                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        bsum[tn] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{a[2 * j], a[2 * j + 1]}, ones2, bsum[tn], false);
+                }
+            }
+        }
+    };
+
+    stage_load(s_begin, 0);
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // stage s has landed for every wave; buffer cur^1 is no longer read
+        if (s + 1 < s_end) stage_load(s + 1, cur ^ 1);
+        if (nv > 0 && kv > 0) compute(cur);
+    }
+
+    // ---- write out: D[n][k]; lane: k = lane&15 (col), n = (lane>>4)*4 + r (rows); row splits meet in fp32 atomics
+    float* W = d.dW + z * d.strideW;
+    const bool atomic = d.accumulate || split_m > 1;
+#pragma unroll
+    for (int tn = 0; tn < 8; ++tn)
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 128 + tn * 16 + (lane >> 4) * 4 + r;
+                const int k = k0 + wk * 64 + tk * 16 + (lane & 15);
+                if (n < d.N && k < d.K) {
+                    const float v = acc[tn][tk][r] * d.alpha;
+                    if (atomic) atomicAdd(W + (long)n * d.ldw + k, v);
+                    else W[(long)n * d.ldw + k] = v;
+                }
+            }
+    if (do_bias) {                            // lane holds column n = tn*16 + (lane&15); the 4 lane groups hold row subsets
+#pragma unroll
+        for (int tn = 0; tn < 8; ++tn) {
+            float v = bsum[tn];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int n = n0 + wn * 128 + tn * 16 + lane;
+            if (lane < 16 && n < d.N) atomicAdd(d.dbias + z * d.strideDbias + n, v * d.alpha);
+        }
+    }
+}
+
+// the wide form needs whole 64-row stages, plain bf16 operands, and an output that is accumulated into (so that it
+// may choose its own row split); it pays once the reduction is long enough to amortise the 256 x 256 tile
+bool tn2_eligible(const ga_wgrad_desc* d) {
+    static const int force = [] {
+        const char* e = getenv("GAEXT_TN2");      // 0 disables, for experiments
+        return e ? atoi(e) : 1;
+    }();
+    return force && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 64 == 0 &&
+           d->M >= 8192 && (d->accumulate || d->split_m > 1) && d->ldw % 1 == 0;
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
@@ -890,8 +1078,19 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
     } else {
         GA_REQUIRE(false, "ga_wgrad: bad x_kind %d", d->x_kind);
     }
-    dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128) * d->split_m, 1, d->batch), block(kThreads);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tn2_eligible(d)) {
+        static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, kTn2Smem) == hipSuccess;
+        GA_REQUIRE(attr_ok, "ga_wgrad: cannot reserve %d bytes of LDS", kTn2Smem);
+        const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
+        const int stages = d->M / 64;
+        const int split = std::max(1, std::min(stages / 4, num_cus() / tiles));   // one workgroup per CU
+        dim3 grid2(cdiv(d->N, 256) * cdiv(d->K, 256) * split, 1, d->batch), block2(kTn2Threads);
+        hipLaunchKernelGGL(gemm_tn2_kernel, grid2, block2, kTn2Smem, s, *d, split);
+        return ga_check_launch("ga_wgrad");
+    }
+    dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128) * d->split_m, 1, d->batch), block(kThreads);
     if (d->dtype == GA_BF16)
         hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, block, 65536, s, *d);
     else

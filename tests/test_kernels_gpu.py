@@ -220,6 +220,29 @@ def test_wgrad_plain(dt, shape):
     assert_close(dW, y.t() @ xg, tol(dt, 2), 'wgrad overwrite + gelu(X)')
 
 
+@pytest.mark.parametrize('shape', [(8192, 384, 1536), (8192, 96, 384), (16384, 384, 96), (8256, 200, 328), (12800, 768, 192)])
+def test_wgrad_wide_tile_bf16(shape):
+    """the 256x256-tile LDS-DMA form (bf16, M % 64 == 0, M >= 8192, accumulating output): ragged N / K, padded
+    leading dimensions, bias column sums, its own choice of row splits"""
+    ops = _imp()
+    dt = torch.bfloat16
+    M, N, K = shape
+    g = gen(11)
+    ldy, ldx = N + 8, K + 16
+    y, _ = rnd((M, ldy), dt, g)
+    x, _ = rnd((M, ldx), dt, g)
+    Y, X = y.to(dt).cuda(), x.to(dt).cuda()
+    y, x = y[:, :N], x[:, :K]
+    ref = y.t() @ x
+    for split, acc in ((2, False), (1, True)):
+        dW = torch.full((N, K), 1.0, device='cuda')
+        db = torch.zeros(N, device='cuda')
+        ops.Plan(eager=True).wgrad(Y, X, dW, M, N, K, ops.ga_dtype(dt), ldy=ldy, ldx=ldx, dbias=db, split_m=split,
+                                   accumulate=acc, alpha=0.25)
+        assert_close(dW, 1.0 + 0.25 * ref, 2e-4, f'wide wgrad split {split}')
+        assert_close(db, 0.25 * y.sum(0), 2e-4, 'wide dbias')
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_wgrad_gather_kinds(dt):
     ops = _imp()

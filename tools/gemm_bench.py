@@ -76,8 +76,8 @@ for stage, (C, res) in enumerate([(96, 56), (192, 28), (384, 14), (768, 7)]):
     report(f's{stage} dgrad1', timeit(p), fl, e * M * 5 * C)
     p = ops.Plan(); p.wgrad(h, x, G, M, 4 * C, C, dt)
     report(f's{stage} wgrad1', timeit(p), fl, e * M * 5 * C)
-    p = ops.Plan(); p.wgrad(y, h, G2, M, C, 4 * C, dt, x_act=ops.ACT_GELU, dbias=b2)
-    report(f's{stage} wgrad2(gelu)', timeit(p), fl, e * M * 5 * C)
+    p = ops.Plan(); p.wgrad(y, h, G2, M, C, 4 * C, dt, dbias=b2)
+    report(f's{stage} wgrad2(+dbias)', timeit(p), fl, e * M * 5 * C)
     del x, h, y
 # big square-ish reference
 M = N = K = 4096
