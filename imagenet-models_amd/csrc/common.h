@@ -67,7 +67,11 @@ __device__ __forceinline__ void unpack8(const uint4& a, float v[8]) {   // 8 bf1
     v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
 }
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    // ONE v_cvt_pk_bf16_f32 for the pair (two scalar converts + shift/or otherwise)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    const bf16x2_t b = __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t);
+    return *reinterpret_cast<const unsigned*>(&b);
 }
 __device__ __forceinline__ void store8(float* p, const float v[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -105,7 +109,7 @@ __device__ __forceinline__ void store4(bf16_t* p, const float v[4]) {
 // GEMM operand loader and epilogue instead of being stored.  E = exp(-x^2/2) is shared by GELU'.
 __device__ __forceinline__ float gelu_cdf_f(float x, float* e_out) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn is a full IEEE divide
     float p = fmaf(t, 1.061405429f, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
