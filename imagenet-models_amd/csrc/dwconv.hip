@@ -161,8 +161,7 @@ __global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, co
 // persistent: blockIdx.x walks tiles with stride gridDim.x, blockIdx.y = channel slice.
 template <typename T, int TH, int TW, int NT>
 __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           float* __restrict__ dw49, float* __restrict__ dbias, int B,
-                                                           int H, int W, int C) {
+                                                           float* __restrict__ part, int B, int H, int W, int C) {
     constexpr int PW = TW + 6, PH = TH + 6;
     constexpr int RS = TH / 7;  // row groups of 7 output rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -188,27 +187,87 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
 #pragma unroll
     for (int c = 0; c < 4; ++c) bsum[c] = 0.f;
 
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // bf16 slices made of whole 16-byte pieces: the next tile's pieces are fetched into registers while this tile is
+    // multiplied (a load -> LDS-store loop exposes the memory latency once per iteration, 12x per tile)
+    constexpr int EPC = 16 / (int)sizeof(T);
+    constexpr int PPP = kCSW / EPC;
+    constexpr int NX = (PH * PW * PPP + NT - 1) / NT, ND = (TH * TW * PPP + NT - 1) / NT;
+    constexpr bool kPrefetch = sizeof(T) == 2;
+    const bool fast = kPrefetch && cs % EPC == 0;
+    uint4 rx[kPrefetch ? NX : 1], rd[kPrefetch ? ND : 1];
+    auto fetch = [&](long t) {
         long tt = t;
         const int tx = (int)(tt % tiles_x); tt /= tiles_x;
         const int ty = (int)(tt % tiles_y);
-        const long b = tt / tiles_y;
+        const long img = (tt / tiles_y) * H * W;
         const int y0 = ty * TH, x0 = tx * TW;
-        const long img = b * H * W;
-        __syncthreads();  // previous tile fully consumed
-        stage_halo<T, TH, TW, kCSW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
-        for (int i = tid; i < TH * TW * cgs; i += NT) {
-            const int g = i % cgs, p = i / cgs;
-            const int py = p / TW, px = p - py * TW;
-            const int yy = y0 + py, xx = x0 + px;
-            typename vec4<T>::type v;
-            if (yy < H && xx < W)
-                v = *reinterpret_cast<const typename vec4<T>::type*>(dy + (img + (long)yy * W + xx) * C + c0 + g * kCG);
-            else
-                memset(&v, 0, sizeof(v));
-            *reinterpret_cast<typename vec4<T>::type*>(ds + p * kCSW + g * kCG) = v;
+        const int npp = cs / EPC;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + j * NT;
+            const int pc = i % PPP, p = i / PPP;
+            const int py = p / PW, px = p - py * PW;
+            const int y = y0 + py - 3, xx = x0 + px - 3;
+            rx[j] = make_uint4(0, 0, 0, 0);
+            if (p < PH * PW && pc < npp && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+                rx[j] = *reinterpret_cast<const uint4*>(x + (img + (long)y * W + xx) * C + c0 + pc * EPC);
         }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + j * NT;
+            const int pc = i % PPP, p = i / PPP;
+            const int py = p / TW, px = p - py * TW;
+            const int y = y0 + py, xx = x0 + px;
+            rd[j] = make_uint4(0, 0, 0, 0);
+            if (p < TH * TW && pc < npp && y < H && xx < W)
+                rd[j] = *reinterpret_cast<const uint4*>(dy + (img + (long)y * W + xx) * C + c0 + pc * EPC);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = tid + j * NT;
+            if (i < PH * PW * PPP) *reinterpret_cast<uint4*>(xs + (i / PPP) * kCSW + (i % PPP) * EPC) = rx[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            const int i = tid + j * NT;
+            if (i < TH * TW * PPP) *reinterpret_cast<uint4*>(ds + (i / PPP) * kCSW + (i % PPP) * EPC) = rd[j];
+        }
+    };
+    if constexpr (kPrefetch) {
+        if (fast && (long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    }
+
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();  // previous tile fully consumed
+        if (fast) {
+            if constexpr (kPrefetch) {
+                commit();
+                __syncthreads();
+                if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+            }
+        } else {
+            long tt = t;
+            const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+            const int ty = (int)(tt % tiles_y);
+            const long b = tt / tiles_y;
+            const int y0 = ty * TH, x0 = tx * TW;
+            const long img = b * H * W;
+            stage_halo<T, TH, TW, kCSW>(x, xs, img, H, W, C, y0, x0, c0, cs, tid, NT);
+            for (int i = tid; i < TH * TW * cgs; i += NT) {
+                const int g = i % cgs, p = i / cgs;
+                const int py = p / TW, px = p - py * TW;
+                const int yy = y0 + py, xx = x0 + px;
+                typename vec4<T>::type v;
+                if (yy < H && xx < W)
+                    v = *reinterpret_cast<const typename vec4<T>::type*>(dy + (img + (long)yy * W + xx) * C + c0 + g * kCG);
+                else
+                    memset(&v, 0, sizeof(v));
+                *reinterpret_cast<typename vec4<T>::type*>(ds + p * kCSW + g * kCG) = v;
+            }
+            __syncthreads();
+        }
         if (active) {
 #pragma unroll 1
             for (int r = 0; r < 7; ++r) {
@@ -239,16 +298,63 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
             }
         }
     }
+    // partial sums of this workgroup: part[blockIdx.x * RS + rg][50][C] (rows 0..48 taps, row 49 the bias sums), plain stores.
+    // (Hundreds of workgroups adding into the same 49 x C floats with atomics serialise in L2: that was 10x the
+    // time of the arithmetic.)  dwconv7_wgrad_reduce sums the partials.
     if (active) {
+        float* pp = part + ((long)blockIdx.x * RS + rg) * 50 * C + c0 + cg * kCG;
 #pragma unroll
-        for (int kx = 0; kx < 7; ++kx)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(dw49 + (long)(ky * 7 + kx) * C + c0 + cg * kCG + c, acc[kx][c]);
-        if (ky == 0 && dbias) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(dbias + c0 + cg * kCG + c, bsum[c]);
-        }
+        for (int kx = 0; kx < 7; ++kx) store4(pp + (long)(ky * 7 + kx) * C, acc[kx]);
+        if (ky == 0) store4(pp + 49L * C, bsum);
     }
+}
+
+// dw49[tap][c] += sum_g part[g][tap][c]; dbias[c] += sum_g part[g][49][c].   block = 64 columns x 4 partial ranges
+__global__ __launch_bounds__(256) void dwconv7_wgrad_reduce(const float* __restrict__ part, int nparts, int C,
+                                                            float* __restrict__ dw49, float* __restrict__ dbias) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;           // over 50 * C
+    const int total = 50 * C;
+    float s = 0.f;
+    if (idx < total) {
+        const int per = (nparts + 3) / 4;
+        const int g0 = grp * per, g1 = min(nparts, g0 + per);
+#pragma unroll 4
+        for (int g = g0; g < g1; ++g) s += part[(long)g * total + idx];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && idx < total) {
+        s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+        if (idx < 49 * C) dw49[idx] += s;
+        else if (dbias) dbias[idx - 49 * C] += s;
+    }
+}
+
+// per-stream scratch for the partial sums (grown on demand, never shrunk); launches on one stream are ordered, so one
+// buffer per stream is enough
+float* wgrad_scratch(hipStream_t s, size_t bytes) {
+    struct Slot { hipStream_t s; float* p; size_t bytes; };
+    static Slot slots[16];
+    static int nslots = 0;
+    Slot* sl = nullptr;
+    for (int i = 0; i < nslots; ++i)
+        if (slots[i].s == s) sl = &slots[i];
+    if (!sl) {
+        if (nslots == 16) return nullptr;
+        sl = &slots[nslots++];
+        *sl = Slot{s, nullptr, 0};
+    }
+    if (sl->bytes < bytes) {
+        if (sl->p) (void)hipFree(sl->p);        // synchronises with the work still using it
+        sl->p = nullptr;
+        sl->bytes = 0;
+        const size_t want = std::max(bytes, (size_t)8 << 20);
+        if (hipMalloc(&sl->p, want) != hipSuccess) return nullptr;
+        sl->bytes = want;
+    }
+    return sl->p;
 }
 
 template <typename T>
@@ -285,7 +391,16 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
                         hipStream_t s) {
     const int slices = cdiv(C, kCSW);
     const int num_cu = num_cus();
-    if (H % 14 == 0 && W % 14 == 0) {
+    const bool big = H % 14 == 0 && W % 14 == 0;
+    const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
+    const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? 2 : 4) * num_cu / slices));
+    const int nparts = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
+    float* part = wgrad_scratch(s, (size_t)nparts * 50 * C * sizeof(float));
+    if (!part) {
+        ga_set_error("dwconv7_wgrad: cannot allocate %zu B of scratch", (size_t)nparts * 50 * C * sizeof(float));
+        return GA_ERR_HIP;
+    }
+    if (big) {
         constexpr int TH = 14, TW = 14, NT = 256;
         const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCSW * sizeof(T);
         auto k = dwconv7_wgrad_kernel<T, TH, TW, NT>;
@@ -298,17 +413,14 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
             }
             once = true;
         }
-        const long ntiles = (long)B * (H / TH) * (W / TW);
-        const int gx = (int)std::min<long>(ntiles, std::max(1, 2 * num_cu / slices));
-        hipLaunchKernelGGL(k, dim3(gx, slices), dim3(NT), lds, s, (const T*)dy, (const T*)x, dw49, dbias, B, H, W, C);
+        hipLaunchKernelGGL(k, dim3(gx, slices), dim3(NT), lds, s, (const T*)dy, (const T*)x, part, B, H, W, C);
     } else {
         constexpr int TH = 7, TW = 7, NT = 128;
         const size_t lds = ((TH + 6) * (TW + 6) + TH * TW) * kCSW * sizeof(T);
-        const long ntiles = (long)B * cdiv(H, TH) * cdiv(W, TW);
-        const int gx = (int)std::min<long>(ntiles, std::max(1, 4 * num_cu / slices));
         hipLaunchKernelGGL((dwconv7_wgrad_kernel<T, TH, TW, NT>), dim3(gx, slices), dim3(NT), lds, s, (const T*)dy,
-                           (const T*)x, dw49, dbias, B, H, W, C);
+                           (const T*)x, part, B, H, W, C);
     }
+    hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(256), 0, s, part, nparts, C, dw49, dbias);
     return ga_check_launch("ga_dwconv7_bwd_weight");
 }
 
