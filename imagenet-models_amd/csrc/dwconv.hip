@@ -309,6 +309,175 @@ __global__ __launch_bounds__(NT) void dwconv7_wgrad_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 backward-weight on v_dot2_f32_bf16.  The reduction runs over pixels, so with the tile stored per CHANNEL
+// as rows of consecutive x (two pixels per dword) one dot2 does two multiply-adds straight from the bf16 bits:
+//     acc[kx] += (dy[x], dy[x+1]) . (in[x+kx], in[x+kx+1])
+// -- no bf16 -> fp32 unpacking (it was half of the VALU work of the fp32-FMA form) and fp32 accumulation.  Odd kx
+// need the input pairs shifted by one pixel: one v_alignbit per pair and row.
+//   lane = channel plane (64 planes per workgroup), wave = (ky, group of 7 output rows); acc[7 kx] per thread.
+//   LDS plane strides are odd multiples of 16 B: the 64 lanes' ds_read_b128 fall on distinct 16-B slots, and with
+//   plane(channel c) = (c & 7) * 8 + (c >> 3) the transposing ds_write_b32 of the staging pass are conflict-free
+//   while its global loads stay 128 B contiguous per pixel.
+// ------------------------------------------------------------------------------------------------
+constexpr int odd16(int bytes) { return (((bytes + 15) / 16) | 1) * 16; }
+
+template <int TH, int TW> struct DWD {
+    static constexpr int TWP = (TW + 1) & ~1, NP = TWP / 2;          // dy row: pixels (even), pairs
+    static constexpr int PW = TWP + 6, PH = TH + 6, NPX = PW / 2;    // input tile with halo
+    static constexpr int NPR = NP + 3;                               // input pairs a row item needs
+    static constexpr int ROWX = (PW * 2 + 15) / 16 * 16, ROWD = (TWP * 2 + 15) / 16 * 16;
+    static constexpr int PLX = odd16(PH * ROWX), PLD = odd16(TH * ROWD);
+    static constexpr int RS = TH / 7, NW = 7 * RS, NT = 64 * NW;
+    static constexpr int LDS = 64 * (PLX + PLD);
+    static constexpr int XU = PH * NPX * 8, DU = TH * NP * 8;        // staging units: (row, pixel pair, 8 channels)
+    static constexpr int NXU = (XU + NT - 1) / NT, NDU = (DU + NT - 1) / NT;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 dw_bf16x2;
+__device__ __forceinline__ float dot2bf(unsigned a, unsigned b, float c) {
+    return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const dw_bf16x2*>(&a), *reinterpret_cast<const dw_bf16x2*>(&b),
+                                           c, false);
+}
+
+template <int TH, int TW>
+__global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(const bf16_t* __restrict__ dy,
+                                                                             const bf16_t* __restrict__ x,
+                                                                             float* __restrict__ part, int B, int H,
+                                                                             int W, int C) {
+    using G = DWD<TH, TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                       // [64 planes][PH rows of ROWX bytes]
+    unsigned char* ds = smem + 64 * G::PLX;         // [64 planes][TH rows of ROWD bytes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ky = wave % 7, rg = wave / 7;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long ntiles = (long)B * tiles_x * tiles_y;
+    const int c0 = blockIdx.y * 64;
+    const int cs = min(64, C - c0);
+    const int ncg = cs >> 3;                        // 8-channel groups in this slice (C % 8 == 0)
+    const int ch = (lane & 7) * 8 + (lane >> 3);    // channel held by plane `lane`
+
+    uint4 rxa[G::NXU], rxb[G::NXU], rda[G::NDU], rdb[G::NDU];
+    auto fetch = [&](long t) {
+        long tt = t;
+        const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+        const int ty = (int)(tt % tiles_y);
+        const long img = (tt / tiles_y) * H * W;
+        const int y0 = ty * TH, x0 = tx * TW;
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            const int u = tid + j * G::NT;
+            const int cgi = u & 7, q = u >> 3;
+            const int pr = q % G::NPX, row = q / G::NPX;
+            const int y = y0 + row - 3, xa = x0 - 3 + 2 * pr;
+            rxa[j] = make_uint4(0, 0, 0, 0);
+            rxb[j] = make_uint4(0, 0, 0, 0);
+            if (u < G::XU && cgi < ncg && (unsigned)y < (unsigned)H) {
+                const bf16_t* src = x + (img + (long)y * W + xa) * C + c0 + cgi * 8;
+                if ((unsigned)xa < (unsigned)W) rxa[j] = *reinterpret_cast<const uint4*>(src);
+                if ((unsigned)(xa + 1) < (unsigned)W) rxb[j] = *reinterpret_cast<const uint4*>(src + C);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G::NDU; ++j) {
+            const int u = tid + j * G::NT;
+            const int cgi = u & 7, q = u >> 3;
+            const int pr = q % G::NP, row = q / G::NP;
+            const int y = y0 + row, xa = x0 + 2 * pr;
+            rda[j] = make_uint4(0, 0, 0, 0);
+            rdb[j] = make_uint4(0, 0, 0, 0);
+            if (u < G::DU && cgi < ncg && y < H) {
+                const bf16_t* src = dy + (img + (long)y * W + xa) * C + c0 + cgi * 8;
+                if (xa < W && 2 * pr < TW) rda[j] = *reinterpret_cast<const uint4*>(src);
+                if (xa + 1 < W && 2 * pr + 1 < TW) rdb[j] = *reinterpret_cast<const uint4*>(src + C);
+            }
+        }
+    };
+    // commit: two pixels x 8 channels -> 8 dwords (the pixel pair of one channel), one per channel plane
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            const int u = tid + j * G::NT;
+            if (u < G::XU) {
+                const int cgi = u & 7, q = u >> 3;
+                const int pr = q % G::NPX, row = q / G::NPX;
+                unsigned char* base = xs + cgi * G::PLX + row * G::ROWX + pr * 4;
+                const unsigned wa[4] = {rxa[j].x, rxa[j].y, rxa[j].z, rxa[j].w};
+                const unsigned wb[4] = {rxb[j].x, rxb[j].y, rxb[j].z, rxb[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // channel k = 2i (low halves), 2i+1 (high halves); plane = k*8 + cgi
+                    *reinterpret_cast<unsigned*>(base + (2 * i) * 8 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x05040100u);
+                    *reinterpret_cast<unsigned*>(base + (2 * i + 1) * 8 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x07060302u);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < G::NDU; ++j) {
+            const int u = tid + j * G::NT;
+            if (u < G::DU) {
+                const int cgi = u & 7, q = u >> 3;
+                const int pr = q % G::NP, row = q / G::NP;
+                unsigned char* base = ds + cgi * G::PLD + row * G::ROWD + pr * 4;
+                const unsigned wa[4] = {rda[j].x, rda[j].y, rda[j].z, rda[j].w};
+                const unsigned wb[4] = {rdb[j].x, rdb[j].y, rdb[j].z, rdb[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<unsigned*>(base + (2 * i) * 8 * G::PLD) = __builtin_amdgcn_perm(wb[i], wa[i], 0x05040100u);
+                    *reinterpret_cast<unsigned*>(base + (2 * i + 1) * 8 * G::PLD) = __builtin_amdgcn_perm(wb[i], wa[i], 0x07060302u);
+                }
+            }
+        }
+    };
+
+    float acc[7], bs = 0.f;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) acc[k] = 0.f;
+    const unsigned ones = 0x3f803f80u;              // (1.0bf16, 1.0bf16)
+
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                            // previous tile fully consumed
+        commit();
+        __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+        const unsigned char* xp = xs + lane * G::PLX + (rg * 7 + ky) * G::ROWX;
+        const unsigned char* dp = ds + lane * G::PLD + (rg * 7) * G::ROWD;
+#pragma unroll 1
+        for (int r = 0; r < 7; ++r) {
+            unsigned g2[(G::NP + 3) / 4 * 4], P[(G::NPR + 3) / 4 * 4 + 1], Q[G::NP + 2];
+#pragma unroll
+            for (int i = 0; i < (G::NP + 3) / 4; ++i) {
+                const uint4 v = *reinterpret_cast<const uint4*>(dp + r * G::ROWD + i * 16);
+                g2[4 * i] = v.x; g2[4 * i + 1] = v.y; g2[4 * i + 2] = v.z; g2[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int i = 0; i < (G::NPR + 3) / 4; ++i) {
+                const uint4 v = *reinterpret_cast<const uint4*>(xp + r * G::ROWX + i * 16);
+                P[4 * i] = v.x; P[4 * i + 1] = v.y; P[4 * i + 2] = v.z; P[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < G::NP + 2; ++j) Q[j] = __builtin_amdgcn_alignbit(P[j + 1], P[j], 16);
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                for (int m = 0; m < G::NP; ++m)
+                    acc[kx] = dot2bf(g2[m], (kx & 1) ? Q[m + (kx >> 1)] : P[m + (kx >> 1)], acc[kx]);
+            if (ky == 0) {
+#pragma unroll
+                for (int m = 0; m < G::NP; ++m) bs = dot2bf(g2[m], ones, bs);
+            }
+        }
+    }
+    if (ch < cs) {   // part[blockIdx.x * RS + rg][50][C]
+        float* pp = part + ((long)blockIdx.x * G::RS + rg) * 50 * C + c0 + ch;
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) pp[(long)(ky * 7 + kx) * C] = acc[kx];
+        if (ky == 0) pp[49L * C] = bs;
+    }
+}
+
 // dw49[tap][c] += sum_g part[g][tap][c]; dbias[c] += sum_g part[g][49][c].   block = 64 columns x 4 partial ranges
 __global__ __launch_bounds__(256) void dwconv7_wgrad_reduce(const float* __restrict__ part, int nparts, int C,
                                                             float* __restrict__ dw49, float* __restrict__ dbias) {
@@ -393,12 +562,37 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
     const int num_cu = num_cus();
     const bool big = H % 14 == 0 && W % 14 == 0;
     const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
-    const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? 2 : 4) * num_cu / slices));
+    const bool dot2 = sizeof(T) == 2 && C % 8 == 0;   // dot2 form: 89 KB of LDS at 14x14 -> one workgroup per CU
+    const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? (dot2 ? 1 : 2) : 4) * num_cu / slices));
     const int nparts = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
     float* part = wgrad_scratch(s, (size_t)nparts * 50 * C * sizeof(float));
     if (!part) {
         ga_set_error("dwconv7_wgrad: cannot allocate %zu B of scratch", (size_t)nparts * 50 * C * sizeof(float));
         return GA_ERR_HIP;
+    }
+    if constexpr (sizeof(T) == 2) {
+        if (dot2) {
+            auto k14 = dwconv7_wgrad_dot2_kernel<14, 14>;
+            auto k7 = dwconv7_wgrad_dot2_kernel<7, 7>;
+            constexpr int lds14 = DWD<14, 14>::LDS;
+            static const bool attr_ok =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k14), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds14) == hipSuccess;
+            if (!attr_ok) {
+                ga_set_error("dwconv7_wgrad: cannot reserve %d B of LDS", lds14);
+                return GA_ERR_HIP;
+            }
+            using G14 = DWD<14, 14>;
+            using G7 = DWD<7, 7>;
+            if (big)
+                hipLaunchKernelGGL(k14, dim3(gx, slices), dim3(G14::NT), G14::LDS, s, (const bf16_t*)dy,
+                                   (const bf16_t*)x, part, B, H, W, C);
+            else
+                hipLaunchKernelGGL(k7, dim3(gx, slices), dim3(G7::NT), G7::LDS, s, (const bf16_t*)dy,
+                                   (const bf16_t*)x, part, B, H, W, C);
+            hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(256), 0, s, part, nparts, C, dw49, dbias);
+            return ga_check_launch("ga_dwconv7_bwd_weight");
+        }
     }
     if (big) {
         constexpr int TH = 14, TW = 14, NT = 256;
