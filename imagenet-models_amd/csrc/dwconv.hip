@@ -359,39 +359,58 @@ __global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(c
     const int ncg = cs >> 3;                        // 8-channel groups in this slice (C % 8 == 0)
     const int ch = (lane & 7) * 8 + (lane >> 3);    // channel held by plane `lane`
 
+    // staging units of this thread: (row, pixel pair, 8-channel group) -- the same for every tile, decoded once
     uint4 rxa[G::NXU], rxb[G::NXU], rda[G::NDU], rdb[G::NDU];
+    int xrow[G::NXU], xcol[G::NXU], xsrc[G::NXU], xdst[G::NXU];     // tile-relative y / x of the even pixel, offsets
+    int drow[G::NDU], dcol[G::NDU], dsrc[G::NDU], ddst[G::NDU];
+#pragma unroll
+    for (int j = 0; j < G::NXU; ++j) {
+        const int u = tid + j * G::NT;
+        const int cgi = u & 7, q = u >> 3;
+        const int pr = q % G::NPX, row = q / G::NPX;
+        const bool live = u < G::XU && cgi < ncg;
+        xrow[j] = live ? row - 3 : -(1 << 20);                     // dead units fail the row test of every tile
+        xcol[j] = 2 * pr - 3;
+        xsrc[j] = ((row - 3) * W + 2 * pr - 3) * C + cgi * 8;
+        xdst[j] = cgi * G::PLX + row * G::ROWX + pr * 4;
+    }
+#pragma unroll
+    for (int j = 0; j < G::NDU; ++j) {
+        const int u = tid + j * G::NT;
+        const int cgi = u & 7, q = u >> 3;
+        const int pr = q % G::NP, row = q / G::NP;
+        const bool live = u < G::DU && cgi < ncg;
+        drow[j] = live ? row : (1 << 20);
+        dcol[j] = 2 * pr;
+        dsrc[j] = (row * W + 2 * pr) * C + cgi * 8;
+        ddst[j] = cgi * G::PLD + row * G::ROWD + pr * 4;
+    }
     auto fetch = [&](long t) {
         long tt = t;
         const int tx = (int)(tt % tiles_x); tt /= tiles_x;
         const int ty = (int)(tt % tiles_y);
-        const long img = (tt / tiles_y) * H * W;
         const int y0 = ty * TH, x0 = tx * TW;
+        const long base = ((tt / tiles_y) * H * W + (long)y0 * W + x0) * C + c0;   // tile origin pixel, slice channel 0
 #pragma unroll
         for (int j = 0; j < G::NXU; ++j) {
-            const int u = tid + j * G::NT;
-            const int cgi = u & 7, q = u >> 3;
-            const int pr = q % G::NPX, row = q / G::NPX;
-            const int y = y0 + row - 3, xa = x0 - 3 + 2 * pr;
+            const int y = y0 + xrow[j], xa = x0 + xcol[j];
             rxa[j] = make_uint4(0, 0, 0, 0);
             rxb[j] = make_uint4(0, 0, 0, 0);
-            if (u < G::XU && cgi < ncg && (unsigned)y < (unsigned)H) {
-                const bf16_t* src = x + (img + (long)y * W + xa) * C + c0 + cgi * 8;
+            if ((unsigned)y < (unsigned)H) {
+                const bf16_t* src = x + base + xsrc[j];
                 if ((unsigned)xa < (unsigned)W) rxa[j] = *reinterpret_cast<const uint4*>(src);
                 if ((unsigned)(xa + 1) < (unsigned)W) rxb[j] = *reinterpret_cast<const uint4*>(src + C);
             }
         }
 #pragma unroll
         for (int j = 0; j < G::NDU; ++j) {
-            const int u = tid + j * G::NT;
-            const int cgi = u & 7, q = u >> 3;
-            const int pr = q % G::NP, row = q / G::NP;
-            const int y = y0 + row, xa = x0 + 2 * pr;
+            const int y = y0 + drow[j], xa = x0 + dcol[j];
             rda[j] = make_uint4(0, 0, 0, 0);
             rdb[j] = make_uint4(0, 0, 0, 0);
-            if (u < G::DU && cgi < ncg && y < H) {
-                const bf16_t* src = dy + (img + (long)y * W + xa) * C + c0 + cgi * 8;
-                if (xa < W && 2 * pr < TW) rda[j] = *reinterpret_cast<const uint4*>(src);
-                if (xa + 1 < W && 2 * pr + 1 < TW) rdb[j] = *reinterpret_cast<const uint4*>(src + C);
+            if (y < H) {
+                const bf16_t* src = dy + base + dsrc[j];
+                if (xa < W && dcol[j] < TW) rda[j] = *reinterpret_cast<const uint4*>(src);
+                if (xa + 1 < W && dcol[j] + 1 < TW) rdb[j] = *reinterpret_cast<const uint4*>(src + C);
             }
         }
     };
@@ -399,11 +418,8 @@ __global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(c
     auto commit = [&]() {
 #pragma unroll
         for (int j = 0; j < G::NXU; ++j) {
-            const int u = tid + j * G::NT;
-            if (u < G::XU) {
-                const int cgi = u & 7, q = u >> 3;
-                const int pr = q % G::NPX, row = q / G::NPX;
-                unsigned char* base = xs + cgi * G::PLX + row * G::ROWX + pr * 4;
+            if (xrow[j] > -(1 << 19)) {
+                unsigned char* base = xs + xdst[j];
                 const unsigned wa[4] = {rxa[j].x, rxa[j].y, rxa[j].z, rxa[j].w};
                 const unsigned wb[4] = {rxb[j].x, rxb[j].y, rxb[j].z, rxb[j].w};
 #pragma unroll
@@ -415,11 +431,8 @@ __global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(c
         }
 #pragma unroll
         for (int j = 0; j < G::NDU; ++j) {
-            const int u = tid + j * G::NT;
-            if (u < G::DU) {
-                const int cgi = u & 7, q = u >> 3;
-                const int pr = q % G::NP, row = q / G::NP;
-                unsigned char* base = ds + cgi * G::PLD + row * G::ROWD + pr * 4;
+            if (drow[j] < (1 << 19)) {
+                unsigned char* base = ds + ddst[j];
                 const unsigned wa[4] = {rda[j].x, rda[j].y, rda[j].z, rda[j].w};
                 const unsigned wb[4] = {rdb[j].x, rdb[j].y, rdb[j].z, rdb[j].w};
 #pragma unroll
@@ -470,32 +483,51 @@ __global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(c
             }
         }
     }
-    if (ch < cs) {   // part[blockIdx.x * RS + rg][50][C]
-        float* pp = part + ((long)blockIdx.x * G::RS + rg) * 50 * C + c0 + ch;
+    // the row groups of one workgroup meet in LDS, then ONE partial per workgroup: part[blockIdx.x][50][C]
+    if constexpr (G::RS > 1) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [7 ky][8][64 lanes]
+        if (rg > 0) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) red[(ky * 8 + kx) * 64 + lane] = acc[kx];
+            red[(ky * 8 + 7) * 64 + lane] = bs;
+        }
+        __syncthreads();
+        if (rg == 0) {
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) acc[kx] += red[(ky * 8 + kx) * 64 + lane];
+            bs += red[(ky * 8 + 7) * 64 + lane];
+        }
+    }
+    if (rg == 0 && ch < cs) {
+        float* pp = part + (long)blockIdx.x * 50 * C + c0 + ch;
 #pragma unroll
         for (int kx = 0; kx < 7; ++kx) pp[(long)(ky * 7 + kx) * C] = acc[kx];
         if (ky == 0) pp[49L * C] = bs;
     }
 }
 
-// dw49[tap][c] += sum_g part[g][tap][c]; dbias[c] += sum_g part[g][49][c].   block = 64 columns x 4 partial ranges
-__global__ __launch_bounds__(256) void dwconv7_wgrad_reduce(const float* __restrict__ part, int nparts, int C,
-                                                            float* __restrict__ dw49, float* __restrict__ dbias) {
-    __shared__ float red[4][64];
+// dw49[tap][c] += sum_g part[g][tap][c]; dbias[c] += sum_g part[g][49][c].   block = 64 columns x 16 partial ranges
+__global__ __launch_bounds__(1024) void dwconv7_wgrad_reduce(const float* __restrict__ part, int nparts, int C,
+                                                             float* __restrict__ dw49, float* __restrict__ dbias) {
+    constexpr int NG = 16;
+    __shared__ float red[NG][64];
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + col;           // over 50 * C
     const int total = 50 * C;
     float s = 0.f;
     if (idx < total) {
-        const int per = (nparts + 3) / 4;
+        const int per = (nparts + NG - 1) / NG;
         const int g0 = grp * per, g1 = min(nparts, g0 + per);
-#pragma unroll 4
+#pragma unroll 8
         for (int g = g0; g < g1; ++g) s += part[(long)g * total + idx];
     }
     red[grp][col] = s;
     __syncthreads();
     if (grp == 0 && idx < total) {
-        s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+        s = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) s += red[g][col];
         if (idx < 49 * C) dw49[idx] += s;
         else if (dbias) dbias[idx - 49 * C] += s;
     }
@@ -590,7 +622,7 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
             else
                 hipLaunchKernelGGL(k7, dim3(gx, slices), dim3(G7::NT), G7::LDS, s, (const bf16_t*)dy,
                                    (const bf16_t*)x, part, B, H, W, C);
-            hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(256), 0, s, part, nparts, C, dw49, dbias);
+            hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(1024), 0, s, part, gx, C, dw49, dbias);
             return ga_check_launch("ga_dwconv7_bwd_weight");
         }
     }
@@ -614,7 +646,7 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
         hipLaunchKernelGGL((dwconv7_wgrad_kernel<T, TH, TW, NT>), dim3(gx, slices), dim3(NT), lds, s, (const T*)dy,
                            (const T*)x, part, B, H, W, C);
     }
-    hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(256), 0, s, part, nparts, C, dw49, dbias);
+    hipLaunchKernelGGL(dwconv7_wgrad_reduce, dim3(cdiv(50 * C, 64)), dim3(1024), 0, s, part, nparts, C, dw49, dbias);
     return ga_check_launch("ga_dwconv7_bwd_weight");
 }
 

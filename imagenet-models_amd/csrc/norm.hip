@@ -195,26 +195,63 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float n
     shift[c] = (b ? b[c] : 0.f) - mu * a;
 }
 
-// y = x * scale[c] + shift[c] (+ res) (relu); 8 channels per thread
+// walk over the 8-element chunks i = i0, i0 + S, ... of a [rows][C] tensor keeping (row, chunk column) without a
+// division per chunk (one at the start; 32-bit integer division costs ~20 VALU instructions)
+struct ChunkWalk {
+    unsigned i, row, col, P, drow, dcol, step;
+    __device__ ChunkWalk(unsigned i0, unsigned stride, unsigned P_) : i(i0), P(P_), step(stride) {
+        row = i0 / P_;
+        col = i0 - row * P_;
+        drow = stride / P_;
+        dcol = stride - drow * P_;
+    }
+    __device__ void next() {
+        i += step;
+        row += drow;
+        col += dcol;
+        if (col >= P) { col -= P; ++row; }
+    }
+};
+// row / rps for row < 2^24 (per-sample DropPath scale lookup)
+__device__ __forceinline__ unsigned div_small(unsigned row, unsigned rps, float inv_rps) {
+    unsigned q = (unsigned)((float)row * inv_rps);
+    const int r = (int)(row - q * rps);
+    if (r < 0) --q;
+    else if (r >= (int)rps) ++q;
+    return q;
+}
+
+// y = x * scale[c] + shift[c] (+ res) (relu); 8 channels per thread; per-channel coefficients staged in LDS once
 template <typename T>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res,
                                                          const float* __restrict__ rowscale, long elems_per_scale,
                                                          T* __restrict__ y, long n8, int C, int relu) {
-    // 32-bit index math (n8 < 2^31 for every tensor of this model): 64-bit div/mod costs more than the 16 B it moves
-    const unsigned P = (unsigned)C >> 3, rps = (unsigned)(elems_per_scale / C);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
-        const long e = (long)i * 8;
-        const unsigned row = i / P;
-        const int c = (int)(i - row * P) << 3;
-        const float rsc = rowscale ? rowscale[row / rps] : 1.f;
-        float v[8], r[8];
+    extern __shared__ __attribute__((aligned(16))) float coef[];      // [2][C]: scale, shift
+    if (scale) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            coef[c] = scale[c];
+            coef[C + c] = shift[c];
+        }
+        __syncthreads();
+    }
+    const unsigned rps = (unsigned)(elems_per_scale / C);
+    const float inv_rps = 1.0f / (float)rps;
+    for (ChunkWalk w(blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u, (unsigned)C >> 3); w.i < (unsigned)n8; w.next()) {
+        const long e = (long)w.i * 8;
+        const int c = (int)w.col << 3;
+        const float rsc = rowscale ? rowscale[div_small(w.row, rps, inv_rps)] : 1.f;
+        float v[8], r[8], sc[8], sh[8];
         load8(x + e, v);
         if (res) load8(res + e, r);
+        if (scale) {
+            load8(coef + c, sc);
+            load8(coef + C + c, sh);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float t = v[j];
-            if (scale) t = t * scale[c + j] + shift[c + j];
+            if (scale) t = fmaf(t, sc[j], sh[j]);
             t *= rsc;
             if (res) t += r[j];
             if (relu) t = fmaxf(t, 0.f);
@@ -284,7 +321,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// dx = w*rstd * (g - s1/n - xhat * s2/n), g = dy * (yrelu > 0)
+// dx = w*rstd * (g - s1/n - xhat * s2/n), g = dy * (yrelu > 0)  ==  A[c]*g + B[c]*x + D[c] with the per-channel
+// A = w*rstd, B = -A*rstd*s2/n, D = -A*s1/n (and the mean: x - mean is formed first, no cancellation against D)
+// staged in LDS once per workgroup:  dx = A*g + B*(x - mean) + D
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ yrelu,
                                                            const T* __restrict__ x, const float* __restrict__ mean,
@@ -292,23 +331,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
                                                            const float* __restrict__ rowscale, long elems_per_scale,
                                                            float inv_n, T* __restrict__ dx, long n8, int C) {
-    const unsigned P = (unsigned)C >> 3, rps = (unsigned)(elems_per_scale / C);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
-        const long e = (long)i * 8;
-        const unsigned row = i / P;
-        const int c = (int)(i - row * P) << 3;
-        const float rsc = rowscale ? rowscale[row / rps] : 1.f;
-        float g[8], xv[8], yv[8];
+    extern __shared__ __attribute__((aligned(16))) float coef[];      // [4][C]
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float rs = rstd[c];
+        const float A = (w ? w[c] : 1.f) * rs;
+        const float Bc = -A * rs * s2[c] * inv_n;
+        coef[c] = A;
+        coef[C + c] = Bc;
+        coef[2 * C + c] = -A * s1[c] * inv_n;
+        coef[3 * C + c] = mean[c];
+    }
+    __syncthreads();
+    const unsigned rps = (unsigned)(elems_per_scale / C);
+    const float inv_rps = 1.0f / (float)rps;
+    for (ChunkWalk wk(blockIdx.x * 256u + threadIdx.x, gridDim.x * 256u, (unsigned)C >> 3); wk.i < (unsigned)n8; wk.next()) {
+        const long e = (long)wk.i * 8;
+        const int c = (int)wk.col << 3;
+        const float rsc = rowscale ? rowscale[div_small(wk.row, rps, inv_rps)] : 1.f;
+        float g[8], xv[8], yv[8], A[8], Bc[8], D[8], mu[8];
         load8(dy + e, g);
         load8(x + e, xv);
         if (yrelu) load8(yrelu + e, yv);
+        load8(coef + c, A);
+        load8(coef + C + c, Bc);
+        load8(coef + 2 * C + c, D);
+        load8(coef + 3 * C + c, mu);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float gg = g[j] * rsc;
             if (yrelu && !(yv[j] > 0.f)) gg = 0.f;
-            const float rs = rstd[c + j];
-            const float xh = (xv[j] - mean[c + j]) * rs;
-            g[j] = (w ? w[c + j] : 1.f) * rs * (gg - s1[c + j] * inv_n - xh * s2[c + j] * inv_n);
+            g[j] = fmaf(A[j], gg, fmaf(Bc[j], xv[j] - mu[j], D[j]));
         }
         store8(dx + e, g);
     }
@@ -383,14 +435,16 @@ extern "C" int ga_affine_act(const void* x, const float* scale, const float* shi
                              int dtype, ga_stream_t stream) {
     GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)) &&
                    rows * C / 8 < (1L << 31), "ga_affine_act: bad args");
+    GA_REQUIRE(C <= 8192, "ga_affine_act: C=%d too large for the LDS coefficient table", C);
     const long n8 = rows * C / 8;
-    dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
+    dim3 grid(grid_blocks(n8, 256, 2048)), block(256);
+    const size_t lds = (size_t)2 * C * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
-        hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, scale, shift,
+        hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)x, scale, shift,
                            (const bf16_t*)res, rowscale, (long)rows_per_scale * C, (bf16_t*)y, n8, C, relu);
     else
-        hipLaunchKernelGGL(affine_act_kernel<float>, grid, block, 0, s, (const float*)x, scale, shift, (const float*)res,
+        hipLaunchKernelGGL(affine_act_kernel<float>, grid, block, lds, s, (const float*)x, scale, shift, (const float*)res,
                            rowscale, (long)rows_per_scale * C, (float*)y, n8, C, relu);
     return ga_check_launch("ga_affine_act");
 }
@@ -417,15 +471,17 @@ extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x
                                ga_stream_t stream) {
     GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0 && rows * C / 8 < (1L << 31),
                "ga_bn_bwd_apply: bad args");
+    GA_REQUIRE(C <= 4096, "ga_bn_bwd_apply: C=%d too large for the LDS coefficient table", C);
     const long n8 = rows * C / 8;
-    dim3 grid(grid_blocks(n8, 256, 8192)), block(256);
+    dim3 grid(grid_blocks(n8, 256, 2048)), block(256);
+    const size_t lds = (size_t)4 * C * sizeof(float);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
                            (const bf16_t*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
                            (bf16_t*)dx, n8, C);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, lds, s, (const float*)dy, (const float*)y_relu,
                            (const float*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
                            (float*)dx, n8, C);
     return ga_check_launch("ga_bn_bwd_apply");
