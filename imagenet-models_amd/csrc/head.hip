@@ -476,6 +476,182 @@ __global__ __launch_bounds__(256) void class_attn_bwd_kernel(const T* __restrict
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// class attention, coalesced form (hd % 8 == 0, E <= 512): one workgroup of 16 waves per sample, a WAVE per token
+// row -- lane c holds the 8-channel chunk c of the row, so the k | v rows are read and the dk | dv rows written as
+// whole 16-byte-per-lane lines (the per-head form above walks tokens across lanes: 2-byte accesses 2E apart).
+//   A: per token, per chunk partial dot products -> LDS part[n][chunk]
+//   B: a wave per head finishes the dot products over the head's chunks and does the softmax (fwd) / its gradient (bwd)
+//   C: per token, p-weighted sum of v (fwd); dk, dv rows and the ds-weighted sum of k for dq (bwd); the 16 waves' partial
+//      sums meet in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int kCaWaves = 16, kCaThreads = 64 * kCaWaves;
+
+template <typename T>
+__global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T* __restrict__ q, const T* __restrict__ kv,
+                                                                         T* __restrict__ out, float* __restrict__ P, int N,
+                                                                         int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, NCH = E >> 3, cph = hd >> 3;   // chunks per row, per head
+    float* part = sm;                  // [N][NCH]
+    float* pl = part + N * NCH;        // [heads][N]
+    float* red = pl + heads * N;       // [16][E]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live = lane < NCH;
+    const T* kvb = kv + b * N * (long)(2 * E);
+    float qv[8];
+    if (live) {
+        load8(q + b * E + lane * 8, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= scale;
+    }
+    for (int n = wave; n < N; n += kCaWaves) {
+        if (live) {
+            float k[8];
+            load8(kvb + (long)n * 2 * E + lane * 8, k);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[e], k[e], s);
+            part[n * NCH + lane] = s;
+        }
+    }
+    __syncthreads();
+    for (int h = wave; h < heads; h += kCaWaves) {
+        float mx = -3.0e38f;
+        for (int n = lane; n < N; n += 64) {
+            float s = 0.f;
+            for (int i = 0; i < cph; ++i) s += part[n * NCH + h * cph + i];
+            pl[h * N + n] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            const float e = __expf(pl[h * N + n] - mx);
+            pl[h * N + n] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+        for (int n = lane; n < N; n += 64) {
+            const float p = pl[h * N + n] * inv;
+            pl[h * N + n] = p;
+            P[(b * heads + h) * N + n] = p;
+        }
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int hl = live ? lane / cph : 0;
+    for (int n = wave; n < N; n += kCaWaves) {
+        if (live) {
+            float v[8];
+            load8(kvb + (long)n * 2 * E + E + lane * 8, v);
+            const float p = pl[hl * N + n];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[e], acc[e]);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * E + lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += kCaThreads) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < kCaWaves; ++w) a += red[w * E + c];
+        elt<T>::st(out + b * E + c, a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                                         const T* __restrict__ kv, const float* __restrict__ P,
+                                                                         T* __restrict__ dq, T* __restrict__ dkv, int N,
+                                                                         int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, NCH = E >> 3, cph = hd >> 3;
+    float* part = sm;                  // [N][NCH]
+    float* pl = part + N * NCH;        // [heads][N]  softmax probabilities
+    float* dsl = pl + heads * N;       // [heads][N]  gradient wrt the scaled scores
+    float* red = dsl + heads * N;      // [16][E]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live = lane < NCH;
+    const T* kvb = kv + b * N * (long)(2 * E);
+    T* dkvb = dkv + b * N * (long)(2 * E);
+    float dov[8], qv[8];
+    if (live) {
+        load8(dout + b * E + lane * 8, dov);
+        load8(q + b * E + lane * 8, qv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] *= scale;
+    }
+    for (int n = wave; n < N; n += kCaWaves) {
+        if (live) {
+            float v[8];
+            load8(kvb + (long)n * 2 * E + E + lane * 8, v);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(dov[e], v[e], s);
+            part[n * NCH + lane] = s;
+        }
+    }
+    __syncthreads();
+    for (int h = wave; h < heads; h += kCaWaves) {
+        const float* pp = P + (b * heads + h) * N;
+        float dot = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            float dp = 0.f;
+            for (int i = 0; i < cph; ++i) dp += part[n * NCH + h * cph + i];
+            const float p = pp[n];
+            pl[h * N + n] = p;
+            dsl[h * N + n] = dp;
+            dot = fmaf(dp, p, dot);
+        }
+        dot = wave_sum(dot);
+        for (int n = lane; n < N; n += 64) dsl[h * N + n] = pl[h * N + n] * (dsl[h * N + n] - dot);
+    }
+    __syncthreads();
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int hl = live ? lane / cph : 0;
+    for (int n = wave; n < N; n += kCaWaves) {
+        if (live) {
+            float k[8], dk[8], dv[8];
+            load8(kvb + (long)n * 2 * E + lane * 8, k);
+            const float ds = dsl[hl * N + n], p = pl[hl * N + n];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                acc[e] = fmaf(ds, k[e], acc[e]);
+                dk[e] = ds * qv[e];
+                dv[e] = p * dov[e];
+            }
+            store8(dkvb + (long)n * 2 * E + lane * 8, dk);
+            store8(dkvb + (long)n * 2 * E + E + lane * 8, dv);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[wave * E + lane * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < E; c += kCaThreads) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < kCaWaves; ++w) a += red[w * E + c];
+        elt<T>::st(dq + b * E + c, a * scale);
+    }
+}
+
+// LDS bytes of the row form (0 = not applicable: use the per-head kernels)
+static size_t class_attn_rows_lds(int N, int heads, int hd, bool bwd) {
+    const int E = heads * hd;
+    if (hd % 8 != 0 || E > 512) return 0;
+    const size_t fl = (size_t)N * (E / 8) + (size_t)(bwd ? 2 : 1) * heads * N + (size_t)kCaWaves * E;
+    return fl * sizeof(float) <= 150 * 1024 ? fl * sizeof(float) : 0;
+}
+
 #define DISPATCH_T(dtype, KERNEL, grid, block, lds, s, ...)                                              \
     do {                                                                                                 \
         if ((dtype) == GA_BF16) { using T = bf16_t; hipLaunchKernelGGL(KERNEL<T>, grid, block, lds, s, __VA_ARGS__); } \
@@ -583,6 +759,22 @@ extern "C" int ga_class_attn_fwd(const void* q, const void* kv, void* out, float
                                  float scale, int dtype, ga_stream_t stream) {
     GA_REQUIRE(q && kv && out && P && hd >= 1 && hd <= 64 && N >= 1, "ga_class_attn_fwd: bad args (hd<=64)");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (const size_t lds = class_attn_rows_lds(N, heads, hd, false)) {
+        if (dtype == GA_BF16) {
+            auto k = class_attn_fwd_rows_kernel<bf16_t>;
+            GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds) == hipSuccess, "ga_class_attn_fwd: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, P, N,
+                               heads, hd, scale);
+        } else {
+            auto k = class_attn_fwd_rows_kernel<float>;
+            GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds) == hipSuccess, "ga_class_attn_fwd: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const float*)q, (const float*)kv, (float*)out, P, N,
+                               heads, hd, scale);
+        }
+        return ga_check_launch("ga_class_attn_fwd");
+    }
     DISPATCH_T(dtype, class_attn_fwd_kernel, dim3(B), dim3(256), 4 * (N + 64) * sizeof(float), s, (const T*)q,
                (const T*)kv, (T*)out, P, N, heads, hd, scale);
     return ga_check_launch("ga_class_attn_fwd");
@@ -592,6 +784,22 @@ extern "C" int ga_class_attn_bwd(const void* dout, const void* q, const void* kv
                                  int B, int N, int heads, int hd, float scale, int dtype, ga_stream_t stream) {
     GA_REQUIRE(dout && q && kv && P && dq && dkv && hd >= 1 && hd <= 64, "ga_class_attn_bwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (const size_t lds = class_attn_rows_lds(N, heads, hd, true)) {
+        if (dtype == GA_BF16) {
+            auto k = class_attn_bwd_rows_kernel<bf16_t>;
+            GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds) == hipSuccess, "ga_class_attn_bwd: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const bf16_t*)dout, (const bf16_t*)q,
+                               (const bf16_t*)kv, P, (bf16_t*)dq, (bf16_t*)dkv, N, heads, hd, scale);
+        } else {
+            auto k = class_attn_bwd_rows_kernel<float>;
+            GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds) == hipSuccess, "ga_class_attn_bwd: cannot reserve %zu B of LDS", lds);
+            hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const float*)dout, (const float*)q, (const float*)kv,
+                               P, (float*)dq, (float*)dkv, N, heads, hd, scale);
+        }
+        return ga_check_launch("ga_class_attn_bwd");
+    }
     DISPATCH_T(dtype, class_attn_bwd_kernel, dim3(B), dim3(256), 4 * (N + 128) * sizeof(float), s, (const T*)dout,
                (const T*)q, (const T*)kv, P, (T*)dq, (T*)dkv, N, heads, hd, scale);
     return ga_check_launch("ga_class_attn_bwd");
