@@ -215,6 +215,66 @@ __global__ __launch_bounds__(256) void uncast_kernel(const T* __restrict__ src, 
 // step has ~120 weight-prep, ~90 un-fold and ~60 tiny axpy/transpose jobs of a few KB..MB each; as separate
 // launches they cost ~3 ms of pure launch latency per step.
 // ------------------------------------------------------------------------------------------------
+// 1x1 weights (the bulk of the parameters): 64 x 64 tiles, the master rows are read ONCE with 16-byte loads, the
+// row-major copy is written straight from registers and the transposed copy through a padded LDS tile, both with
+// 4-element stores; padding columns (ldo > K, ldt > Co) are written as zeros.  The scalar path below reads the
+// transposed copy's source with a stride of K floats and pays a 64-bit division per element.
+template <typename T>
+__device__ __forceinline__ void store4z(T* p, const float v[4]) { store4(p, v); }
+
+template <typename T>
+__device__ void wprep_job_1x1(const ga_wprep_desc& d, int nblk, int blk, float (*tile)[65]) {
+    const int KK = d.Ci, Co = d.Co;
+    T* out = reinterpret_cast<T*>(d.out);
+    T* outT = reinterpret_cast<T*>(d.outT);
+    const int n_ext = outT ? max(Co, (int)d.ldt) : Co, k_ext = out ? max(KK, (int)d.ldo) : KK;
+    const int tn = (n_ext + 63) >> 6, tk = (k_ext + 63) >> 6;
+    const int ntiles = d.G * tn * tk;
+    const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
+    for (int t = blk; t < ntiles; t += nblk) {
+        const int g = t / (tn * tk), r = t - g * tn * tk;
+        const int n0 = (r / tk) << 6, k0 = (r % tk) << 6;
+        const int kcol = k0 + tc * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int no = n0 + tr + 16 * i;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (no < Co && kcol < KK) {
+                const int n = d.row_perm ? d.row_perm[g * Co + no] : g * Co + no;
+                load4(d.w + (long)n * KK + kcol, v);
+                const float rs = d.rs ? d.rs[n] : 1.f;
+                float cs[4] = {1.f, 1.f, 1.f, 1.f};
+                if (d.cs) load4(d.cs + kcol, cs);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= rs * cs[j];
+            }
+            if (out && no < Co && kcol < d.ldo) store4(out + ((long)g * Co + no) * d.ldo + kcol, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tile[tc * 4 + j][tr + 16 * i] = v[j];
+        }
+        __syncthreads();
+        if (outT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + tr + 16 * i, nc = n0 + tc * 4;
+                if (k < KK && nc < d.ldt) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = tile[tr + 16 * i][tc * 4 + j];
+                    store4(outT + ((long)g * KK + k) * d.ldt + nc, v);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool wprep_is_1x1(const ga_wprep_desc& d) {
+    return d.KH == 1 && d.KW == 1 && !d.stem && !d.flip && d.Ci % 4 == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 &&
+           (!d.cs || (reinterpret_cast<uintptr_t>(d.cs) & 15) == 0) && (!d.out || d.ldo % 4 == 0) &&
+           (!d.outT || d.ldt % 4 == 0);
+}
+
 template <typename T>
 __device__ void wprep_job(const ga_wprep_desc& d, int nblk, int blk) {
     const int KK = d.Ci * d.KH * d.KW;
@@ -265,7 +325,13 @@ __device__ void wprep_job(const ga_wprep_desc& d, int nblk, int blk) {
 }
 
 __global__ __launch_bounds__(256) void wprep_batch_kernel(const ga_wprep_desc* __restrict__ jobs) {
+    __shared__ float tile[64][65];
     const ga_wprep_desc d = jobs[blockIdx.y];
+    if (wprep_is_1x1(d)) {
+        if (d.dtype == GA_BF16) wprep_job_1x1<bf16_t>(d, gridDim.x, blockIdx.x, tile);
+        else wprep_job_1x1<float>(d, gridDim.x, blockIdx.x, tile);
+        return;
+    }
     if (d.dtype == GA_BF16) wprep_job<bf16_t>(d, gridDim.x, blockIdx.x);
     else wprep_job<float>(d, gridDim.x, blockIdx.x);
 }
@@ -298,7 +364,37 @@ __global__ __launch_bounds__(256) void small_batch_kernel(const ga_small_desc* _
 __global__ __launch_bounds__(256) void unfold_batch_kernel(const ga_wunfold_desc* __restrict__ jobs) {
     const ga_wunfold_desc d = jobs[blockIdx.y];
     const int KK = d.Ci * d.KH * d.KW;
-    if (d.dW) {
+    const bool vec4 = d.KH == 1 && d.KW == 1 && !d.stem && KK % 4 == 0 && d.ldg % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(d.G) | reinterpret_cast<uintptr_t>(d.dW) |
+                        reinterpret_cast<uintptr_t>(d.cs) | reinterpret_cast<uintptr_t>(d.v)) & 15) == 0;
+    if (d.dW && vec4) {   // 1x1 weights: 4 columns per thread, one 32-bit division per 16 bytes
+        const unsigned P = (unsigned)KK >> 2, total = (unsigned)d.N * P;
+        for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+            const unsigned no = i / P, k4 = (i - no * P) << 2;
+            const int n = d.row_perm ? d.row_perm[no] : (int)no;
+            float g[4], w[4];
+            load4(d.G + (long)no * d.ldg + k4, g);
+            if (d.cs) {
+                float cs[4];
+                load4(d.cs + k4, cs);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] *= cs[j];
+            }
+            if (d.gb && d.v) {
+                float vv[4];
+                load4(d.v + k4, vv);
+                const float gbn = d.gb[no];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = fmaf(gbn, vv[j], g[j]);
+            }
+            const float rs = d.rs ? d.rs[n] : 1.f;
+            float* dst = d.dW + (long)n * KK + k4;
+            load4(dst, w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = fmaf(g[j], rs, w[j]);
+            store4(dst, w);
+        }
+    } else if (d.dW) {
         const long total = (long)d.N * KK;
         for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
             const int no = (int)(i / KK), kcol = (int)(i - (long)no * KK);
