@@ -353,8 +353,18 @@ __global__ __launch_bounds__(256) void small_batch_kernel(const ga_small_desc* _
         for (int no = blockIdx.x * 4 + (threadIdx.x >> 6); no < d.R; no += gridDim.x * 4) {
             const int n = d.row_perm ? d.row_perm[no] : no;
             float s = 0.f;
-            if (d.v)
-                for (int c = lane; c < d.C; c += 64) s += d.x[(long)n * d.C + c] * d.v[c];
+            if (d.v) {
+                if (d.C % 4 == 0 && ((reinterpret_cast<uintptr_t>(d.x) | reinterpret_cast<uintptr_t>(d.v)) & 15) == 0) {
+                    for (int c = lane * 4; c < d.C; c += 256) {
+                        float w[4], vv[4];
+                        load4(d.x + (long)n * d.C + c, w);
+                        load4(d.v + c, vv);
+                        s += w[0] * vv[0] + w[1] * vv[1] + w[2] * vv[2] + w[3] * vv[3];
+                    }
+                } else {
+                    for (int c = lane; c < d.C; c += 64) s += d.x[(long)n * d.C + c] * d.v[c];
+                }
+            }
             s = wave_sum(s);
             if (lane == 0) d.y[no] = (d.rs ? d.rs[n] : 1.f) * ((d.b ? d.b[n] : 0.f) + s);
         }
@@ -554,18 +564,18 @@ extern "C" int ga_cast_to_f32(const void* src, float* dst, int64_t n, int dtype,
 
 extern "C" int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_stream_t stream) {
     GA_REQUIRE(jobs_dev && n > 0, "ga_weight_prep_batch: bad args");
-    hipLaunchKernelGGL(wprep_batch_kernel, dim3(48, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    hipLaunchKernelGGL(wprep_batch_kernel, dim3(64, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
     return ga_check_launch("ga_weight_prep_batch");
 }
 
 extern "C" int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t stream) {
     GA_REQUIRE(jobs_dev && n > 0, "ga_small_batch: bad args");
-    hipLaunchKernelGGL(small_batch_kernel, dim3(8, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    hipLaunchKernelGGL(small_batch_kernel, dim3(48, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
     return ga_check_launch("ga_small_batch");
 }
 
 extern "C" int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream) {
     GA_REQUIRE(jobs_dev && n > 0, "ga_weight_unfold_batch: bad args");
-    hipLaunchKernelGGL(unfold_batch_kernel, dim3(32, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
+    hipLaunchKernelGGL(unfold_batch_kernel, dim3(64, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
     return ga_check_launch("ga_weight_unfold_batch");
 }
