@@ -533,31 +533,6 @@ __global__ __launch_bounds__(1024) void dwconv7_wgrad_reduce(const float* __rest
     }
 }
 
-// per-stream scratch for the partial sums (grown on demand, never shrunk); launches on one stream are ordered, so one
-// buffer per stream is enough
-float* wgrad_scratch(hipStream_t s, size_t bytes) {
-    struct Slot { hipStream_t s; float* p; size_t bytes; };
-    static Slot slots[16];
-    static int nslots = 0;
-    Slot* sl = nullptr;
-    for (int i = 0; i < nslots; ++i)
-        if (slots[i].s == s) sl = &slots[i];
-    if (!sl) {
-        if (nslots == 16) return nullptr;
-        sl = &slots[nslots++];
-        *sl = Slot{s, nullptr, 0};
-    }
-    if (sl->bytes < bytes) {
-        if (sl->p) (void)hipFree(sl->p);        // synchronises with the work still using it
-        sl->p = nullptr;
-        sl->bytes = 0;
-        const size_t want = std::max(bytes, (size_t)8 << 20);
-        if (hipMalloc(&sl->p, want) != hipSuccess) return nullptr;
-        sl->bytes = want;
-    }
-    return sl->p;
-}
-
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s) {
@@ -597,7 +572,7 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
     const bool dot2 = sizeof(T) == 2 && C % 8 == 0;   // dot2 form: 89 KB of LDS at 14x14 -> one workgroup per CU
     const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? (dot2 ? 1 : 2) : 4) * num_cu / slices));
     const int nparts = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
-    float* part = wgrad_scratch(s, (size_t)nparts * 50 * C * sizeof(float));
+    float* part = ga_scratch(s, (size_t)nparts * 50 * C * sizeof(float));
     if (!part) {
         ga_set_error("dwconv7_wgrad: cannot allocate %zu B of scratch", (size_t)nparts * 50 * C * sizeof(float));
         return GA_ERR_HIP;

@@ -735,10 +735,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
 }
 
 // ================================================================================================
-// TN kernel, wide form (bf16, plain operands, M % 64 == 0): 256 x 256 output tile, 8 waves (2 over n x 4 over k,
-// 128 x 64 per wave), operands brought in by LDS-DMA (global_load_lds_dwordx4) into two 64 KiB stage buffers:
-// the loads of stage s+1 are in flight while stage s is multiplied, one barrier per stage.
-// A stage = 64 reduction rows x {Y0, Y1, X0, X1}, each a [64][256 B] image in the same XOR layout as the narrow
+// TN kernel, wide form (bf16, plain operands, M % 32 == 0): 256 x 256 output tile, 8 waves (2 over n x 4 over k,
+// 128 x 64 per wave), operands brought in by LDS-DMA (global_load_lds_dwordx4) into a ring of four 32 KiB stages:
+// the loads of stages s+1..s+3 are in flight while stage s is multiplied, one barrier per stage.
+// A stage = 32 reduction rows x {Y0, Y1, X0, X1}, each a [32][256 B] image in the same XOR layout as the narrow
 // kernel (the DMA writes LDS lane-linearly, so the swizzle is applied to the SOURCE chunk each lane fetches).
 // vs the 128 x 128 form: half the operand bytes per FLOP from L2 and no staging registers / ds_writes.
 // Column sums of Y (bias gradient) ride along as one extra MFMA per fragment against a constant ones operand.
@@ -755,9 +755,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-constexpr int kTn2Threads = 512, kTn2Stage = 65536, kTn2Smem = 2 * kTn2Stage;
+constexpr int kTn2Threads = 512, kTn2Stage = 32768, kTn2Smem = 4 * kTn2Stage;
 
-__global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_desc d, const int split_m) {
+__global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_desc d, const int split_m,
+                                                               float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform roles stay in SGPRs
@@ -769,13 +770,13 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
     const int tile_n = tile / tiles_k, tile_k = tile - tile_n * tiles_k;
     const int n0 = tile_n * 256, k0 = tile_k * 256;
     const int z = blockIdx.z;
-    const int stages = d.M / 64;
+    const int stages = d.M / 32;
     const int per = (stages + split_m - 1) / split_m;
     const int s_begin = split * per;
     const int s_end = s_begin + per < stages ? s_begin + per : stages;
     if (s_begin >= s_end) return;
 
-    // ---- DMA role: wave w fills sub-image w>>1 (0,1 = Y halves; 2,3 = X halves), rows 32*(w&1) + 4*i + (lane>>4)
+    // ---- DMA role: wave w fills sub-image w>>1 (0,1 = Y halves; 2,3 = X halves), rows 16*(w&1) + 4*i + (lane>>4)
     const int sub = wave >> 1;
     const bool is_y = sub < 2;
     const int ncols = is_y ? d.N : d.K;
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
     const int zx = d.x_batch_mod > 0 ? z % d.x_batch_mod : z;
     const bf16_t* gsrc = is_y ? reinterpret_cast<const bf16_t*>(d.Y) + z * d.strideY
                               : reinterpret_cast<const bf16_t*>(d.X) + zx * d.strideX;
-    const int lrow = 32 * (wave & 1) + (lane >> 4);                // + 4*i
+    const int lrow = 16 * (wave & 1) + (lane >> 4);                // + 4*i
     const int pc = lane & 15;
     // source chunk for i even / odd pairs: swizzle = ((row&3)<<1) | (((row>>3)&1)<<3), row&3 = (lane>>4)&3, row bit 3 = (i>>1)&1
     const int sw_lo = ((lane >> 4) & 3) << 1;
@@ -799,10 +800,10 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto stage_load = [&](int s, int buf) {
         if (!sub_live) return;
-        const bf16_t* g = gsrc + (long)s * 64 * ld;
-        const unsigned dst = lds0 + buf * kTn2Stage + sub * 16384 + (wave & 1) * 8192;
+        const bf16_t* g = gsrc + (long)s * 32 * ld;
+        const unsigned dst = lds0 + buf * kTn2Stage + sub * 8192 + (wave & 1) * 4096;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) glds16(g + goff[(i >> 1) & 1] + (long)(4 * i) * ld, dst + i * 1024);
+        for (int i = 0; i < 4; ++i) glds16(g + goff[(i >> 1) & 1] + (long)(4 * i) * ld, dst + i * 1024);
     };
 
     // ---- MFMA role
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
     const bf16x2_t ones2 = {(__bf16)1.0f, (__bf16)1.0f};
 
-    const unsigned y_img = wn * 16384, x_img = 32768 + (wk >> 1) * 16384;
+    const unsigned y_img = wn * 8192, x_img = 16384 + (wk >> 1) * 8192;
     const int xc0 = (wk & 1) * 8;                                  // first chunk of this wave's 64 X columns
     // fragment addresses: the XOR term depends on the lane only (row & 3 and bit 3 of the row are the same for both
     // 4-row halves and both k-steps), so one address per fragment column + immediates for half / k-step / buffer
@@ -834,56 +835,64 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
 #pragma unroll
         for (int t = 0; t < 4; ++t) xaddr[t] = x_img + rb + (((xc0 + 2 * t + ((lane & 3) >> 1)) ^ sw) << 4);
     }
-    // one stage = 2 k-steps of 32 reduction rows.  Fragments beyond N / K are multiplied too (their inputs are
+    // one stage = one k-step of 32 reduction rows.  Fragments beyond N / K are multiplied too (their inputs are
     // clamped loads, their outputs are never written): no predicates in the loop.
     auto compute = [&](int cur) {
         const unsigned char* st = smem + cur * kTn2Stage;
+        s16x4_t yf[8][2], xf[4][2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            s16x4_t yf[8][2], xf[4][2];
+        for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
+            for (int t = 0; t < 4; ++t)
+                xf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(st + xaddr[t] + hf * 1024));
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    xf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(st + xaddr[t] + ks * 8192 + hf * 1024));
+            for (int t = 0; t < 8; ++t)
+                yf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(st + yaddr[t] + hf * 1024));
+        }
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    yf[t][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (__attribute__((address_space(3))) s16x4_t*)(st + yaddr[t] + ks * 8192 + hf * 1024));
-            }
+        for (int tn = 0; tn < 8; ++tn) {
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]);
+#pragma unroll
+            for (int tk = 0; tk < 4; ++tk)
+                acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    a, *reinterpret_cast<const bf16x8_t*>(&xf[tk][0]), acc[tn][tk], 0, 0, 0);
+        }
+        if (do_bias) {
 #pragma unroll
             for (int tn = 0; tn < 8; ++tn) {
                 const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]);
 #pragma unroll
-                for (int tk = 0; tk < 4; ++tk)
-                    acc[tn][tk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        a, *reinterpret_cast<const bf16x8_t*>(&xf[tk][0]), acc[tn][tk], 0, 0, 0);
-            }
-            if (do_bias) {
-#pragma unroll
-                for (int tn = 0; tn < 8; ++tn) {
-                    const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&yf[tn][0]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        bsum[tn] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{a[2 * j], a[2 * j + 1]}, ones2, bsum[tn], false);
-                }
+                for (int j = 0; j < 4; ++j)
+                    bsum[tn] = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{a[2 * j], a[2 * j + 1]}, ones2, bsum[tn], false);
             }
         }
     };
 
-    stage_load(s_begin, 0);
-    for (int s = s_begin; s < s_end; ++s) {
-        const int cur = (s - s_begin) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // stage s has landed for every wave; buffer cur^1 is no longer read
-        if (s + 1 < s_end) stage_load(s + 1, cur ^ 1);
-        if (nv > 0 && kv > 0) compute(cur);
+    // 4-slot ring, three stages in flight: at iteration `it` the wave's own DMA of stages it+1 and it+2 (4 loads each) may
+    // still be outstanding when stage `it` is consumed -- a COUNTED wait, the loads span the barrier
+    const int nst = s_end - s_begin;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (j < nst) stage_load(s_begin + j, j);
+    for (int it = 0; it < nst; ++it) {
+        const int ahead = nst - 1 - it;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // stage `it` has landed for every wave; slot (it-1)&3 is no longer read
+        if (it + 3 < nst) stage_load(s_begin + it + 3, (it + 3) & 3);
+        if (nv > 0 && kv > 0) compute(it & 3);
     }
 
-    // ---- write out: D[n][k]; lane: k = lane&15 (col), n = (lane>>4)*4 + r (rows); row splits meet in fp32 atomics
-    float* W = d.dW + z * d.strideW;
-    const bool atomic = d.accumulate || split_m > 1;
+    // ---- write out: D[n][k]; lane: k = lane&15 (col), n = (lane>>4)*4 + r (rows).  With row splits every workgroup
+    // stores its partial tile to part[split][N][K] (plain stores; tn2_reduce sums the splits): 20 splits adding 256 KiB
+    // tiles into the same 2 MB with fp32 atomics took as long as the multiplication itself.
+    float* W = part ? part + ((long)z * split_m + split) * d.N * d.K : d.dW + z * d.strideW;
+    const long ldw = part ? d.K : d.ldw;
+    const float alpha = part ? 1.f : d.alpha;
+    const bool atomic = !part && (d.accumulate || split_m > 1);
 #pragma unroll
     for (int tn = 0; tn < 8; ++tn)
 #pragma unroll
@@ -893,9 +902,9 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
                 const int n = n0 + wn * 128 + tn * 16 + (lane >> 4) * 4 + r;
                 const int k = k0 + wk * 64 + tk * 16 + (lane & 15);
                 if (n < d.N && k < d.K) {
-                    const float v = acc[tn][tk][r] * d.alpha;
-                    if (atomic) atomicAdd(W + (long)n * d.ldw + k, v);
-                    else W[(long)n * d.ldw + k] = v;
+                    const float v = acc[tn][tk][r] * alpha;
+                    if (atomic) atomicAdd(W + (long)n * ldw + k, v);
+                    else W[(long)n * ldw + k] = v;
                 }
             }
     if (do_bias) {                            // lane holds column n = tn*16 + (lane&15); the 4 lane groups hold row subsets
@@ -910,14 +919,32 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
     }
 }
 
-// the wide form needs whole 64-row stages, plain bf16 operands, and an output that is accumulated into (so that it
+// dW[n][k] += alpha * sum_s part[s][n][k]   (N*K multiple of 4: N, K are multiples of 8)
+__global__ __launch_bounds__(256) void tn2_reduce_kernel(const float* __restrict__ part, int nsplit, long nk, int K,
+                                                         float alpha, float* __restrict__ dW, long ldw, long strideW) {
+    const long z = blockIdx.y;
+    const float* p = part + z * nsplit * nk;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < nk; i += (long)gridDim.x * 1024) {
+        float4 a = *reinterpret_cast<const float4*>(p + i);
+#pragma unroll 4
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(p + (long)s * nk + i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const long n = i / K, k = i - n * K;
+        float* dst = dW + z * strideW + n * ldw + k;
+        dst[0] += alpha * a.x; dst[1] += alpha * a.y; dst[2] += alpha * a.z; dst[3] += alpha * a.w;
+    }
+}
+
+// the wide form needs whole 32-row stages, plain bf16 operands, and an output that is accumulated into (so that it
 // may choose its own row split); it pays once the reduction is long enough to amortise the 256 x 256 tile
 bool tn2_eligible(const ga_wgrad_desc* d) {
     static const int force = [] {
         const char* e = getenv("GAEXT_TN2");      // 0 disables, for experiments
         return e ? atoi(e) : 1;
     }();
-    return force && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 64 == 0 &&
+    return force && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 32 == 0 &&
            d->M >= 8192 && (d->accumulate || d->split_m > 1) && d->ldw % 1 == 0;
 }
 
@@ -1084,10 +1111,20 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kTn2Smem) == hipSuccess;
         GA_REQUIRE(attr_ok, "ga_wgrad: cannot reserve %d bytes of LDS", kTn2Smem);
         const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
-        const int stages = d->M / 64;
-        const int split = std::max(1, std::min(stages / 4, num_cus() / tiles));   // one workgroup per CU
+        const int stages = d->M / 32;
+        int split = std::max(1, std::min(stages / 8, num_cus() / tiles));         // one workgroup per CU
+        split = cdiv(stages, cdiv(stages, split));                                // no empty row range
         dim3 grid2(cdiv(d->N, 256) * cdiv(d->K, 256) * split, 1, d->batch), block2(kTn2Threads);
-        hipLaunchKernelGGL(gemm_tn2_kernel, grid2, block2, kTn2Smem, s, *d, split);
+        float* part = nullptr;
+        const long nk = (long)d->N * d->K;
+        if (split > 1 && nk >= 131072) {   // small outputs: the atomics are cheaper than a second launch
+            part = ga_scratch(s, (size_t)d->batch * split * nk * sizeof(float));
+            GA_REQUIRE(part, "ga_wgrad: cannot allocate %zu B of scratch", (size_t)d->batch * split * nk * sizeof(float));
+        }
+        hipLaunchKernelGGL(gemm_tn2_kernel, grid2, block2, kTn2Smem, s, *d, split, part);
+        if (part)
+            hipLaunchKernelGGL(tn2_reduce_kernel, dim3((unsigned)std::min<long>(2048, cdiv(nk, 1024)), d->batch), dim3(256),
+                               0, s, part, split, nk, d->K, d->alpha, d->dW, d->ldw, d->strideW);
         return ga_check_launch("ga_wgrad");
     }
     dim3 grid(cdiv(d->N, 128) * cdiv(d->K, 128) * d->split_m, 1, d->batch), block(kThreads);

@@ -220,7 +220,7 @@ def test_wgrad_plain(dt, shape):
     assert_close(dW, y.t() @ xg, tol(dt, 2), 'wgrad overwrite + gelu(X)')
 
 
-@pytest.mark.parametrize('shape', [(8192, 384, 1536), (8192, 96, 384), (16384, 384, 96), (8256, 200, 328), (12800, 768, 192)])
+@pytest.mark.parametrize('shape', [(8192, 384, 1536), (8192, 96, 384), (16384, 384, 96), (8256, 200, 328), (12800, 768, 192), (8224, 136, 264)])
 def test_wgrad_wide_tile_bf16(shape):
     """the 256x256-tile LDS-DMA form (bf16, M % 64 == 0, M >= 8192, accumulating output): ragged N / K, padded
     leading dimensions, bias column sums, its own choice of row splits"""
