@@ -157,6 +157,21 @@ template <typename T> __device__ __forceinline__ uint4 act_chunk(uint4 v, int ac
     }
 }
 
+// one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB) (dst is
+// wave-uniform, carried in M0).  Written as asm so that hipcc does not count it: a builtin glds makes every later
+// ds_read wait vmcnt(0) (possible alias), which would drain the prefetch it exists for.  The kernel waits itself.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
+// lanes whose source row / k chunk is out of range fetch zeros from here
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
 // ================================================================================================
 // NT kernel.  Tile = 128 rows x BN columns (BN = 32*TNW = 64 / 96 / 128), 256 threads = 4 waves as 2(M) x 2(N),
 // each wave 64 x 16*TNW.  One 128-byte K slab of A and B lives in LDS (single buffer, <= 32 KiB) while the NEXT
@@ -170,14 +185,26 @@ template <int TNW, int NWM> struct NTCfg {
     static constexpr int BN = 32 * TNW;
     static constexpr int A_BYTES = BM * kRowBytes;
     static constexpr int RSTEP = NTHR / 8;                    // rows staged per pass of the workgroup
-    static constexpr int NB = BN * 8 / NTHR;                  // B chunks per thread per slab
-    static_assert((BN * 8) % NTHR == 0, "B slab must split evenly over the threads");
+    static constexpr int NB = BN * 8 / NTHR > 0 ? BN * 8 / NTHR : 1;   // B chunks per thread per slab (register staging)
     static constexpr int LDCS = BN + 4;                       // padded fp32 row stride of the staged 64-row piece
     static constexpr int SMEM_AB = A_BYTES + BN * kRowBytes;
     static constexpr int SMEM_C = 64 * LDCS * 4;
     static constexpr int SMEM = SMEM_AB > SMEM_C ? SMEM_AB : SMEM_C;
     static constexpr int P8 = BN / 8;                         // 8-column pieces per row
     static constexpr int RG = NTHR / P8;                      // row groups in the coalesced store phase
+    // LDS-DMA form: [fp32 staging | ring of NS slots].  With 128-column tiles of 8 waves the staging area shrinks to
+    // 32 unpadded (XOR-swizzled) rows = 16 KiB and THREE slots fit into the 160 KiB of a CU: two slabs (96 KiB) in
+    // flight while one is multiplied.  Otherwise two slots behind the padded 64-row staging area (which must also hold
+    // the [2][RG][BN] column-sum scratch).
+    static constexpr bool DMA3 = TNW == 4 && NWM == 4;
+    static constexpr int NS = DMA3 ? 3 : 2;
+    static constexpr int PR = DMA3 ? 32 : 64;                 // rows per staged piece (LDS-DMA form)
+    static constexpr int CSUM_BYTES = 2 * RG * BN * 4;
+    static constexpr int STAGE_DMA = DMA3 ? 32 * BN * 4 : (SMEM_C > CSUM_BYTES ? SMEM_C : CSUM_BYTES);
+    static constexpr int RING0 = (STAGE_DMA + 1023) & ~1023;
+    static constexpr int SMEM_DMA = RING0 + NS * SMEM_AB;
+    static constexpr int NW = 2 * NWM;                        // waves
+    static constexpr int NBP = (4 * TNW + NW - 1) / NW;       // B pieces (8 rows) per wave, the last may be idle
 };
 
 // EPI >= 0 fixes the epilogue at compile time (dead paths are not even emitted: the all-runtime generic kernel is
@@ -186,7 +213,11 @@ template <int TNW, int NWM> struct NTCfg {
 //   2 fc2: bias (+ DropPath row scale) + residual      3 dgrad2: multiply by the stored GELU' (+ column sums)
 enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_FC1 = 1, EPI_FC2 = 2, EPI_DG2 = 3 };
 
-template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI>
+// DMA (bf16, plain A): the K slabs are brought in by LDS-DMA (glds16) into a 2-slot ring that sits BEHIND the fp32
+// staging area of the epilogue, one barrier per slab; the stream of slabs runs across tile boundaries, so the first
+// slab of the next tile lands while this tile's epilogue runs.  No staging registers and no ds_write pass: with
+// register staging the 8 ds_write_b128 per thread and slab (~79 B/clk/CU) cost more LDS time than the MFMAs take.
+template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI, bool DMA = false>
 __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d) {
 #define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
 #define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
@@ -204,11 +235,15 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
     constexpr int EPC = elt<T>::EPC;
     constexpr int BK = kRowBytes / (int)sizeof(T);
     constexpr int BN = CF::BN;
+    static_assert(!DMA || (PLAIN && sizeof(T) == 2), "the LDS-DMA form needs plain bf16 operands");
+    static_assert(DMA || (CF::BN * 8) % CF::NTHR == 0, "B slab must split evenly over the threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + CF::A_BYTES;
+    constexpr int RING0 = DMA ? CF::RING0 : 0;
+    unsigned char* As = smem + RING0;
+    unsigned char* Bs = As + CF::A_BYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = DMA ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (d.N + BN - 1) / BN, tiles_m = (d.M + CF::BM - 1) / CF::BM;
     const int nwg = tiles_n * tiles_m;
@@ -274,6 +309,46 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
         }
     };
 
+    // ---- LDS-DMA roles: wave w brings A pieces 4w..4w+3 and B pieces w, w+NW, ... (a piece = 8 rows x 128 B);
+    // lane: row lane>>3 of the piece, LDS chunk lane&7, which holds SOURCE chunk (lane&7) ^ (lane>>3)
+    long aoff[DMA ? 4 : 1], boff[DMA ? CF::NBP : 1];           // element offset of the row start, < 0: row out of range
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + RING0;
+    auto dma_rows = [&](int tm0, int tn0) {
+        if constexpr (DMA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = (long)tm0 + (wave * 4 + i) * 8 + (lane >> 3);
+                aoff[i] = m < d.M ? m * d.lda : -1;
+            }
+#pragma unroll
+            for (int i = 0; i < CF::NBP; ++i) {
+                const long n = (long)tn0 + (i * CF::NW + wave) * 8 + (lane >> 3);
+                boff[i] = n < d.N ? n * d.ldb : -1;
+            }
+        }
+    };
+    auto dma_issue = [&](int kt, int slot) {
+        if constexpr (DMA) {
+            const int k = kt * BK + dchunk;
+            const bool kv = k < d.K;
+            const T* Ap = reinterpret_cast<const T*>(Ab) + k;
+            const unsigned dst = lds_ring + slot * CF::SMEM_AB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                glds16((kv && aoff[i] >= 0) ? static_cast<const void*>(Ap + aoff[i]) : static_cast<const void*>(g_zero_page),
+                       dst + (wave * 4 + i) * 1024);
+#pragma unroll
+            for (int i = 0; i < CF::NBP; ++i) {
+                const int p = i * CF::NW + wave;
+                if (p < 4 * TNW)
+                    glds16((kv && boff[i] >= 0) ? static_cast<const void*>(Bb + boff[i] + k)
+                                               : static_cast<const void*>(g_zero_page),
+                           dst + CF::A_BYTES + p * 1024);
+            }
+        }
+    };
+
     const T* Hb = d.H ? reinterpret_cast<const T*>(d.H) + z * d.strideH : nullptr;
     const T* Rb = d.R ? reinterpret_cast<const T*>(d.R) + z * d.strideR : nullptr;
     float* Cs = reinterpret_cast<float*>(smem);
@@ -293,7 +368,32 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
 
     int vt = blockIdx.x;
     set_tile(vt);
-    g_load(0);
+    // LDS-DMA form: the slabs of all the workgroup's tiles form ONE stream; the issue side runs NS-1 slabs ahead of the
+    // consuming side, across tile boundaries (issue-side state: tile ivt, slab ikt, ring slot islot)
+    int cslot = 0, ivt = blockIdx.x, ikt = 0, islot = 0, inflight = 0;
+    auto issue_next = [&]() {
+        if constexpr (DMA) {
+            if (ivt >= nwg) return;
+            if (ikt == 0) {
+                const int bid = xcd_remap(ivt, nwg);
+                const int tile_m = bid / tiles_n;
+                dma_rows(tile_m * CF::BM, (bid - tile_m * tiles_n) * BN);
+            }
+            dma_issue(ikt, islot);
+            islot = islot + 1 == CF::NS ? 0 : islot + 1;
+            if (++ikt == nk) {
+                ikt = 0;
+                ivt += gridDim.x;
+            }
+            ++inflight;
+        }
+    };
+    if constexpr (DMA) {
+#pragma unroll
+        for (int j = 0; j < CF::NS - 1; ++j) issue_next();
+    } else {
+        g_load(0);
+    }
     for (; vt < nwg; ) {
     const int cm0 = m0, cn0 = n0;   // the tile being computed (m0/n0 move on to the prefetched tile below)
     const int n = cn0 + c8 * 8;
@@ -306,11 +406,27 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    s_store();
-    __syncthreads();
+    if constexpr (!DMA) {
+        s_store();
+        __syncthreads();
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) g_load(kt + 1);
+        if constexpr (DMA) {
+            // this wave's pieces of the slab about to be consumed have landed; with three slots the NEXT slab's
+            // 6 loads (4 A + 2 B pieces per wave) may stay in flight across the barrier: a counted wait.  Younger
+            // stores / loads of the epilogue only make the wait stricter, never weaker (loads return in order).
+            if (CF::NS == 3 && inflight >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // ... everyone's; the slot consumed last is free
+            issue_next();
+            --inflight;
+            As = smem + RING0 + cslot * CF::SMEM_AB;
+            Bs = As + CF::A_BYTES;
+            cslot = cslot + 1 == CF::NS ? 0 : cslot + 1;
+        } else {
+            if (kt + 1 < nk) g_load(kt + 1);
+        }
         if constexpr (kPre) {
             if (kt == nk - 1 && use_pre) {
 #pragma unroll
@@ -353,17 +469,19 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                 }
             }
         }
-        __syncthreads();  // every wave is done reading this slab
-        if (kt + 1 < nk) {
-            s_store();
-            __syncthreads();
+        if constexpr (!DMA) {
+            __syncthreads();  // every wave is done reading this slab
+            if (kt + 1 < nk) {
+                s_store();
+                __syncthreads();
+            }
         }
     }
     // start fetching the next tile's first slab; it lands while this tile's epilogue runs
     vt += gridDim.x;
     if (vt < nwg) {
         set_tile(vt);
-        g_load(0);
+        if constexpr (!DMA) g_load(0);
     }
 
     // ---- fused epilogue, two 64-row halves staged through LDS as fp32 [64][BN+4]
@@ -378,29 +496,40 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
         const int tap = n / d.c_C, ch = n - tap * d.c_C;
         c_off = ((long)(tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch;
     }
+    // staged piece: 64 padded rows, or (3-slot LDS-DMA form) 32 unpadded rows whose 16-byte units are XOR-swizzled with
+    // the row (conflict-free fragment writes, 2-way on the row reads)
+    constexpr bool SW = DMA && CF::DMA3;
+    constexpr int PRr = SW ? 32 : 64, NSUB = 64 / PRr, TMP = PRr / 16, NRP = SW ? 1 : NR;
 #pragma unroll
     for (int half = 0; half < NWM; ++half) {
-        if (half) __syncthreads();  // previous half fully read
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+        if (half || sub) __syncthreads();  // previous piece fully read
         if (wm == half) {
 #pragma unroll
             for (int tn = 0; tn < TNW; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-                    *reinterpret_cast<f32x4_t*>(Cs + (tm * 16 + (lane & 15)) * CF::LDCS + wn * (16 * TNW) + tn * 16 +
-                                                (lane >> 4) * 4) = acc[tn][tm];
+                for (int tml = 0; tml < TMP; ++tml) {
+                    const int row = tml * 16 + (lane & 15), col = wn * (16 * TNW) + tn * 16 + (lane >> 4) * 4;
+                    float* dst = SW ? Cs + row * BN + ((((col >> 2) ^ (row & 15))) << 2) : Cs + row * CF::LDCS + col;
+                    *reinterpret_cast<f32x4_t*>(dst) = acc[tn][sub * TMP + tml];
+                }
         }
         __syncthreads();
         if (n_ok) {
 #pragma unroll
-            for (int it = 0; it < NR; ++it) {
-                const int row = rg + it * CF::RG;
-                if (row >= 64) break;
-                const long m = (long)cm0 + half * 64 + row;
+            for (int itp = 0; itp < NRP; ++itp) {
+                const int it = sub * NRP + itp;       // index of this row among the thread's rows of the 64-row half
+                const int row = rg + itp * CF::RG;
+                if (row >= PRr) break;
+                const long m = (long)cm0 + half * 64 + sub * PRr + row;
                 if (m >= d.M) break;
                 float v[8];
                 {
-                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(Cs + row * CF::LDCS + c8 * 8);
-                    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(Cs + row * CF::LDCS + c8 * 8 + 4);
+                    const float* pa = SW ? Cs + row * BN + (((2 * c8) ^ (row & 15)) << 2) : Cs + row * CF::LDCS + c8 * 8;
+                    const float* pb = SW ? Cs + row * BN + (((2 * c8 + 1) ^ (row & 15)) << 2) : Cs + row * CF::LDCS + c8 * 8 + 4;
+                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(pa);
+                    const f32x4_t b = *reinterpret_cast<const f32x4_t*>(pb);
                     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
                     v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
                 }
@@ -410,7 +539,10 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                     float w[8];
                     if (EPI >= 0 || (d.c2_mode == 2 && d.act == GA_ACT_GELU)) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) gelu_both_f(v[j], v[j], w[j]);   // v := gelu, w := gelu'
+                        for (int j = 0; j < 8; ++j) {   // v := gelu, w := gelu'
+                            if constexpr (sizeof(T) == 2 && EPI == EPI_FC1) gelu_both_fast(v[j], v[j], w[j]);
+                            else gelu_both_f(v[j], v[j], w[j]);
+                        }
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) w[j] = d.c2_mode == 2 ? gelu_grad_f(v[j]) : v[j];
@@ -518,23 +650,33 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
             }
         }
     }
+    }
     if (F_CSUM) {  // workgroup-level column reduction over the RG row groups, then one atomic per column
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);  // [2][RG][BN]
-        if (t_active) {
+        float* red = reinterpret_cast<float*>(smem);  // [2][RG][BN]; the 16 KiB staging area takes one half at a time
+        constexpr int NPASS = SW ? 2 : 1;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                red[rg * BN + c8 * 8 + j] = csum[j];
-                red[CF::RG * BN + rg * BN + c8 * 8 + j] = csq[j];
+        for (int pass = 0; pass < NPASS; ++pass) {
+            if (SW && pass == 1 && !d.colsumsq) break;
+            __syncthreads();
+            if (t_active) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if constexpr (SW) {
+                        red[rg * BN + c8 * 8 + j] = pass == 0 ? csum[j] : csq[j];
+                    } else {
+                        red[rg * BN + c8 * 8 + j] = csum[j];
+                        red[CF::RG * BN + rg * BN + c8 * 8 + j] = csq[j];
+                    }
+                }
             }
-        }
-        __syncthreads();
-        for (int i = tid; i < 2 * BN; i += CF::NTHR) {
-            const int which = i / BN, col = i - which * BN;
-            if (cn0 + col < d.N && (which == 0 || d.colsumsq)) {
-                float s = 0.f;
-                for (int r = 0; r < CF::RG; ++r) s += red[which * CF::RG * BN + r * BN + col];
-                atomicAdd((which ? d.colsumsq : d.colsum) + z * d.strideCol + cn0 + col, s);
+            __syncthreads();
+            for (int i = tid; i < (SW ? BN : 2 * BN); i += CF::NTHR) {
+                const int which = SW ? pass : i / BN, col = SW ? i : i - which * BN;
+                if (cn0 + col < d.N && (which == 0 || d.colsumsq)) {
+                    float s = 0.f;
+                    for (int r = 0; r < CF::RG; ++r) s += red[(SW ? 0 : which * CF::RG * BN) + r * BN + col];
+                    atomicAdd((which ? d.colsumsq : d.colsum) + z * d.strideCol + cn0 + col, s);
+                }
             }
         }
     }
@@ -743,18 +885,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const ga_wgrad_des
 // vs the 128 x 128 form: half the operand bytes per FLOP from L2 and no staging registers / ds_writes.
 // Column sums of Y (bias gradient) ride along as one extra MFMA per fragment against a constant ones operand.
 // ================================================================================================
-// one LDS-DMA wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KiB) (dst is
-// wave-uniform, carried in M0).  Written as asm so that hipcc does not count it: a builtin glds makes every later
-// ds_read wait vmcnt(0) (possible alias), which would drain the prefetch it exists for.  The kernel waits itself.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-
 constexpr int kTn2Threads = 512, kTn2Stage = 32768, kTn2Smem = 4 * kTn2Stage;
 
 __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_desc d, const int split_m,
@@ -952,20 +1082,27 @@ bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 
 // persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
 // rounded down to a multiple of 8 so every XCD gets the same share of the tile walk
-template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI>
+template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI, bool DMA = false>
 void launch_nt_(const ga_gemm_desc* d, hipStream_t s) {
     using CF = NTCfg<TNW, NWM>;
-    static const int per_cu = [] {
+    constexpr int smem = DMA ? CF::SMEM_DMA : CF::SMEM;
+    auto kern = gemm_nt_kernel<T, TNW, NWM, PLAIN, PRE, EPI, DMA>;
+    static const int per_cu = [&] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<T, TNW, NWM, PLAIN, PRE, EPI>, CF::NTHR,
-                                                         CF::SMEM) != hipSuccess || n < 1)
-            n = 1;
+        if (smem > 65536 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+            return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, CF::NTHR, smem) != hipSuccess || n < 1) n = 1;
         return n;
     }();
+    if (per_cu == 0) {
+        ga_set_error("ga_gemm: cannot reserve %d bytes of LDS", smem);
+        return;
+    }
     const int tiles = cdiv(d->M, CF::BM) * cdiv(d->N, CF::BN);
     const int cap = std::max(8, (per_cu * num_cus() / d->batch) / 8 * 8);
     dim3 grid(std::min(tiles, cap), 1, d->batch), block(CF::NTHR);
-    hipLaunchKernelGGL((gemm_nt_kernel<T, TNW, NWM, PLAIN, PRE, EPI>), grid, block, CF::SMEM, s, *d);
+    hipLaunchKernelGGL(kern, grid, block, smem, s, *d);
 }
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
@@ -993,6 +1130,17 @@ bool want_big_tile(const ga_gemm_desc* d, int epi) {
     if (d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || (epi != EPI_FC2 && epi != EPI_DG2)) return false;
     if (force >= 0) return force != 0;
     return (long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch >= 2L * num_cus();
+}
+
+// LDS-DMA form: 256-row tiles, plain bf16 operands, one of the compile-time epilogues
+bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
+    const char* e = getenv("GAEXT_NT_DMA");       // 0 off, 1 heuristic (default), 2 every eligible launch; read per call
+    const int mode = e ? atoi(e) : 1;             // so that a test can switch it
+    if (!mode || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || (tnw != 4 && tnw != 3)) return false;
+    if ((long)cdiv(d->M, 256) * cdiv(d->N, 32 * tnw) * d->batch < num_cus()) return false;
+    // measured (tools/gemm_bench.py): ahead only for the fc2 epilogue with a long reduction (K >= 1024, +8..20 %);
+    // mode 2 forces it on every eligible launch (tests, experiments)
+    return mode == 2 || (epi == EPI_FC2 && tnw == 4 && d->K >= 1024);
 }
 
 template <typename T, int TNW, int NWM>
@@ -1067,8 +1215,24 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         if (bf) launch_nt<bf16_t, TNW, NWM>(d, s);     \
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
-    if (tnw == 4) {
-        const int epi = classify_epilogue(d);
+    const int epi = classify_epilogue(d);
+    if (want_dma(d, epi, tnw)) {
+        if (tnw == 4) {
+            switch (epi) {
+                case EPI_PLAIN: launch_nt_<bf16_t, 4, 4, true, false, EPI_PLAIN, true>(d, s); break;
+                case EPI_FC1: launch_nt_<bf16_t, 4, 4, true, false, EPI_FC1, true>(d, s); break;
+                case EPI_FC2: launch_nt_<bf16_t, 4, 4, true, true, EPI_FC2, true>(d, s); break;
+                default: launch_nt_<bf16_t, 4, 4, true, true, EPI_DG2, true>(d, s); break;
+            }
+        } else {
+            switch (epi) {
+                case EPI_PLAIN: launch_nt_<bf16_t, 3, 4, true, false, EPI_PLAIN, true>(d, s); break;
+                case EPI_FC1: launch_nt_<bf16_t, 3, 4, true, false, EPI_FC1, true>(d, s); break;
+                case EPI_FC2: launch_nt_<bf16_t, 3, 4, true, true, EPI_FC2, true>(d, s); break;
+                default: launch_nt_<bf16_t, 3, 4, true, true, EPI_DG2, true>(d, s); break;
+            }
+        }
+    } else if (tnw == 4) {
         if (want_big_tile(d, epi)) {
             if (epi == EPI_FC2) launch_nt_<bf16_t, 4, 4, true, true, EPI_FC2>(d, s);
             else launch_nt_<bf16_t, 4, 4, true, true, EPI_DG2>(d, s);

@@ -197,6 +197,48 @@ def test_gemm_stem(dt):
     assert_close(dW, ww.grad.reshape(N, 48), tol(dt, 2), 'stem wgrad')
 
 
+@pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384)])
+def test_gemm_lds_dma_form_bf16(shape, monkeypatch):
+    """large-M bf16 launches take the 256-row LDS-DMA form (ragged M, ragged K slab, 96- and 128-wide column tiles):
+    plain + column sums, fc1 (GELU and GELU' outputs), fc2 (row scale + residual), dgrad2 (x stored GELU' + sums)"""
+    ops = _imp()
+    monkeypatch.setenv('GAEXT_NT_DMA', '2')      # every eligible launch, not only the shapes the heuristic picks
+    dt = torch.bfloat16
+    M, N, K = shape
+    g = gen(5)
+    a, A = rnd((M, K), dt, g)
+    b, B = rnd((N, K), dt, g, 1 / math.sqrt(K))
+    bias = torch.randn(N, generator=g)
+    h, Hm = rnd((M, N), dt, g)
+    rs = torch.rand(M // 100, generator=g) + 0.5
+    base = a @ b.t() + bias
+    P = ops.Plan(eager=True)
+    # plain + column sums
+    Cout = torch.empty(M, N, dtype=dt, device='cuda')
+    cs, cq = torch.zeros(N, device='cuda'), torch.zeros(N, device='cuda')
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), colsum=cs, colsumsq=cq)
+    assert_close(Cout, base, 2e-2, 'dma plain')
+    assert_close(cs, base.sum(0), 2e-3, 'dma colsum')
+    assert_close(cq, (base * base).sum(0), 2e-3, 'dma colsumsq')
+    # fc1: gelu + gelu'
+    C2 = torch.empty_like(Cout)
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), act=ops.ACT_GELU, C2=C2, c2_mode=2)
+    xr = base.clone().requires_grad_(True)
+    act = F.gelu(xr)
+    act.sum().backward()
+    assert_close(Cout, act, 2e-2, 'dma fc1 gelu')
+    assert_close(C2, xr.grad, 2e-2, "dma fc1 gelu'")
+    # fc2: row scale (one per 100 rows) + residual
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), rowscale=rs.cuda(), rows_per_scale=100, R=Hm, ldr=N)
+    assert_close(Cout, base * rs.repeat_interleave(100)[:, None] + h, 2e-2, 'dma fc2')
+    # dgrad2: multiply by the stored derivative, column sums of the result
+    cs.zero_()
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), H=Hm, ldh=N, h_is_deriv=True, colsum=cs)
+    ref = (a @ b.t()) * h
+    assert_close(Cout, ref, 2e-2, 'dma dgrad2')
+    assert_close(cs, ref.sum(0), 3e-3, 'dma dgrad2 colsum')
+
+
 # ----------------------------------------------------------------------------------------------------------
 # wgrad (TN)
 # ----------------------------------------------------------------------------------------------------------
