@@ -473,9 +473,9 @@ __global__ __launch_bounds__((DWD<TH, TW>::NT)) void dwconv7_wgrad_dot2_kernel(c
 #pragma unroll
             for (int j = 0; j < G::NP + 2; ++j) Q[j] = __builtin_amdgcn_alignbit(P[j + 1], P[j], 16);
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx)
+            for (int m = 0; m < G::NP; ++m)       // pixel pair outermost: consecutive dot2 hit different accumulators
 #pragma unroll
-                for (int m = 0; m < G::NP; ++m)
+                for (int kx = 0; kx < 7; ++kx)
                     acc[kx] = dot2bf(g2[m], (kx & 1) ? Q[m + (kx >> 1)] : P[m + (kx >> 1)], acc[kx]);
             if (ky == 0) {
 #pragma unroll
@@ -533,9 +533,204 @@ __global__ __launch_bounds__(1024) void dwconv7_wgrad_reduce(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 forward / backward-data on v_dot2_f32_bf16, same channel-plane LDS image as the backward-weight kernel above
+// (lane = channel, rows of consecutive x, two pixels per dword):
+//     y[x] += (in[x+kx], in[x+kx+1]) . (w[kx], w[kx+1])        kx = 0, 2, 4, 6  (w[7] = 0)
+// The 7x7 taps of the lane's channel live in 28 registers as bf16 pairs (rounded once per workgroup: the bf16 mode
+// rounds every GEMM weight the same way); odd output pixels use the input pairs shifted by one pixel (v_alignbit).
+// 28 dot2 + 4.5 alignbit per output element, no bf16 unpacking, no weight reads from LDS, all 64 lanes busy.
+//   wave = output row(s) of the tile; results go through a per-wave [pixel][64 ch] LDS strip back to NHWC 16-byte
+//   stores (+ residual for backward-data).  Persistent over tiles, next tile's pixels prefetched in registers.
+// ------------------------------------------------------------------------------------------------
+template <int TH, int TW> struct DWF {
+    static constexpr int TWP = (TW + 1) & ~1;                        // output columns computed (even)
+    static constexpr int PW = TWP + 6, PH = TH + 6, NPX = PW / 2;    // input tile with halo, pixel pairs per row
+    static constexpr int NPR = NPX + 1;                              // dwords of a row an item touches (incl. zero pad)
+    static constexpr int ROWX = (NPR * 4 + 15) / 16 * 16;            // 48 (14x14) / 32 (7x7)
+    static constexpr int PLX = odd16(PH * ROWX);
+    static constexpr int NW = 7, NT = 64 * NW;                       // 7 waves: rows wave, wave + 7, ...
+    static constexpr int STRIP = TW * 128;                           // per-wave [TW pixels][64 ch] bf16
+    static constexpr int LDS = 64 * PLX + NW * STRIP;
+    static constexpr int XU = PH * NPX * 8;
+    static constexpr int NXU = (XU + NT - 1) / NT;
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__((DWF<TH, TW>::NT)) void dwconv7_dot2_kernel(const bf16_t* __restrict__ x,
+                                                                       const float* __restrict__ w49,
+                                                                       const float* __restrict__ bias,
+                                                                       const bf16_t* __restrict__ res,
+                                                                       bf16_t* __restrict__ y, int B, int H, int W, int C,
+                                                                       int flip) {
+    using G = DWF<TH, TW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;                                   // [64 planes][PH rows of ROWX bytes]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* strip = smem + 64 * G::PLX + wave * G::STRIP;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const long ntiles = (long)B * tiles_x * tiles_y;
+    const int c0 = blockIdx.y * 64;
+    const int cs = min(64, C - c0);
+    const int ncg = cs >> 3;
+    const int ch = (lane & 7) * 8 + (lane >> 3);                // channel held by plane `lane`
+    const bool ch_ok = ch < cs;
+
+    // taps of this lane's channel as bf16 pairs (w[2p], w[2p+1]), w[7] = 0; backward-data: the flipped kernel
+    unsigned wq[7][4];
+    float bv = 0.f;
+    {
+        float wf[49];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) wf[t] = ch_ok ? w49[(long)(flip ? 48 - t : t) * C + c0 + ch] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) wq[ky][p] = pack2bf(wf[ky * 7 + 2 * p], p < 3 ? wf[ky * 7 + 2 * p + 1] : 0.f);
+        if (bias && ch_ok) bv = bias[c0 + ch];
+    }
+    // the pad dwords behind every row are multiplied by the zero tap: they must hold finite values -> zero them once
+    for (int i = tid; i < 64 * G::PLX / 4; i += G::NT) reinterpret_cast<unsigned*>(xs)[i] = 0u;
+
+    uint4 rxa[G::NXU], rxb[G::NXU];
+    int xrow[G::NXU], xcol[G::NXU], xsrc[G::NXU], xdst[G::NXU];
+#pragma unroll
+    for (int j = 0; j < G::NXU; ++j) {
+        const int u = tid + j * G::NT;
+        const int cgi = u & 7, q = u >> 3;
+        const int pr = q % G::NPX, row = q / G::NPX;
+        const bool live = u < G::XU && cgi < ncg;
+        xrow[j] = live ? row - 3 : -(1 << 20);
+        xcol[j] = 2 * pr - 3;
+        xsrc[j] = ((row - 3) * W + 2 * pr - 3) * C + cgi * 8;
+        xdst[j] = cgi * G::PLX + row * G::ROWX + pr * 4;
+    }
+    auto fetch = [&](long t) {
+        long tt = t;
+        const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+        const int ty = (int)(tt % tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const long base = ((tt / tiles_y) * H * W + (long)y0 * W + x0) * C + c0;
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            const int yy = y0 + xrow[j], xa = x0 + xcol[j];
+            rxa[j] = make_uint4(0, 0, 0, 0);
+            rxb[j] = make_uint4(0, 0, 0, 0);
+            if ((unsigned)yy < (unsigned)H) {
+                const bf16_t* src = x + base + xsrc[j];
+                if ((unsigned)xa < (unsigned)W) rxa[j] = *reinterpret_cast<const uint4*>(src);
+                if ((unsigned)(xa + 1) < (unsigned)W) rxb[j] = *reinterpret_cast<const uint4*>(src + C);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            if (xrow[j] > -(1 << 19)) {
+                unsigned char* base = xs + xdst[j];
+                const unsigned wa[4] = {rxa[j].x, rxa[j].y, rxa[j].z, rxa[j].w};
+                const unsigned wb[4] = {rxb[j].x, rxb[j].y, rxb[j].z, rxb[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *reinterpret_cast<unsigned*>(base + (2 * i) * 8 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x05040100u);
+                    *reinterpret_cast<unsigned*>(base + (2 * i + 1) * 8 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x07060302u);
+                }
+            }
+        }
+    };
+
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                            // previous tile fully consumed (and the pad zeroing, first time)
+        commit();
+        __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+        long tt = t;
+        const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+        const int ty = (int)(tt % tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const long img = (tt / tiles_y) * H * W;
+#pragma unroll 1
+        for (int oy = wave; oy < TH; oy += G::NW) {
+            float acc[G::TWP];
+#pragma unroll
+            for (int o = 0; o < G::TWP; ++o) acc[o] = bv;
+            const unsigned char* xp = xs + lane * G::PLX + oy * G::ROWX;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                unsigned P[G::ROWX / 4], Q[G::NPX];
+#pragma unroll
+                for (int i = 0; i < G::ROWX / 16; ++i) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(xp + ky * G::ROWX + i * 16);
+                    P[4 * i] = v.x; P[4 * i + 1] = v.y; P[4 * i + 2] = v.z; P[4 * i + 3] = v.w;
+                }
+#pragma unroll
+                for (int j = 0; j < G::NPX; ++j) Q[j] = __builtin_amdgcn_alignbit(P[j + 1], P[j], 16);
+#pragma unroll
+                for (int o = 0; o < G::TWP; ++o)
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        acc[o] = dot2bf((o & 1) ? Q[(o >> 1) + p] : P[(o >> 1) + p], wq[ky][p], acc[o]);
+            }
+            // lane's channel, TW pixels -> strip[pixel][channel]; then 16-byte NHWC pieces (+ residual) out
+#pragma unroll
+            for (int o = 0; o < TW; ++o)
+                *reinterpret_cast<bf16_t*>(strip + o * 128 + ch * 2) = f2bf(acc[o]);
+            const int yy = y0 + oy;
+#pragma unroll
+            for (int it = 0; it < (TW * 8 + 63) / 64; ++it) {
+                const int i = lane + it * 64;
+                const int px = i >> 3, pc = i & 7;
+                if (i < TW * 8 && pc < ncg && yy < H && x0 + px < W) {
+                    uint4 v = *reinterpret_cast<const uint4*>(strip + px * 128 + pc * 16);
+                    const long off = (img + (long)yy * W + x0 + px) * C + c0 + pc * 8;
+                    if (res) {
+                        float a[8], r[8];
+                        unpack8(v, a);
+                        load8(res + off, r);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] += r[e];
+                        store8(y + off, a);
+                    } else {
+                        *reinterpret_cast<uint4*>(y + off) = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0) {
+            using G14 = DWF<14, 14>;
+            using G7 = DWF<7, 7>;
+            auto k14 = dwconv7_dot2_kernel<14, 14>;
+            auto k7 = dwconv7_dot2_kernel<7, 7>;
+            constexpr int lds14 = G14::LDS;
+            static const bool attr_ok =
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k14), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    lds14) == hipSuccess;
+            if (!attr_ok) {
+                ga_set_error("dwconv7: cannot reserve %d B of LDS", lds14);
+                return GA_ERR_HIP;
+            }
+            const int sl = cdiv(C, 64);
+            const bool big = H % 14 == 0 && W % 14 == 0;
+            const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
+            const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? 2 : 4) * num_cus() / sl));
+            if (big)
+                hipLaunchKernelGGL(k14, dim3(gx, sl), dim3(G14::NT), G14::LDS, s, (const bf16_t*)x, w49, bias,
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+            else
+                hipLaunchKernelGGL(k7, dim3(gx, sl), dim3(G7::NT), G7::LDS, s, (const bf16_t*)x, w49, bias,
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+            return ga_check_launch("ga_dwconv7");
+        }
+    }
     const int slices = cdiv(C, kCSF);
     if (H % 14 == 0 && W % 14 == 0) {
         constexpr int TH = 14, TW = 14, NT = 256;
