@@ -7,14 +7,20 @@
 
 namespace {
 
-constexpr int kMaxCh = 4;  // chunks (of 4 channels) per lane
+constexpr int kMaxCh = 4;  // 16-byte chunks (8 bf16 / 4 fp32 channels) per lane
 
-int pick_group(int C) {
-    const int nch = C / 4;
+int pick_group(int C, int epc) {
+    const int nch = C / epc;
     for (int g = 4; g <= 64; g <<= 1)
         if (kMaxCh * g >= nch) return g;
     return 0;
 }
+
+// one 16-byte chunk <-> floats
+__device__ __forceinline__ void ld_chunk(const float* p, float v[4]) { load4(p, v); }
+__device__ __forceinline__ void ld_chunk(const bf16_t* p, float v[8]) { load8(p, v); }
+__device__ __forceinline__ void st_chunk(float* p, const float v[4]) { store4(p, v); }
+__device__ __forceinline__ void st_chunk(bf16_t* p, const float v[8]) { store8(p, v); }
 
 int grid_blocks(long work_items, int per_block, int max_blocks = 2048) {
     return (int)std::max<long>(1, std::min<long>(max_blocks, (work_items + per_block - 1) / per_block));
@@ -23,25 +29,41 @@ int grid_blocks(long work_items, int per_block, int max_blocks = 2048) {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int G>
+template <typename T, int G, bool AFF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
                                                      int C, float eps) {
+    constexpr int E = elt<T>::EPC;            // channels per 16-byte chunk
     const int lg = threadIdx.x % G, rib = threadIdx.x / G, rpb = 256 / G;
-    const int nch = C >> 2;
+    const int nch = C / E;
     const float invC = 1.f / (float)C;
+    // the lane's chunks are the same for every row: affine parameters are read once
+    float wv[AFF ? kMaxCh : 1][E], bv[AFF ? kMaxCh : 1][E];
+    if constexpr (AFF) {
+#pragma unroll
+        for (int j = 0; j < kMaxCh; ++j) {
+            const int ci = lg + G * j;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                wv[j][e] = ci < nch ? w[ci * E + e] : 1.f;
+                bv[j][e] = ci < nch ? b[ci * E + e] : 0.f;
+            }
+        }
+    }
     for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
-        float v[kMaxCh][4];
+        float v[kMaxCh][E];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                load4(x + row * C + ci * 4, v[j]);
-                s += v[j][0] + v[j][1] + v[j][2] + v[j][3];
+                ld_chunk(x + row * C + ci * E, v[j]);
+#pragma unroll
+                for (int e = 0; e < E; ++e) s += v[j][e];
             } else {
-                v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+#pragma unroll
+                for (int e = 0; e < E; ++e) v[j][e] = 0.f;
             }
         }
         const float mu = group_sum<G>(s) * invC;
@@ -51,7 +73,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             const int ci = lg + G * j;
             if (ci < nch) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < E; ++e) {
                     const float dlt = v[j][e] - mu;
                     q += dlt * dlt;
                 }
@@ -66,13 +88,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                float o[4];
+                float o[E];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < E; ++e) {
                     o[e] = (v[j][e] - mu) * rs;
-                    if (w) o[e] = o[e] * w[ci * 4 + e] + b[ci * 4 + e];
+                    if constexpr (AFF) o[e] = fmaf(o[e], wv[j][e], bv[j][e]);
                 }
-                store4(y + row * C + ci * 4, o);
+                st_chunk(y + row * C + ci * E, o);
             }
         }
     }
@@ -83,45 +105,52 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 //   dx = rstd * (gw - mean_c(gw) - xhat * mean_c(gw * xhat)) + dres,   gw = g * w
 //   dw[c] += sum_rows g * xhat ;  db[c] += sum_rows g
 // ------------------------------------------------------------------------------------------------
-template <typename T, int G>
+template <typename T, int G, bool AFF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dw,
                                                      float* __restrict__ db, long rows, int C, int xnorm) {
+    constexpr int E = elt<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [2][rpb][C] when dw != null
     const int lg = threadIdx.x % G, rib = threadIdx.x / G, rpb = 256 / G;
-    const int nch = C >> 2;
+    const int nch = C / E;
     const float invC = 1.f / (float)C;
-    float aw[kMaxCh][4], ab[kMaxCh][4], wv[kMaxCh][4];
+    // AFF: affine weight and / or parameter gradients present (the block LayerNorms have neither: their affine part is
+    // folded into fc1) -- 96 fewer VGPRs without
+    float aw[AFF ? kMaxCh : 1][E], ab[AFF ? kMaxCh : 1][E], wv[AFF ? kMaxCh : 1][E];
+    if constexpr (AFF) {
 #pragma unroll
-    for (int j = 0; j < kMaxCh; ++j)
+        for (int j = 0; j < kMaxCh; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            aw[j][e] = ab[j][e] = 0.f;
-            const int ci = lg + G * j;
-            wv[j][e] = (w && ci < nch) ? w[ci * 4 + e] : 1.f;
-        }
+            for (int e = 0; e < E; ++e) {
+                aw[j][e] = ab[j][e] = 0.f;
+                const int ci = lg + G * j;
+                wv[j][e] = (w && ci < nch) ? w[ci * E + e] : 1.f;
+            }
+    }
     for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
         const float rs = rstd[row];
         const float mu = xnorm ? 0.f : mean[row];
         const float sc = xnorm ? 1.f : rs;
-        float gv[kMaxCh][4], xh[kMaxCh][4];
+        float gv[kMaxCh][E], xh[kMaxCh][E];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                load4(g + row * C + ci * 4, gv[j]);
-                load4(x + row * C + ci * 4, xh[j]);
+                ld_chunk(g + row * C + ci * E, gv[j]);
+                ld_chunk(x + row * C + ci * E, xh[j]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < E; ++e) {
                     xh[j][e] = (xh[j][e] - mu) * sc;
-                    aw[j][e] += gv[j][e] * xh[j][e];
-                    ab[j][e] += gv[j][e];
-                    gv[j][e] *= wv[j][e];
+                    if constexpr (AFF) {
+                        aw[j][e] = fmaf(gv[j][e], xh[j][e], aw[j][e]);
+                        ab[j][e] += gv[j][e];
+                        gv[j][e] *= wv[j][e];
+                    }
                     s1 += gv[j][e];
-                    s2 += gv[j][e] * xh[j][e];
+                    s2 = fmaf(gv[j][e], xh[j][e], s2);
                 }
             }
         }
@@ -131,16 +160,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                float o[4];
-                if (dres) load4(dres + row * C + ci * 4, o);
-                else o[0] = o[1] = o[2] = o[3] = 0.f;
+                float o[E];
+                if (dres) {
+                    ld_chunk(dres + row * C + ci * E, o);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += rs * (gv[j][e] - s1 - xh[j][e] * s2);
-                store4(dx + row * C + ci * 4, o);
+                    for (int e = 0; e < E; ++e) o[e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] += rs * (gv[j][e] - s1 - xh[j][e] * s2);
+                st_chunk(dx + row * C + ci * E, o);
             }
         }
     }
-    if (dw) {  // reduce the per-thread column partials over the rpb row slots of this workgroup
+    if (AFF && dw) {  // reduce the per-thread column partials over the rpb row slots of this workgroup
         float* rw = red;
         float* rb = red + rpb * C;
 #pragma unroll
@@ -148,9 +181,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
             const int ci = lg + G * j;
             if (ci < nch) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    rw[rib * C + ci * 4 + e] = aw[j][e];
-                    rb[rib * C + ci * 4 + e] = ab[j][e];
+                for (int e = 0; e < E; ++e) {
+                    rw[rib * C + ci * E + e] = aw[j][e];
+                    rb[rib * C + ci * E + e] = ab[j][e];
                 }
             }
         }
@@ -368,41 +401,47 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 }  // namespace
 
-#define LN_DISPATCH(G, KERNEL, ...)                                                              \
+#define LN_DISPATCH_(G, AFF, KERNEL, ...)                                                        \
     switch (G) {                                                                                 \
-        case 4: hipLaunchKernelGGL((KERNEL<T, 4>), __VA_ARGS__); break;                          \
-        case 8: hipLaunchKernelGGL((KERNEL<T, 8>), __VA_ARGS__); break;                          \
-        case 16: hipLaunchKernelGGL((KERNEL<T, 16>), __VA_ARGS__); break;                        \
-        case 32: hipLaunchKernelGGL((KERNEL<T, 32>), __VA_ARGS__); break;                        \
-        default: hipLaunchKernelGGL((KERNEL<T, 64>), __VA_ARGS__); break;                        \
+        case 4: hipLaunchKernelGGL((KERNEL<T, 4, AFF>), __VA_ARGS__); break;                     \
+        case 8: hipLaunchKernelGGL((KERNEL<T, 8, AFF>), __VA_ARGS__); break;                     \
+        case 16: hipLaunchKernelGGL((KERNEL<T, 16, AFF>), __VA_ARGS__); break;                   \
+        case 32: hipLaunchKernelGGL((KERNEL<T, 32, AFF>), __VA_ARGS__); break;                   \
+        default: hipLaunchKernelGGL((KERNEL<T, 64, AFF>), __VA_ARGS__); break;                   \
     }
+#define LN_DISPATCH(G, aff, KERNEL, ...)                 \
+    do {                                                 \
+        if (aff) { LN_DISPATCH_(G, true, KERNEL, __VA_ARGS__) } \
+        else { LN_DISPATCH_(G, false, KERNEL, __VA_ARGS__) }    \
+    } while (0)
 
 template <typename T>
 static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows,
                     int C, float eps, hipStream_t s) {
-    const int G = pick_group(C);
+    const int G = pick_group(C, elt<T>::EPC);
     const int rpb = 256 / G;
     dim3 grid(grid_blocks(rows, rpb, 4096)), block(256);
-    LN_DISPATCH(G, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
+    LN_DISPATCH(G, w != nullptr, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
     return ga_check_launch("ga_layernorm_fwd");
 }
 
 template <typename T>
 static int ln_bwd_t(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
                     const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int xnorm, hipStream_t s) {
-    const int G = pick_group(C);
+    const int G = pick_group(C, elt<T>::EPC);
     const int rpb = 256 / G;
     // persistent when parameter gradients are reduced (bounds the number of atomics)
     dim3 grid(grid_blocks(rows, rpb, dw ? 1024 : 4096)), block(256);
     const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
-    LN_DISPATCH(G, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
+    LN_DISPATCH(G, (w != nullptr || dw != nullptr), ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
                 dw, db, (long)rows, C, xnorm);
     return ga_check_launch("ga_layernorm_bwd");
 }
 
 extern "C" int ga_layernorm_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
                                 int64_t rows, int C, float eps, int dtype, ga_stream_t stream) {
-    GA_REQUIRE(x && y && rows > 0 && C > 0 && C % 4 == 0 && pick_group(C) > 0, "ga_layernorm_fwd: C=%d unsupported", C);
+    const int epc = dtype == GA_BF16 ? 8 : 4;   // whole 16-byte chunks
+    GA_REQUIRE(x && y && rows > 0 && C > 0 && C % epc == 0 && pick_group(C, epc) > 0, "ga_layernorm_fwd: C=%d unsupported", C);
     GA_REQUIRE((w == nullptr) == (b == nullptr), "ga_layernorm_fwd: w and b must both be given or both NULL");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == GA_BF16 ? ln_fwd_t<bf16_t>(x, w, b, y, mean, rstd, rows, C, eps, s)
@@ -412,7 +451,8 @@ extern "C" int ga_layernorm_fwd(const void* x, const float* w, const float* b, v
 extern "C" int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
                                 const void* dres, void* dx, float* dw, float* db, int64_t rows, int C,
                                 int x_is_normalized, int dtype, ga_stream_t stream) {
-    GA_REQUIRE(g && x && rstd && dx && rows > 0 && C % 4 == 0 && pick_group(C) > 0, "ga_layernorm_bwd: bad args");
+    const int epc = dtype == GA_BF16 ? 8 : 4;
+    GA_REQUIRE(g && x && rstd && dx && rows > 0 && C % epc == 0 && pick_group(C, epc) > 0, "ga_layernorm_bwd: bad args");
     GA_REQUIRE(x_is_normalized || mean, "ga_layernorm_bwd: mean required");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == GA_BF16 ? ln_bwd_t<bf16_t>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s)
