@@ -8,6 +8,7 @@
 //  * forward and backward-data are the same kernel (backward-data = flipped taps, + fused residual add);
 //  * backward-weight keeps the 49 x 64 partial sums of a channel slice in registers while a persistent
 //    workgroup walks over many tiles, so only nblocks x 49 x 64 fp32 atomics reach memory.
+#include <stdlib.h>
 #include <algorithm>
 #include "common.h"
 
@@ -701,6 +702,173 @@ __global__ __launch_bounds__((DWF<TH, TW>::NT)) void dwconv7_dot2_kernel(const b
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 forward / backward-data of 14 x 14 tiles on the MATRIX cores.  Per channel and tap row ky, the 1-D correlation
+// along x of 16 output rows at once is a small GEMM with a banded Toeplitz operand built from the 7 taps:
+//     D[ox][n] += sum_j T_ky[ox][j] * IN[n + ky][j],   T_ky[ox][j] = w[ky][j - ox] for 0 <= j - ox <= 6, else 0
+// i.e. one v_mfma_f32_16x16x32_bf16 (A = T_ky: 16 ox x 32 j, B = 16 input rows x 32 j of the channel plane) replaces
+// 14 x 14 x 7 multiply-adds.  Only 3136 of the instruction's 16384 MACs are useful, but the matrix pipe is 16x the
+// packed-VALU rate: 7 MFMAs (112 cycles) per channel tile instead of ~1600 VALU cycles in the dot2 form, and the kernel
+// lands on the HBM roofline instead of the VALU's.
+//   workgroup = 16 waves, 32-channel slice; wave w owns channel planes 2w, 2w+1 and keeps their 2 x 7 Toeplitz
+//   fragments in registers (56 VGPRs) across a persistent walk over tiles; same transposing staging as the dot2 kernels;
+//   results go through an LDS [pixel][32 ch] buffer back to 16-byte NHWC stores (+ residual for backward-data).
+// ------------------------------------------------------------------------------------------------
+struct DWM {
+    static constexpr int CS = 32, NCG = 4;                           // channels per slice, 8-channel groups
+    static constexpr int PH = 20, NPX = 10;                          // 20 x 20 input tile, 10 pixel pairs per row
+    static constexpr int ROWX = 48, PLX = 976;                       // as DWF<14, 14>
+    static constexpr int NT = 512, CPW = 4;                          // 8 waves, 4 channel planes per wave
+    static constexpr int OROW = 14 * 64 + 16;                        // out buffer: [14 rows][14 px x 64 B] + 16 B pad per row
+    static constexpr int OUT0 = CS * PLX;
+    static constexpr int LDS = OUT0 + 16 * OROW;                     // 16 rows so that the garbage rows 14, 15 stay inside
+    static constexpr int XU = PH * NPX * NCG;                        // 800 staging units
+    static constexpr int NXU = (XU + NT - 1) / NT;
+};
+
+__global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w49,
+                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ y, int B, int H, int W, int C, int flip) {
+    using G = DWM;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* xs = smem;
+    unsigned char* ob = smem + G::OUT0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = W / 14, tiles_y = H / 14;
+    const long ntiles = (long)B * tiles_x * tiles_y;
+    const int c0 = blockIdx.y * G::CS;
+    const int cs = min(G::CS, C - c0);
+    const int ncg = cs >> 3;
+
+    // Toeplitz fragments of this wave's four channels: lane holds T[ox = lane & 15][j = 8 * (lane >> 4) + i], i < 8
+    bf16x8_t tq[G::CPW][7];
+    float bv[G::CPW];
+    int chl[G::CPW];
+#pragma unroll
+    for (int q = 0; q < G::CPW; ++q) {
+        const int p = G::CPW * wave + q;               // plane; channel = (p % 4) * 8 + p / 4
+        chl[q] = (p & 3) * 8 + (p >> 2);
+        const bool ok = chl[q] < cs;
+        const int ox = lane & 15, j0 = 8 * (lane >> 4);
+#pragma unroll
+        for (int ky = 0; ky < 7; ++ky) {
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int dd = j0 + i - ox;
+                const int tap = ky * 7 + dd;
+                t[i] = (ok && ox < 14 && dd >= 0 && dd <= 6) ? w49[(long)(flip ? 48 - tap : tap) * C + c0 + chl[q]] : 0.f;
+            }
+            unsigned u[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) u[i] = pack2bf(t[2 * i], t[2 * i + 1]);
+            tq[q][ky] = *reinterpret_cast<const bf16x8_t*>(u);
+            __builtin_amdgcn_sched_barrier(0);     // one fragment's loads at a time (224 hoisted loads spill)
+        }
+        bv[q] = (bias && ok) ? bias[c0 + chl[q]] : 0.f;
+    }
+    // every LDS byte a fragment read can touch must be finite (it meets a zero of T): zero the whole allocation once
+    for (int i = tid; i < G::LDS / 4; i += G::NT) reinterpret_cast<unsigned*>(smem)[i] = 0u;
+
+    // staging units of this thread (tile-invariant): (row, pixel pair, 8-channel group)
+    uint4 rxa[G::NXU], rxb[G::NXU];
+    int xrow[G::NXU], xcol[G::NXU], xsrc[G::NXU], xdst[G::NXU];
+#pragma unroll
+    for (int j = 0; j < G::NXU; ++j) {
+        const int u = tid + j * G::NT;
+        const int cgi = u & 3, q = u >> 2;
+        const int pr = q % G::NPX, row = q / G::NPX;
+        const bool live = u < G::XU && cgi < ncg;
+        xrow[j] = live ? row - 3 : -(1 << 20);
+        xcol[j] = 2 * pr - 3;
+        xsrc[j] = ((row - 3) * W + 2 * pr - 3) * C + cgi * 8;
+        xdst[j] = cgi * G::PLX + row * G::ROWX + pr * 4;
+    }
+    auto fetch = [&](long t) {
+        long tt = t;
+        const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+        const int ty = (int)(tt % tiles_y);
+        const int y0 = ty * 14, x0 = tx * 14;
+        const long base = ((tt / tiles_y) * H * W + (long)y0 * W + x0) * C + c0;
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            const int yy = y0 + xrow[j], xa = x0 + xcol[j];
+            rxa[j] = make_uint4(0, 0, 0, 0);
+            rxb[j] = make_uint4(0, 0, 0, 0);
+            if ((unsigned)yy < (unsigned)H) {
+                const bf16_t* src = x + base + xsrc[j];
+                if ((unsigned)xa < (unsigned)W) rxa[j] = *reinterpret_cast<const uint4*>(src);
+                if ((unsigned)(xa + 1) < (unsigned)W) rxb[j] = *reinterpret_cast<const uint4*>(src + C);
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < G::NXU; ++j) {
+            if (xrow[j] > -(1 << 19)) {
+                unsigned char* base = xs + xdst[j];
+                const unsigned wa[4] = {rxa[j].x, rxa[j].y, rxa[j].z, rxa[j].w};
+                const unsigned wb[4] = {rxb[j].x, rxb[j].y, rxb[j].z, rxb[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {   // channel k = 2i / 2i+1 of the group -> plane k * 4 + cgi
+                    *reinterpret_cast<unsigned*>(base + (2 * i) * 4 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x05040100u);
+                    *reinterpret_cast<unsigned*>(base + (2 * i + 1) * 4 * G::PLX) = __builtin_amdgcn_perm(wb[i], wa[i], 0x07060302u);
+                }
+            }
+        }
+    };
+
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        __syncthreads();                            // planes and out buffer of the previous tile fully consumed
+        commit();
+        __syncthreads();
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+#pragma unroll
+        for (int q = 0; q < G::CPW; ++q) {
+            f32x4_t acc = {bv[q], bv[q], bv[q], bv[q]};
+            const unsigned char* bp = xs + (G::CPW * wave + q) * G::PLX + (lane & 15) * G::ROWX + (lane >> 4) * 16;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const uint4 bfrag = *reinterpret_cast<const uint4*>(bp + ky * G::ROWX);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tq[q][ky], *reinterpret_cast<const bf16x8_t*>(&bfrag), acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one channel's 7 fragment reads in flight at a time (28 VGPRs)
+            // D[ox = 4 * (lane >> 4) + r][n = lane & 15] -> out[n][ox][channel]
+            const int n = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = 4 * (lane >> 4) + r;
+                if (ox < 14) *reinterpret_cast<bf16_t*>(ob + n * G::OROW + ox * 64 + chl[q] * 2) = f2bf(acc[r]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (14 * 14 * 4 + G::NT - 1) / G::NT; ++it) {   // 16-byte NHWC pieces: (row, pixel, 8-channel group)
+            const int id = tid + it * G::NT;
+            const int pc = id & 3, px = (id >> 2) % 14, rw = (id >> 2) / 14;
+            if (id < 14 * 14 * 4 && pc < ncg) {
+                long tt = t;
+                const int tx = (int)(tt % tiles_x); tt /= tiles_x;
+                const int ty = (int)(tt % tiles_y);
+                const long off = ((tt / tiles_y) * H * W + (long)(ty * 14 + rw) * W + tx * 14 + px) * C + c0 + pc * 8;
+                uint4 v = *reinterpret_cast<const uint4*>(ob + rw * G::OROW + px * 64 + pc * 16);
+                if (res) {
+                    float a[8], rr[8];
+                    unpack8(v, a);
+                    load8(res + off, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] += rr[e];
+                    store8(y + off, a);
+                } else {
+                    *reinterpret_cast<uint4*>(y + off) = v;
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s) {
@@ -722,7 +890,17 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             const bool big = H % 14 == 0 && W % 14 == 0;
             const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
             const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? 2 : 4) * num_cus() / sl));
-            if (big)
+            const char* e = getenv("GAEXT_DW_MFMA");        // 0: never, 1: heuristic (default), 2: every 14 x 14-tiled launch
+            const int use_mfma = e ? atoi(e) : 1;           // read per call so that a test can switch it
+            // the MFMA form pays a long prologue (Toeplitz fragments) per workgroup: ahead of the dot2 form only when
+            // a workgroup walks many tiles (56 x 56 maps: 0.169 vs 0.192 ms; 28 x 28 and 14 x 14: 5-10 % behind)
+            const bool many = ntiles * cdiv(C, DWM::CS) >= 32L * num_cus();
+            if (big && (use_mfma == 2 || (use_mfma == 1 && many))) {
+                const int slm = cdiv(C, DWM::CS);
+                const int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));
+                hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(gxm, slm), dim3(DWM::NT), DWM::LDS, s, (const bf16_t*)x, w49, bias,
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+            } else if (big)
                 hipLaunchKernelGGL(k14, dim3(gx, sl), dim3(G14::NT), G14::LDS, s, (const bf16_t*)x, w49, bias,
                                    (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
             else

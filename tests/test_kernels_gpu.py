@@ -377,9 +377,13 @@ def test_weight_prep_fold_unfold(dt):
 # depthwise 7x7
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dt', DT)
-@pytest.mark.parametrize('geom', [(2, 14, 14, 96), (1, 28, 28, 72), (3, 7, 7, 128), (2, 10, 9, 16), (1, 56, 56, 32)])
-def test_dwconv7(dt, geom):
+@pytest.mark.parametrize('geom', [(2, 14, 14, 96), (1, 28, 28, 72), (3, 7, 7, 128), (2, 10, 9, 16), (1, 56, 56, 32),
+                                  (2, 28, 28, 40, 'mfma')])
+def test_dwconv7(dt, geom, monkeypatch):
     ops = _imp()
+    if len(geom) == 5:     # force the matrix-core (Toeplitz) form of the bf16 forward / backward-data kernel
+        monkeypatch.setenv('GAEXT_DW_MFMA', '2')
+        geom = geom[:4]
     Bn, H, W, Cc = geom
     g = gen(11)
     x, X = rnd((Bn, H, W, Cc), dt, g)
