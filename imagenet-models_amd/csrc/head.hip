@@ -270,68 +270,78 @@ __device__ __forceinline__ void tri_ij(int t, int C, int& i, int& j) {
     j = i + t - (int)((long)i * C - (long)i * (i - 1) / 2);
 }
 
+// One workgroup of 1024 threads per sample, a wave per matrix row (coalesced reads of the upper-triangular part, no
+// index inversion: the packed position of (i, j) is rowstart(i) + j - i and the lane steps through it).
 template <typename T>
-__global__ __launch_bounds__(256) void gram_pack_kernel(const float* __restrict__ G, T* __restrict__ out,
-                                                        float* __restrict__ inv_norm, int C, int groups, int Kg,
-                                                        int Kp) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void gram_pack_kernel(const float* __restrict__ G, T* __restrict__ out,
+                                                         float* __restrict__ inv_norm, int C, int groups, int Kg,
+                                                         int Kp) {
+    __shared__ float red[16];
     const long b = blockIdx.x;
-    const int ntri = C * (C + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float* Gb = G + b * C * C;
     float ss = 0.f;
-    for (int t = threadIdx.x; t < ntri; t += 256) {
-        int i, j;
-        tri_ij(t, C, i, j);
-        const float v = Gb[i * C + j];
-        ss += v * v;
-    }
+    for (int i = wave; i < C; i += 16)
+        for (int j = i + lane; j < C; j += 64) {
+            const float v = Gb[i * C + j];
+            ss = fmaf(v, v, ss);
+        }
     ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    if (lane == 0) red[wave] = ss;
     __syncthreads();
-    const float nrm = sqrtf(red[0] + red[1] + red[2] + red[3]);
-    const float inv = 1.f / fmaxf(nrm, 1e-12f);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
     if (threadIdx.x == 0) inv_norm[b] = inv;
     T* ob = out + b * groups * Kp;
-    for (int t = threadIdx.x; t < groups * Kp; t += 256) {
-        const int g = t / Kp, k = t - g * Kp;
-        float v = 0.f;
-        if (k < Kg) {
-            int i, j;
-            tri_ij(g * Kg + k, C, i, j);
-            v = Gb[i * C + j] * inv;
+    for (int i = wave; i < C; i += 16) {
+        const unsigned t0 = (unsigned)(i * C - i * (i - 1) / 2);        // packed index of (i, i)
+        unsigned t = t0 + lane;
+        unsigned g = t / (unsigned)Kg, k = t - g * (unsigned)Kg;
+        for (int j = i + lane; j < C; j += 64) {
+            if (g < (unsigned)groups) elt<T>::st(ob + g * Kp + k, Gb[i * C + j] * inv);
+            k += 64;
+            while (k >= (unsigned)Kg) { k -= Kg; ++g; }
         }
-        elt<T>::st(ob + t, v);
+    }
+    const int pad = Kp - Kg;                                             // zero padding behind every group
+    for (int t = threadIdx.x; t < groups * pad; t += 1024) {
+        const int g = t / pad;
+        elt<T>::st(ob + g * Kp + Kg + (t - g * pad), 0.f);
     }
 }
 
 // backward of normalise + pack: S[b][i][j] (T, symmetric; diagonal doubled) = d(raw gram entry)
 //   draw = inv * (dvec - vhat * <vhat, dvec>)
 template <typename T>
-__global__ __launch_bounds__(256) void gram_pack_bwd_kernel(const T* __restrict__ dvec, const T* __restrict__ vhat,
-                                                            const float* __restrict__ inv_norm, T* __restrict__ S,
-                                                            int C, int groups, int Kg, int Kp) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void gram_pack_bwd_kernel(const T* __restrict__ dvec, const T* __restrict__ vhat,
+                                                             const float* __restrict__ inv_norm, T* __restrict__ S,
+                                                             int C, int groups, int Kg, int Kp) {
+    __shared__ float red[16];
     const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const T* db = dvec + b * groups * Kp;
     const T* vb = vhat + b * groups * Kp;
     float dot = 0.f;
-    for (int t = threadIdx.x; t < groups * Kp; t += 256) {
-        const int k = t % Kp;
-        if (k < Kg) dot += elt<T>::ld(db + t) * elt<T>::ld(vb + t);
-    }
+    for (int g = 0; g < groups; ++g)
+        for (int k = threadIdx.x; k < Kg; k += 1024) dot = fmaf(elt<T>::ld(db + g * Kp + k), elt<T>::ld(vb + g * Kp + k), dot);
     dot = wave_sum(dot);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dot;
+    if (lane == 0) red[wave] = dot;
     __syncthreads();
-    dot = red[0] + red[1] + red[2] + red[3];
+    dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) dot += red[w];
     const float inv = inv_norm[b];
     T* Sb = S + b * C * C;
-    for (int e = threadIdx.x; e < C * C; e += 256) {
-        const int i = e / C, j = e - i * C;
-        const int lo = min(i, j), hi = max(i, j);
-        const int t = (int)((long)lo * C - (long)lo * (lo - 1) / 2) + (hi - lo);
-        const int g = t / Kg, k = t - g * Kg;
-        const float draw = inv * (elt<T>::ld(db + g * Kp + k) - elt<T>::ld(vb + g * Kp + k) * dot);
-        elt<T>::st(Sb + e, i == j ? 2.f * draw : draw);
+    for (int i = wave; i < C; i += 16) {                 // output row i: entries (i, j) read packed (min, max)
+        for (int j = lane; j < C; j += 64) {
+            const int lo = min(i, j), hi = max(i, j);
+            const unsigned t = (unsigned)(lo * C - lo * (lo - 1) / 2 + (hi - lo));
+            const unsigned g = t / (unsigned)Kg, k = t - g * (unsigned)Kg;
+            const float draw = g < (unsigned)groups ? inv * (elt<T>::ld(db + g * Kp + k) - elt<T>::ld(vb + g * Kp + k) * dot) : 0.f;
+            elt<T>::st(Sb + i * C + j, i == j ? 2.f * draw : draw);
+        }
     }
 }
 
@@ -722,7 +732,7 @@ extern "C" int ga_gram_pack_fwd(const float* G, void* out, float* inv_norm, int 
     const int ntri = C * (C + 1) / 2;
     GA_REQUIRE(G && out && inv_norm && ntri % groups == 0 && Kp >= ntri / groups, "ga_gram_pack_fwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(256), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp);
+    DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(1024), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp);
     return ga_check_launch("ga_gram_pack_fwd");
 }
 
@@ -731,7 +741,7 @@ extern "C" int ga_gram_pack_bwd(const void* dvec, const void* vhat, const float*
     const int ntri = C * (C + 1) / 2;
     GA_REQUIRE(dvec && vhat && inv_norm && S && ntri % groups == 0, "ga_gram_pack_bwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(256), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
+    DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(1024), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
                groups, ntri / groups, Kp);
     return ga_check_launch("ga_gram_pack_bwd");
 }
