@@ -239,3 +239,74 @@ def test_no_cpu_fallback():
     m = A.create_model('ga_convnext_tiny_768')
     with pytest.raises(RuntimeError, match='no CPU'):
         m(torch.zeros(1, 3, 224, 224))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# full-size cases: BASELINE.json configs[1] (ga_convnext_tiny_768 at batch 256, 3x224x224) -- the shapes the large-M
+# kernel forms (256-row GEMM tiles, LDS-DMA GEMM / wgrad, matrix-core and dot2 depthwise kernels) only see here
+# ----------------------------------------------------------------------------------------------------------------------
+def _full_model(mode):
+    import imagenet_models_amd as A
+    O = _oracle()
+    cfg = O.make_cfg('ga_convnext_tiny_768')
+    m = A.create_model('ga_convnext_tiny_768', math_mode=mode)
+    sd = O.fill_state(cfg)
+    m.load_state_dict(sd)
+    return m.cuda(), sd, cfg
+
+
+def _full_step(m, x, target, lam=-0.8):
+    import imagenet_models_amd as A
+    m.train()
+    m.zero_grad()
+    outs = m(x.cuda())
+    loss = A.ga_loss(outs, target.cuda(), lam)
+    loss.backward()
+    return [o.detach().float().cpu() for o in outs], float(loss), {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+
+
+def test_t768_full_batch_train_step_fp32_vs_oracle():
+    """fp32 math mode at the benchmark's batch 256 against the CPU oracle (fp32 Gram branch of the reference, B >= 128):
+    logits / loss 1e-3, gradients 3e-2 under oracle.grad_errors"""
+    O = _oracle()
+    m, sd, cfg = _full_model('fp32')
+    B = 256
+    x = O.gen_input(B, seed=3)
+    target = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(3))
+    outs, loss, grads = _full_step(m, x, target)
+    del m
+    torch.cuda.empty_cache()
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    oloss, oouts, ograds, _ = O.train_step_grads(sd, x, target, cfg, lam=-0.8)
+    e_out = max(rel(a, b) for a, b in zip(outs, oouts))
+    e_loss = abs(loss - float(oloss)) / abs(float(oloss))
+    errs = O.grad_errors(grads, ograds)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f'[fp32 B=256 tiny_768] logits {e_out:.2e} loss {e_loss:.2e} worst grads {worst}')
+    assert e_out < 1e-3 and e_loss < 1e-3
+    assert worst[0][1] < 3e-2, worst
+
+
+def test_t768_full_batch_bf16_close_to_fp32_mode():
+    """the bf16 throughput mode (every large-M kernel form) against this library's own fp32 parity mode at batch 256:
+    logits 6e-2, loss 2e-2, gradients 0.35 (the tolerances of the small bf16 test)"""
+    O = _oracle()
+    B = 256
+    x = O.gen_input(B, seed=4)
+    target = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4))
+    m, _, _ = _full_model('fp32')
+    outs32, loss32, g32 = _full_step(m, x, target)
+    del m
+    torch.cuda.empty_cache()
+    m, _, _ = _full_model('bf16')
+    outs16, loss16, g16 = _full_step(m, x, target)
+    e_out = max(rel(a, b) for a, b in zip(outs16, outs32))
+    e_loss = abs(loss16 - loss32) / abs(loss32)
+    errs = O.grad_errors(g16, g32)
+    gmax = max(float(g.abs().max()) for g in g32.values())
+    errs = {n: e for n, e in errs.items() if float(g32[n].abs().max()) >= 1e-4 * gmax}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    print(f'[bf16 vs fp32 mode, B=256 tiny_768] logits {e_out:.2e} loss {e_loss:.2e} worst grads {worst}')
+    assert all(torch.isfinite(g).all() for g in g16.values())
+    assert e_out < 6e-2 and e_loss < 2e-2
+    assert worst[0][1] < 0.35, worst
