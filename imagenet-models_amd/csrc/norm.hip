@@ -7,12 +7,12 @@
 
 namespace {
 
-constexpr int kMaxCh = 4;  // 16-byte chunks (8 bf16 / 4 fp32 channels) per lane
+constexpr int kMaxChunks = 4;  // 16-byte chunks (8 bf16 / 4 fp32 channels) per lane, at most
 
 int pick_group(int C, int epc) {
     const int nch = C / epc;
     for (int g = 4; g <= 64; g <<= 1)
-        if (kMaxCh * g >= nch) return g;
+        if (kMaxChunks * g >= nch) return g;
     return 0;
 }
 
@@ -29,7 +29,7 @@ int grid_blocks(long work_items, int per_block, int max_blocks = 2048) {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int G, bool AFF>
+template <typename T, int G, bool AFF, int kMaxCh>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, long rows,
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 //   dx = rstd * (gw - mean_c(gw) - xhat * mean_c(gw * xhat)) + dres,   gw = g * w
 //   dw[c] += sum_rows g * xhat ;  db[c] += sum_rows g
 // ------------------------------------------------------------------------------------------------
-template <typename T, int G, bool AFF>
+template <typename T, int G, bool AFF, int kMaxCh>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const T* __restrict__ dres,
@@ -401,18 +401,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 }  // namespace
 
-#define LN_DISPATCH_(G, AFF, KERNEL, ...)                                                        \
+// chunks per lane: 3 for the C = 96 * 2^k of this model family (12 / 24 / 48 / 96 chunks over 4 / 8 / 16 / 32 lanes), else 4
+#define LN_DISPATCH__(G, AFF, NCH, KERNEL, ...)                                                  \
     switch (G) {                                                                                 \
-        case 4: hipLaunchKernelGGL((KERNEL<T, 4, AFF>), __VA_ARGS__); break;                     \
-        case 8: hipLaunchKernelGGL((KERNEL<T, 8, AFF>), __VA_ARGS__); break;                     \
-        case 16: hipLaunchKernelGGL((KERNEL<T, 16, AFF>), __VA_ARGS__); break;                   \
-        case 32: hipLaunchKernelGGL((KERNEL<T, 32, AFF>), __VA_ARGS__); break;                   \
-        default: hipLaunchKernelGGL((KERNEL<T, 64, AFF>), __VA_ARGS__); break;                   \
+        case 4: hipLaunchKernelGGL((KERNEL<T, 4, AFF, NCH>), __VA_ARGS__); break;                \
+        case 8: hipLaunchKernelGGL((KERNEL<T, 8, AFF, NCH>), __VA_ARGS__); break;                \
+        case 16: hipLaunchKernelGGL((KERNEL<T, 16, AFF, NCH>), __VA_ARGS__); break;              \
+        case 32: hipLaunchKernelGGL((KERNEL<T, 32, AFF, NCH>), __VA_ARGS__); break;              \
+        default: hipLaunchKernelGGL((KERNEL<T, 64, AFF, NCH>), __VA_ARGS__); break;              \
     }
-#define LN_DISPATCH(G, aff, KERNEL, ...)                 \
-    do {                                                 \
-        if (aff) { LN_DISPATCH_(G, true, KERNEL, __VA_ARGS__) } \
-        else { LN_DISPATCH_(G, false, KERNEL, __VA_ARGS__) }    \
+#define LN_DISPATCH_(G, AFF, nch3, KERNEL, ...)                    \
+    do {                                                           \
+        if (nch3) { LN_DISPATCH__(G, AFF, 3, KERNEL, __VA_ARGS__) } \
+        else { LN_DISPATCH__(G, AFF, 4, KERNEL, __VA_ARGS__) }      \
+    } while (0)
+#define LN_DISPATCH(G, aff, nch3, KERNEL, ...)                            \
+    do {                                                                  \
+        if (aff) LN_DISPATCH_(G, true, nch3, KERNEL, __VA_ARGS__);        \
+        else LN_DISPATCH_(G, false, nch3, KERNEL, __VA_ARGS__);           \
     } while (0)
 
 template <typename T>
@@ -421,7 +427,8 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
     const int G = pick_group(C, elt<T>::EPC);
     const int rpb = 256 / G;
     dim3 grid(grid_blocks(rows, rpb, 4096)), block(256);
-    LN_DISPATCH(G, w != nullptr, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
+    const bool nch3 = C / elt<T>::EPC <= 3 * G;
+    LN_DISPATCH(G, w != nullptr, nch3, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
     return ga_check_launch("ga_layernorm_fwd");
 }
 
@@ -433,7 +440,8 @@ static int ln_bwd_t(const void* g, const void* x, const float* mean, const float
     // persistent when parameter gradients are reduced (bounds the number of atomics)
     dim3 grid(grid_blocks(rows, rpb, dw ? 1024 : 4096)), block(256);
     const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
-    LN_DISPATCH(G, (w != nullptr || dw != nullptr), ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
+    const bool nch3 = C / elt<T>::EPC <= 3 * G;
+    LN_DISPATCH(G, (w != nullptr || dw != nullptr), nch3, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
                 dw, db, (long)rows, C, xnorm);
     return ga_check_launch("ga_layernorm_bwd");
 }
