@@ -200,3 +200,53 @@ extern "C" int ga_adamw_step(float* p, const float* g, float* m, float* v, const
                        (long)n, wd_mult);
     return ga_check_launch("ga_adamw_step");
 }
+
+// ------------------------------------------------------------------------------------------------
+// gradient clipping on the flat gradient buffer (timm dispatch_clip_grad, GA/train.py:325: 'norm' and 'value')
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = x[n4 * 4 + threadIdx.x];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+// g *= min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* __restrict__ g, long n, const float* __restrict__ sumsq,
+                                                         float max_norm) {
+    const float coef = fminf(1.f, max_norm / (sqrtf(*sumsq) + 1e-6f));
+    if (coef >= 1.f) return;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] *= coef;
+}
+__global__ __launch_bounds__(256) void clip_value_kernel(float* __restrict__ g, long n, float v) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] = fminf(fmaxf(g[i], -v), v);
+}
+}  // namespace
+
+extern "C" int ga_sumsq_f32(const float* x, int64_t n, float* out, ga_stream_t stream) {
+    GA_REQUIRE(x && out && n > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "ga_sumsq_f32: bad args (x 16-byte aligned)");
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n / 4 + 255) / 256));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, (long)n, out);
+    return ga_check_launch("ga_sumsq_f32");
+}
+
+extern "C" int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float limit, int mode, ga_stream_t stream) {
+    GA_REQUIRE(g && n > 0 && limit > 0.f && (mode == 0 ? sumsq != nullptr : mode == 1), "ga_clip_grad_f32: bad args");
+    const int blocks = (int)std::max<long>(1, std::min<long>(4096, (n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (mode == 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, s, g, (long)n, sumsq, limit);
+    else hipLaunchKernelGGL(clip_value_kernel, dim3(blocks), dim3(256), 0, s, g, (long)n, limit);
+    return ga_check_launch("ga_clip_grad_f32");
+}
+

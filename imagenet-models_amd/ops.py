@@ -310,6 +310,12 @@ class Plan:
             return
         self._add('ga_axpy_f32', (_ptr(y), _ptr(x), a, n), label, keep=(y, x))
 
+    def sumsq_f32(self, x, n, out, label=None):
+        self._add('ga_sumsq_f32', (_ptr(x), n, _ptr(out)), label, keep=(x, out))
+
+    def clip_grad_f32(self, g, n, sumsq, limit, mode, label=None):
+        self._add('ga_clip_grad_f32', (_ptr(g), n, _ptr(sumsq), float(limit), int(mode)), label, keep=(g, sumsq))
+
     def rowscale(self, x, s, y, n, elems_per_scale, dtype, label=None):
         self._add('ga_rowscale', (_ptr(x), _ptr(s), _ptr(y), n, elems_per_scale, dtype), label, keep=(x, s, y))
 

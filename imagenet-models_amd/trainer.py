@@ -11,7 +11,7 @@ _KINDS = {'ce': 0, 'bce': 1}
 
 class TrainStep:
     def __init__(self, model, optimizer, batch, lam=0.0, loss='ce', smoothing=0.0, grad_accumulation=1,
-                 process_group=None):
+                 process_group=None, clip_grad=None, clip_mode='norm'):
         self.model, self.opt = model, optimizer
         self.eng = model.engine(batch, True)
         self.lam, self.kind, self.smoothing = lam, _KINDS[loss], smoothing
@@ -22,6 +22,23 @@ class TrainStep:
         st = model.flat_state()
         self.flat_g = st['grads']
         self.buckets = self._make_buckets(st) if self.world > 1 else []
+        # gradient clipping (timm dispatch_clip_grad through NativeScaler, GA/train.py:312-333): global L2 norm or
+        # value clamp over the flat gradient buffer, after the all-reduce, before the optimizer
+        if clip_mode not in ('norm', 'value'):
+            raise NotImplementedError(f"clip_mode {clip_mode!r}: only 'norm' and 'value' are built ('agc' is not)")
+        self.clip_plan = None
+        if clip_grad is not None:
+            from . import ops
+            self.gnorm_sq = torch.zeros(1, device=self.flat_g.device)
+            p = ops.Plan(name='clip')
+            n = self.flat_g.numel()
+            if clip_mode == 'norm':
+                p.zero(self.gnorm_sq)
+                p.sumsq_f32(self.flat_g, n, self.gnorm_sq)
+                p.clip_grad_f32(self.flat_g, n, self.gnorm_sq, clip_grad, 0)
+            else:
+                p.clip_grad_f32(self.flat_g, n, self.gnorm_sq, clip_grad, 1)
+            self.clip_plan = p
 
     def _make_buckets(self, st):
         """[(plan mark, start, end)] -- contiguous slices of the flat gradient buffer in backward-completion order"""
@@ -67,6 +84,8 @@ class TrainStep:
             bwd.run()
         self.micro += 1
         if last_micro:
+            if self.clip_plan is not None:
+                self.clip_plan.run()
             self.opt.step()
             self.opt.zero_grad()
         return loss

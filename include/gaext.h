@@ -295,6 +295,12 @@ int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_stream_t strea
 int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream);
 int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t stream);
 
+/* gradient clipping on the flat fp32 gradient buffer (timm dispatch_clip_grad via NativeScaler, GA/train.py:312-333):
+ *   ga_sumsq_f32: *out += sum x^2 (caller zeroes *out; under DDP call after the all-reduce);
+ *   ga_clip_grad_f32 mode 0 ('norm'): g *= min(1, limit / (sqrt(*sumsq) + 1e-6));  mode 1 ('value'): clamp to [-limit, limit] */
+int ga_sumsq_f32(const float* x, int64_t n, float* out, ga_stream_t stream);
+int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float limit, int mode, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */

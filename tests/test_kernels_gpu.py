@@ -708,3 +708,27 @@ def test_error_path_is_loud():
         ops.Plan(eager=True).gemm(A, B, Cc, 8, 8, 10, ops.GA_F32, lda=12, ldb=12)
     with pytest.raises(AssertionError):
         ops.Plan(eager=True).gemm(A.cpu(), B, Cc, 8, 8, 12, ops.GA_F32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# gradient clipping on the flat gradient buffer (timm dispatch_clip_grad: 'norm', 'value')
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('n', [1000003, 4096, 7])
+def test_clip_grad_flat(n):
+    ops = _imp()
+    g = gen(23)
+    base = torch.randn(n + 4, generator=g)[:n].contiguous()
+    for limit in (0.5 * float(base.norm()), 10.0 * float(base.norm())):       # clips / leaves untouched
+        G = base.clone().cuda()
+        ss = torch.zeros(1, device='cuda')
+        P = ops.Plan(eager=True)
+        P.sumsq_f32(G, n, ss)
+        assert abs(float(ss) - float((base.double() ** 2).sum())) <= 1e-5 * float((base.double() ** 2).sum())
+        P.clip_grad_f32(G, n, ss, limit, 0)
+        ref = base.clone().requires_grad_(True)
+        ref.grad = base.clone()
+        torch.nn.utils.clip_grad_norm_([ref], limit)
+        assert_close(G, ref.grad, 1e-4, 'clip norm')   # fp32 sum of 1e6 squares: ~1e-5 relative
+    G = base.clone().cuda()
+    ops.Plan(eager=True).clip_grad_f32(G, n, G, 0.3, 1)
+    assert torch.equal(G.cpu(), base.clamp(-0.3, 0.3))

@@ -46,6 +46,8 @@ parser.add_argument('--bce-loss', action='store_true')
 parser.add_argument('--drop-path', type=float, default=None)
 parser.add_argument('--grad-accumulation', type=int, default=1)
 parser.add_argument('--GA_lam', type=float, default=0)
+parser.add_argument('--clip-grad', type=float, default=None, help='clip gradients (GA/train.py --clip-grad)')
+parser.add_argument('--clip-mode', default='norm', help='"norm" or "value" ("agc" is not built)')
 parser.add_argument('--amp', action='store_true', help='bf16 math mode (default)')
 parser.add_argument('--fp32', action='store_true', help='fp32 parity math mode')
 parser.add_argument('--channels-last', action='store_true', help='accepted for CLI compatibility (activations are always NHWC)')
@@ -157,7 +159,8 @@ def main():
     sched = A.CosineLRScheduler(opt, t_initial=args.epochs, lr_min=args.min_lr, warmup_t=args.warmup_epochs,
                                 warmup_lr_init=args.warmup_lr) if args.sched == 'cosine' else None
     step_fn = A.TrainStep(model, opt, args.batch_size, lam=args.GA_lam, loss='bce' if args.bce_loss else 'ce',
-                          smoothing=args.smoothing, grad_accumulation=args.grad_accumulation)
+                          smoothing=args.smoothing, grad_accumulation=args.grad_accumulation,
+                          clip_grad=args.clip_grad, clip_mode=args.clip_mode)
     loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda')
     eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda')
     model.train()
