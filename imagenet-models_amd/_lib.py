@@ -106,6 +106,8 @@ _SIGS = {
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),
     'ga_sumsq_f32': ([vp, i64, vp, vp], i32),
+    'ga_lamb_stage1': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp], i32),
+    'ga_lamb_stage2': ([vp, vp, vp, vp, i32, vp, vp], i32),
     'ga_clip_grad_f32': ([vp, i64, vp, f32, i32, vp], i32),
     'ga_rowscale': ([vp, vp, vp, i64, i64, i32, vp], i32),
     'ga_cast_from_f32': ([vp, vp, i64, i32, vp], i32),

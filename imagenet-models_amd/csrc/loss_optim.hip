@@ -250,3 +250,80 @@ extern "C" int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float l
     return ga_check_launch("ga_clip_grad_f32");
 }
 
+// ------------------------------------------------------------------------------------------------
+// LAMB on the flat buffers (timm.optim.Lamb as used by the published GA recipes, GA/README.md:26 `--opt lamb`):
+// per-TENSOR trust ratios need per-tensor norms, so the flat buffer is walked in chunks that never straddle a tensor
+// (device table {offset, length, tensor id, weight-decay flag}); stage 1 updates the moments, writes the update
+// direction and accumulates sum p^2 / sum u^2 per tensor, stage 2 applies p -= lr * trust * u.
+//   hp (device): [lr, wd, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, beta3, max_grad_norm]
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void lamb_stage1_kernel(const float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v,
+                                                          float* __restrict__ u, const float* __restrict__ hp,
+                                                          const float* __restrict__ gsumsq, const int* __restrict__ chunks,
+                                                          float* __restrict__ norms) {
+    __shared__ float red[2][4];
+    const int* c = chunks + 4 * blockIdx.x;
+    const long off = c[0];
+    const int len = c[1], tid = c[2];
+    const float wd = c[3] ? hp[1] : 0.f;
+    const float b1 = hp[2], b2 = hp[3], eps = hp[4], ibc1 = 1.f / hp[5], isbc2 = rsqrtf(hp[6]), b3 = hp[7];
+    const float gn = sqrtf(*gsumsq);
+    const float iclip = gn > hp[8] ? hp[8] / gn : 1.f;
+    float sp = 0.f, su = 0.f;
+    for (int i = threadIdx.x; i < len; i += 256) {
+        const long e = off + i;
+        const float gi = g[e] * iclip, pi = p[e];
+        const float mi = b1 * m[e] + b3 * gi;
+        const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+        m[e] = mi;
+        v[e] = vi;
+        const float up = (mi * ibc1) / (sqrtf(vi) * isbc2 + eps) + wd * pi;
+        u[e] = up;
+        sp = fmaf(pi, pi, sp);
+        su = fmaf(up, up, su);
+    }
+    sp = wave_sum(sp);
+    su = wave_sum(su);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = sp;
+        red[1][threadIdx.x >> 6] = su;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2)
+        atomicAdd(norms + 2 * tid + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void lamb_stage2_kernel(float* __restrict__ p, const float* __restrict__ u,
+                                                          const float* __restrict__ hp, const int* __restrict__ chunks,
+                                                          const float* __restrict__ norms) {
+    const int* c = chunks + 4 * blockIdx.x;
+    const long off = c[0];
+    const int len = c[1], tid = c[2];
+    float trust = 1.f;
+    if (c[3] && hp[1] != 0.f) {     // trust ratio only where weight decay applies (timm: weight_decay != 0 or always_adapt)
+        const float wn = sqrtf(norms[2 * tid]), un = sqrtf(norms[2 * tid + 1]);
+        trust = (wn > 0.f && un > 0.f) ? wn / un : 1.f;
+    }
+    const float step = hp[0] * trust;
+    for (int i = threadIdx.x; i < len; i += 256) p[off + i] -= step * u[off + i];
+}
+}  // namespace
+
+extern "C" int ga_lamb_stage1(const float* p, const float* g, float* m, float* v, float* u, const float* hp,
+                              const float* gsumsq, const int* chunks, int nchunks, float* norms, ga_stream_t stream) {
+    GA_REQUIRE(p && g && m && v && u && hp && gsumsq && chunks && norms && nchunks > 0, "ga_lamb_stage1: bad args");
+    hipLaunchKernelGGL(lamb_stage1_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, u,
+                       hp, gsumsq, chunks, norms);
+    return ga_check_launch("ga_lamb_stage1");
+}
+
+extern "C" int ga_lamb_stage2(float* p, const float* u, const float* hp, const int* chunks, int nchunks, const float* norms,
+                              ga_stream_t stream) {
+    GA_REQUIRE(p && u && hp && chunks && norms && nchunks > 0, "ga_lamb_stage2: bad args");
+    hipLaunchKernelGGL(lamb_stage2_kernel, dim3(nchunks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, u, hp,
+                       chunks, norms);
+    return ga_check_launch("ga_lamb_stage2");
+}
+

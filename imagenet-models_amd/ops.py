@@ -310,6 +310,14 @@ class Plan:
             return
         self._add('ga_axpy_f32', (_ptr(y), _ptr(x), a, n), label, keep=(y, x))
 
+    def lamb_stage1(self, p, g, m, v, u, hp, gsumsq, chunks, nchunks, norms, label=None):
+        self._add('ga_lamb_stage1', (_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(u), _ptr(hp), _ptr(gsumsq), _ptr(chunks), nchunks,
+                                     _ptr(norms)), label, keep=(p, g, m, v, u, hp, gsumsq, chunks, norms))
+
+    def lamb_stage2(self, p, u, hp, chunks, nchunks, norms, label=None):
+        self._add('ga_lamb_stage2', (_ptr(p), _ptr(u), _ptr(hp), _ptr(chunks), nchunks, _ptr(norms)), label,
+                  keep=(p, u, hp, chunks, norms))
+
     def sumsq_f32(self, x, n, out, label=None):
         self._add('ga_sumsq_f32', (_ptr(x), n, _ptr(out)), label, keep=(x, out))
 

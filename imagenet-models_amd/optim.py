@@ -99,8 +99,59 @@ class FusedAdamW(_FlatOptimizer):
         self.param_groups[0].update(sd['param_groups'][0])
 
 
+class FusedLamb(_FlatOptimizer):
+    """timm.optim.Lamb (bias correction, grad averaging, max_grad_norm 1.0, trust ratio where weight decay applies) -- the
+    optimizer of the published GA recipes (GA/README.md:26).  timm is un-vendored: semantics restated, parity unpinned."""
+    CHUNK = 16384
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, max_grad_norm=1.0,
+                 grad_averaging=True):
+        super().__init__(model, lr, weight_decay)
+        self.betas, self.eps, self.max_grad_norm, self.grad_averaging = betas, eps, max_grad_norm, grad_averaging
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.u = torch.empty_like(self.p)
+        st = model.flat_state()
+        rows = []
+        for tid, (name, (off, numel)) in enumerate(st['slices'].items()):
+            decay = 1 if off < self.n_decay else 0
+            for c0 in range(0, numel, self.CHUNK):
+                rows.append((off + c0, min(self.CHUNK, numel - c0), tid, decay))
+        self.ntensors = len(st['slices'])
+        self.chunks = torch.tensor(rows, dtype=torch.int32, device=self.p.device)
+        self.norms = torch.zeros(2 * self.ntensors, device=self.p.device)
+        self.gsumsq = torch.zeros(1, device=self.p.device)
+        self.hp = torch.zeros(9, device=self.p.device)
+        pl = self.plan = Plan(name='lamb')
+        pl.zero(self.gsumsq)
+        pl.zero(self.norms)
+        pl.sumsq_f32(self.g, self.total, self.gsumsq)
+        pl.lamb_stage1(self.p, self.g, self.m, self.v, self.u, self.hp, self.gsumsq, self.chunks, len(rows), self.norms)
+        pl.lamb_stage2(self.p, self.u, self.hp, self.chunks, len(rows), self.norms)
+
+    def step(self):
+        g = self.param_groups[0]
+        t = self.steps + 1
+        b1, b2 = self.betas
+        self._push_hp([g['lr'], g['weight_decay'], b1, b2, self.eps, 1 - b1 ** t, 1 - b2 ** t,
+                       (1 - b1) if self.grad_averaging else 1.0, self.max_grad_norm])
+        self.plan.run()
+        self.steps = t
+        self._mark_dirty()
+
+    def state_dict(self):
+        return dict(kind='lamb', steps=self.steps, m=self.m.clone(), v=self.v.clone(),
+                    param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        self.steps = sd['steps']
+        self.m.copy_(sd['m'])
+        self.v.copy_(sd['v'])
+        self.param_groups[0].update(sd['param_groups'][0])
+
+
 def create_optimizer_v2(model, opt='sgd', lr=None, weight_decay=0., momentum=0.9, eps=None, betas=None, **_):
-    """timm.optim.create_optimizer_v2 surface for the optimizers the north-star names (sgd / momentum / nesterov / adamw)."""
+    """timm.optim.create_optimizer_v2 surface: sgd / momentum / nesterov / adamw (north star) and lamb (the published recipes)."""
     opt = opt.lower()
     if opt in ('sgd', 'nesterov'):
         return FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=True)
@@ -108,7 +159,9 @@ def create_optimizer_v2(model, opt='sgd', lr=None, weight_decay=0., momentum=0.9
         return FusedSGD(model, lr=lr, momentum=momentum, weight_decay=weight_decay, nesterov=False)
     if opt == 'adamw':
         return FusedAdamW(model, lr=lr, betas=betas or (0.9, 0.999), eps=eps or 1e-8, weight_decay=weight_decay)
-    raise ValueError(f'optimizer {opt!r} is not implemented on the HIP path yet (available: sgd, momentum, nesterov, adamw)')
+    if opt == 'lamb':
+        return FusedLamb(model, lr=lr, betas=betas or (0.9, 0.999), eps=eps or 1e-6, weight_decay=weight_decay)
+    raise ValueError(f'optimizer {opt!r} is not implemented on the HIP path yet (available: sgd, momentum, nesterov, adamw, lamb)')
 
 
 class CosineLRScheduler:

@@ -295,6 +295,17 @@ int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_stream_t strea
 int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream);
 int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t stream);
 
+/* LAMB (timm.optim.Lamb, the optimizer of the published GA recipes: GA/README.md:26) on the flat buffers.
+ *   chunks: int32 [nchunks][4] = {element offset, length, tensor id, weight-decay flag}; a chunk never straddles a tensor.
+ *   hp (device fp32[9]): lr, weight_decay, beta1, beta2, eps, 1-beta1^t, 1-beta2^t, beta3, max_grad_norm.
+ *   stage1: g' = g / max(|g|_2 / max_grad_norm, 1) (|g|_2^2 = *gsumsq, from ga_sumsq_f32); m, v updated;
+ *           u = (m/bc1) / (sqrt(v)/sqrt(bc2) + eps) + wd*p;  norms[2t] += sum p^2, norms[2t+1] += sum u^2 (caller zeroes norms)
+ *   stage2: p -= lr * trust_t * u, trust_t = |p_t| / |u_t| where weight decay applies (both > 0), else 1. */
+int ga_lamb_stage1(const float* p, const float* g, float* m, float* v, float* u, const float* hp, const float* gsumsq,
+                   const int* chunks, int nchunks, float* norms, ga_stream_t stream);
+int ga_lamb_stage2(float* p, const float* u, const float* hp, const int* chunks, int nchunks, const float* norms,
+                   ga_stream_t stream);
+
 /* gradient clipping on the flat fp32 gradient buffer (timm dispatch_clip_grad via NativeScaler, GA/train.py:312-333):
  *   ga_sumsq_f32: *out += sum x^2 (caller zeroes *out; under DDP call after the all-reduce);
  *   ga_clip_grad_f32 mode 0 ('norm'): g *= min(1, limit / (sqrt(*sumsq) + 1e-6));  mode 1 ('value'): clamp to [-limit, limit] */

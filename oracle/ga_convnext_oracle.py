@@ -468,6 +468,35 @@ def adamw_step(params, grads, m, v, step, lr, betas=(0.9, 0.999), eps=1e-8, weig
     return newp, newm, newv
 
 
+def lamb_step(params, grads, m, v, step, lr, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, max_grad_norm=1.0,
+              grad_averaging=True):
+    """timm.optim.Lamb (timm 0.9.x, un-vendored: restated from the published algorithm -- You et al. 2020 -- and the
+    timm source as recalled; PARITY UNPINNED against timm itself) -- one step, `step` 1-based:
+    global grad-norm clip to max_grad_norm, Adam moments (bias-corrected), update += wd * p, per-tensor trust ratio
+    ||p|| / ||update|| (only where weight decay applies), p -= lr * trust * update.
+    Weight-decay grouping as create_optimizer_v2 (GA/train.py:466): none for ndim <= 1 / *.bias."""
+    b1, b2 = betas
+    gn = math.sqrt(sum(float((g.double() ** 2).sum()) for g in grads.values()))
+    clip = gn / max_grad_norm if gn > max_grad_norm else 1.0
+    beta3 = 1 - b1 if grad_averaging else 1.0
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    newp, newm, newv = OrderedDict(), OrderedDict(), OrderedDict()
+    for n, p in params.items():
+        g = grads[n] / clip
+        m1 = b1 * m[n] + beta3 * g if n in m else beta3 * g
+        v1 = b2 * v[n] + (1 - b2) * g * g if n in v else (1 - b2) * g * g
+        upd = (m1 / bc1) / (v1.sqrt() / math.sqrt(bc2) + eps)
+        wd = 0.0 if no_weight_decay(n, p.shape) else weight_decay
+        if wd != 0:
+            upd = upd + wd * p
+            wn, un = float(p.norm()), float(upd.norm())
+            trust = wn / un if (wn > 0 and un > 0) else 1.0
+            upd = upd * trust
+        newp[n] = p - lr * upd
+        newm[n], newv[n] = m1, v1
+    return newp, newm, newv
+
+
 def grad_errors(got, ref):
     """Per-parameter normalised gradient error used by every parity test.
 

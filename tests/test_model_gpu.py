@@ -217,7 +217,7 @@ def test_optimizer_step_on_flat_buffers():
     import imagenet_models_amd as A
     O = _oracle()
     cfg = O.make_cfg(**V2)
-    for kind in ('sgd', 'adamw'):
+    for kind in ('sgd', 'adamw', 'lamb'):
         m, sd = build(cfg, 'fp32')
         opt = A.create_optimizer_v2(m, opt=kind, lr=0.05, weight_decay=0.05, momentum=0.9)
         st = m.flat_state()
@@ -228,10 +228,16 @@ def test_optimizer_step_on_flat_buffers():
         opt.step()
         if kind == 'sgd':
             want, _ = O.sgd_nesterov_step(params, grads, {}, 0.05, 0.9, 0.05, first=True)
-        else:
+        elif kind == 'adamw':
             want, _, _ = O.adamw_step(params, grads, {}, {}, 1, 0.05, (0.9, 0.999), 1e-8, 0.05)
+        else:   # two steps, so that the moments and the bias corrections of step 2 are exercised as well
+            want, m1, v1 = O.lamb_step(params, grads, {}, {}, 1, 0.05, (0.9, 0.999), 1e-6, 0.05)
+            st['grads'].copy_(torch.randn(st['total'], generator=g).cuda())
+            grads2 = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}
+            opt.step()
+            want, _, _ = O.lamb_step(want, grads2, m1, v1, 2, 0.05, (0.9, 0.999), 1e-6, 0.05)
         for n, p in m.named_parameters():
-            assert torch.allclose(p.detach().cpu(), want[n], atol=2e-6, rtol=1e-5), (kind, n)
+            assert torch.allclose(p.detach().cpu(), want[n], atol=(2e-5 if kind == 'lamb' else 2e-6), rtol=1e-4 if kind == 'lamb' else 1e-5), (kind, n)
 
 
 def test_no_cpu_fallback():
