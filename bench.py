@@ -127,8 +127,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1:
+        # one process per GPU over RCCL; GA_DIST_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode only
+        # (ranks share a device, the all-reduce goes through the host): it exercises the N > 1 code, not its speed
+        backend = os.environ.get('GA_DIST_BACKEND', 'nccl')
+        local = local % max(1, torch.cuda.device_count()) if backend != 'nccl' else local
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, init_method='env://')
     else:
         torch.cuda.set_device(0)
     assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1'

@@ -1,0 +1,18 @@
+"""GPU: the N > 1 path of the training step, two ranks under torch.distributed.run.  The GPU box has one device, so
+the ranks share it and talk over gloo (host-staged all-reduce): this checks the bucket logic, not RCCL."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bucketed_allreduce_matches_whole_buffer_reduction():
+    env = dict(os.environ, GA_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(ROOT, 'tests', 'ddp_check.py')]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'DDP_CHECK_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
