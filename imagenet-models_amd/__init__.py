@@ -15,4 +15,4 @@ from .ga_convnext import GA_ConvNeXt  # noqa: E402,F401
 from .loss import ga_loss, heads_topk, accuracy_from_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401
 from .trainer import TrainStep  # noqa: E402,F401
-from .checkpoint import save_checkpoint, load_checkpoint  # noqa: E402,F401
+from .checkpoint import save_checkpoint, load_checkpoint, ModelEma  # noqa: E402,F401

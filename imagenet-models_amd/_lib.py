@@ -105,6 +105,7 @@ _SIGS = {
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),
+    'ga_lerp_f32': ([vp, vp, f32, i64, vp], i32),
     'ga_sumsq_f32': ([vp, i64, vp, vp], i32),
     'ga_lamb_stage1': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp], i32),
     'ga_lamb_stage2': ([vp, vp, vp, vp, i32, vp, vp], i32),

@@ -178,6 +178,11 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
     }
 }
 
+// y += w * (x - y)   (model EMA: ema = decay * ema + (1 - decay) * param, w = 1 - decay)
+__global__ __launch_bounds__(256) void lerp_f32_kernel(float* __restrict__ y, const float* __restrict__ x, float w, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = fmaf(w, x[i] - y[i], y[i]);
+}
+
 __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, const float* __restrict__ x, float a,
                                                        long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
@@ -527,6 +532,13 @@ extern "C" int ga_axpy_f32(float* y, const float* x, float a, int64_t n, ga_stre
     hipLaunchKernelGGL(axpy_f32_kernel, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x, a,
                        (long)n);
     return ga_check_launch("ga_axpy_f32");
+}
+
+extern "C" int ga_lerp_f32(float* y, const float* x, float w, int64_t n, ga_stream_t stream) {
+    GA_REQUIRE(y && x && n > 0, "ga_lerp_f32: bad args");
+    hipLaunchKernelGGL(lerp_f32_kernel, dim3(nblocks(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, x, w,
+                       (long)n);
+    return ga_check_launch("ga_lerp_f32");
 }
 
 extern "C" int ga_rowscale(const void* x, const float* s, void* y, int64_t n, int64_t elems_per_scale, int dtype,

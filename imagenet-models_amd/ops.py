@@ -318,6 +318,9 @@ class Plan:
         self._add('ga_lamb_stage2', (_ptr(p), _ptr(u), _ptr(hp), _ptr(chunks), nchunks, _ptr(norms)), label,
                   keep=(p, u, hp, chunks, norms))
 
+    def lerp_f32(self, y, x, w, n, label=None):
+        self._add('ga_lerp_f32', (_ptr(y), _ptr(x), float(w), n), label, keep=(y, x))
+
     def sumsq_f32(self, x, n, out, label=None):
         self._add('ga_sumsq_f32', (_ptr(x), n, _ptr(out)), label, keep=(x, out))
 

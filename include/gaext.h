@@ -316,6 +316,7 @@ int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float limit, int m
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
 int ga_axpy_f32(float* y, const float* x, float a, int64_t n, ga_stream_t stream);
+int ga_lerp_f32(float* y, const float* x, float w, int64_t n, ga_stream_t stream); /* y += w*(x-y): ModelEmaV2 update, GA/train.py:499 */
 int ga_rowscale(const void* x, const float* s, void* y, int64_t n, int64_t elems_per_scale, int dtype,
                 ga_stream_t stream);
 int ga_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, ga_stream_t stream);

@@ -316,3 +316,39 @@ def test_t768_full_batch_bf16_close_to_fp32_mode():
     assert all(torch.isfinite(g).all() for g in g16.values())
     assert e_out < 6e-2 and e_loss < 2e-2
     assert worst[0][1] < 0.35, worst
+
+
+def test_model_ema_and_checkpoint_roundtrip(tmp_path):
+    """ModelEmaV2 semantics on the flat buffers (ema = d*ema + (1-d)*w over parameters and BN statistics) and the timm
+    checkpoint layout (state_dict / state_dict_ema / optimizer), loaded back with weights_only=True"""
+    import imagenet_models_amd as A
+    O = _oracle()
+    cfg = O.make_cfg(**V2)
+    m, sd = build(cfg, 'fp32')
+    m.train()
+    ema = A.ModelEma(m, decay=0.9)
+    opt = A.create_optimizer_v2(m, opt='sgd', lr=0.1, weight_decay=0.0, momentum=0.0)
+    before = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    st = m.flat_state()
+    st['grads'].copy_(torch.randn(st['total'], generator=torch.Generator().manual_seed(2)).cuda())
+    opt.step()
+    with torch.no_grad():
+        dict(m.named_buffers())['stages.4.bn1.running_mean'].add_(1.0)
+    ema.update()
+    after = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    got = ema.state_dict()
+    for k in before:
+        if before[k].dtype == torch.float32:
+            want = 0.9 * before[k] + 0.1 * after[k]
+            assert torch.allclose(got[k].cpu(), want, atol=1e-6, rtol=1e-5), k
+        else:
+            assert torch.equal(got[k].cpu(), after[k]), k
+    path = str(tmp_path / 'ck.pth.tar')
+    A.save_checkpoint(m, opt, 3, path, metric=1.0, arch='v2', model_ema=ema)
+    m2, _ = build(cfg, 'fp32')
+    A.load_checkpoint(m2, path, use_ema=True)
+    for k, v in m2.state_dict().items():
+        assert torch.allclose(v.cpu().float(), got[k].cpu().float(), atol=1e-7), k
+    A.load_checkpoint(m2, path)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), after[k]), k

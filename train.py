@@ -46,6 +46,8 @@ parser.add_argument('--bce-loss', action='store_true')
 parser.add_argument('--drop-path', type=float, default=None)
 parser.add_argument('--grad-accumulation', type=int, default=1)
 parser.add_argument('--GA_lam', type=float, default=0)
+parser.add_argument('--model-ema', action='store_true', help='track an EMA of the weights (timm ModelEmaV2)')
+parser.add_argument('--model-ema-decay', type=float, default=0.9998)
 parser.add_argument('--clip-grad', type=float, default=None, help='clip gradients (GA/train.py --clip-grad)')
 parser.add_argument('--clip-mode', default='norm', help='"norm" or "value" ("agc" is not built)')
 parser.add_argument('--amp', action='store_true', help='bf16 math mode (default)')
@@ -88,13 +90,15 @@ class AverageMeter:
         self.avg = self.sum / self.count
 
 
-def train_one_epoch(epoch, step_fn, loader, args, world, rank):
+def train_one_epoch(epoch, step_fn, loader, args, world, rank, model_ema=None):
     batch_time_m, losses_m = AverageMeter(), AverageMeter()
     end = time.time()
     last_idx = len(loader) - 1
     loss = None
     for batch_idx, (x, y) in enumerate(loader):
         loss = step_fn(x, y)
+        if model_ema is not None and step_fn.micro % step_fn.accum == 0:   # after every optimizer step (GA/train.py:774)
+            model_ema.update()
         if batch_idx % args.log_interval == 0 or batch_idx == last_idx:
             torch.cuda.synchronize()
             lv = loss.detach().clone()
@@ -161,13 +165,14 @@ def main():
     step_fn = A.TrainStep(model, opt, args.batch_size, lam=args.GA_lam, loss='bce' if args.bce_loss else 'ce',
                           smoothing=args.smoothing, grad_accumulation=args.grad_accumulation,
                           clip_grad=args.clip_grad, clip_mode=args.clip_mode)
+    model_ema = A.ModelEma(model, args.model_ema_decay) if args.model_ema else None
     loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda')
     eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda')
     model.train()
     for epoch in range(args.epochs):
         if sched is not None:
             sched.step(epoch)
-        train_metrics = train_one_epoch(epoch, step_fn, loader, args, world, rank)
+        train_metrics = train_one_epoch(epoch, step_fn, loader, args, world, rank, model_ema)
         eval_metrics = validate(model, eval_loader, args, world)
         if rank == 0:
             _logger.info('*** epoch %d: train loss %.4f  top1 %.3f  top5 %.3f', epoch, train_metrics['loss'],
@@ -175,7 +180,7 @@ def main():
             if args.output:
                 os.makedirs(args.output, exist_ok=True)
                 A.save_checkpoint(model, opt, epoch, os.path.join(args.output, f'checkpoint-{epoch}.pth.tar'),
-                                  metric=eval_metrics['top1'], arch=args.model)
+                                  metric=eval_metrics['top1'], arch=args.model, model_ema=model_ema)
     if world > 1:
         dist.destroy_process_group()
 
