@@ -169,6 +169,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
+// streaming (non-temporal) 16-byte store of 8 bf16: output tiles are written once and not re-read by this kernel
+__device__ __forceinline__ void store8_nt(bf16_t* p, const float v[8]) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    u32x4_t a;
+    a.x = pack2bf(v[0], v[1]); a.y = pack2bf(v[2], v[3]); a.z = pack2bf(v[4], v[5]); a.w = pack2bf(v[6], v[7]);
+    __builtin_nontemporal_store(a, reinterpret_cast<u32x4_t*>(p));
+}
+__device__ __forceinline__ void store8_nt(float* p, const float v[8]) { store8(p, v); }
+
 // lanes whose source row / k chunk is out of range fetch zeros from here
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                     }
                     T* C2p = reinterpret_cast<T*>(d.C2) + z * d.strideC + m * d.ldc + n;
                     if (full) {
-                        store8(C2p, w);
+                        store8_nt(C2p, w);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                 } else {
                     T* Cp = reinterpret_cast<T*>(d.C) + off;
                     if (full) {
-                        store8(Cp, v);
+                        store8_nt(Cp, v);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
