@@ -169,15 +169,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-// streaming (non-temporal) 16-byte store of 8 bf16: output tiles are written once and not re-read by this kernel
-__device__ __forceinline__ void store8_nt(bf16_t* p, const float v[8]) {
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-    u32x4_t a;
-    a.x = pack2bf(v[0], v[1]); a.y = pack2bf(v[2], v[3]); a.z = pack2bf(v[4], v[5]); a.w = pack2bf(v[6], v[7]);
-    __builtin_nontemporal_store(a, reinterpret_cast<u32x4_t*>(p));
-}
-__device__ __forceinline__ void store8_nt(float* p, const float v[8]) { store8(p, v); }
-
 // lanes whose source row / k chunk is out of range fetch zeros from here
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -444,7 +435,7 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                     for (int it = 0; it < NR; ++it) {
                         const int row = rg + it * CF::RG;
                         const long m = (long)cm0 + hf * 64 + row;
-                        if (row < 64 && m < d.M) pre[hf][it] = *reinterpret_cast<const uint4*>(Pb + m * ldp + n);
+                        if (row < 64 && m < d.M) pre[hf][it] = load16_nt(Pb + m * ldp + n);   // read once: do not displace the operand panels in L2
                     }
             }
         }
@@ -584,7 +575,7 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                     if (use_pre) {
                         if constexpr (kPre) unpack8(pre_sel(half, it), h);
                     } else if (full) {
-                        load8(Hb + m * d.ldh + n, h);
+                        load8_nt(Hb + m * d.ldh + n, h);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) h[j] = n + j < d.N ? elt<T>::ld(Hb + m * d.ldh + n + j) : 0.f;
@@ -607,7 +598,7 @@ __global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d
                     if (use_pre && !F_H) {
                         if constexpr (kPre) unpack8(pre_sel(half, it), r);
                     } else if (full) {
-                        load8(Rb + m * d.ldr + n, r);
+                        load8_nt(Rb + m * d.ldr + n, r);
                     } else {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) r[j] = n + j < d.N ? elt<T>::ld(Rb + m * d.ldr + n + j) : 0.f;
