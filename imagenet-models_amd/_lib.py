@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libgaext.so')
+# GAEXT_LIB: another build of the same library (A/B timing of kernel variants on ONE box; boxes differ by several %)
+LIB_PATH = os.environ.get('GAEXT_LIB') or os.path.join(_HERE, 'csrc', 'libgaext.so')
 
 GA_F32, GA_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

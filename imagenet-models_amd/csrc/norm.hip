@@ -19,6 +19,9 @@ int pick_group(int C, int epc) {
 // one 16-byte chunk <-> floats
 __device__ __forceinline__ void ld_chunk(const float* p, float v[4]) { load4(p, v); }
 __device__ __forceinline__ void ld_chunk(const bf16_t* p, float v[8]) { load8(p, v); }
+// read-once input (dead after this kernel): streaming load, keeps the L2 for what the next GEMM re-reads
+__device__ __forceinline__ void ld_chunk_nt(const float* p, float v[4]) { load4(p, v); }
+__device__ __forceinline__ void ld_chunk_nt(const bf16_t* p, float v[8]) { load8_nt(p, v); }
 __device__ __forceinline__ void st_chunk(float* p, const float v[4]) { store4(p, v); }
 __device__ __forceinline__ void st_chunk(bf16_t* p, const float v[8]) { store8(p, v); }
 
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                ld_chunk(x + row * C + ci * E, v[j]);
+                ld_chunk_nt(x + row * C + ci * E, v[j]);
 #pragma unroll
                 for (int e = 0; e < E; ++e) s += v[j][e];
             } else {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
             if (ci < nch) {
-                ld_chunk(g + row * C + ci * E, gv[j]);
+                ld_chunk_nt(g + row * C + ci * E, gv[j]);
                 ld_chunk(x + row * C + ci * E, xh[j]);
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
