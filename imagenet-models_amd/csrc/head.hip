@@ -23,72 +23,82 @@ __device__ __forceinline__ void bil_coef(int o, int n_in, int& i0, int& i1, floa
     l = s - (float)i0;
 }
 
-template <typename T>
+// E channels per thread (8 = 16-byte accesses for bf16 when C, ldd and c_off allow, else 4); 32-bit index math
+template <int E> __device__ __forceinline__ void ldE(const float* p, float v[E]) { if constexpr (E == 8) load8(p, v); else load4(p, v); }
+template <int E> __device__ __forceinline__ void ldE(const bf16_t* p, float v[E]) { if constexpr (E == 8) load8(p, v); else load4(p, v); }
+template <int E> __device__ __forceinline__ void stE(float* p, const float v[E]) { if constexpr (E == 8) store8(p, v); else store4(p, v); }
+template <int E> __device__ __forceinline__ void stE(bf16_t* p, const float v[E]) { if constexpr (E == 8) store8(p, v); else store4(p, v); }
+
+template <typename T, int E>
 __global__ __launch_bounds__(256) void pool_concat_kernel(const T* __restrict__ src, T* __restrict__ dst, int B,
                                                           int Hin, int Win, int C, int Hout, int Wout, int ldd,
                                                           int c_off, int mode) {
-    const int cgs = C >> 2;
-    const long total = (long)B * Hout * Wout * cgs;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cg = (int)(i % cgs);
-        long p = i / cgs;
-        const int ox = (int)(p % Wout); p /= Wout;
-        const int oy = (int)(p % Hout);
-        const long b = p / Hout;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const T* sb = src + b * Hin * Win * C + cg * 4;
+    const unsigned cgs = (unsigned)C / E;
+    const unsigned total = (unsigned)B * Hout * Wout * cgs;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cg = i % cgs;
+        unsigned p = i / cgs;
+        const int ox = (int)(p % (unsigned)Wout); p /= (unsigned)Wout;
+        const int oy = (int)(p % (unsigned)Hout);
+        const long b = p / (unsigned)Hout;
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        const T* sb = src + b * Hin * Win * C + cg * E;
         if (mode == 0) {
             const int f = Hin / Hout;
             for (int dy = 0; dy < f; ++dy)
                 for (int dx = 0; dx < f; ++dx) {
-                    float v[4];
-                    load4(sb + ((long)(oy * f + dy) * Win + ox * f + dx) * C, v);
+                    float v[E];
+                    ldE<E>(sb + ((long)(oy * f + dy) * Win + ox * f + dx) * C, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+                    for (int e = 0; e < E; ++e) acc[e] += v[e];
                 }
             const float inv = 1.f / (float)(f * f);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] *= inv;
+            for (int e = 0; e < E; ++e) acc[e] *= inv;
         } else {
             int y0, y1, x0, x1;
             float ly, lx;
             bil_coef(oy, Hin, y0, y1, ly);
             bil_coef(ox, Win, x0, x1, lx);
-            float a[4], bb[4], c[4], d[4];
-            load4(sb + ((long)y0 * Win + x0) * C, a);
-            load4(sb + ((long)y0 * Win + x1) * C, bb);
-            load4(sb + ((long)y1 * Win + x0) * C, c);
-            load4(sb + ((long)y1 * Win + x1) * C, d);
+            float a[E], bb[E], c[E], d[E];
+            ldE<E>(sb + ((long)y0 * Win + x0) * C, a);
+            ldE<E>(sb + ((long)y0 * Win + x1) * C, bb);
+            ldE<E>(sb + ((long)y1 * Win + x0) * C, c);
+            ldE<E>(sb + ((long)y1 * Win + x1) * C, d);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < E; ++e)
                 acc[e] = (1.f - ly) * ((1.f - lx) * a[e] + lx * bb[e]) + ly * ((1.f - lx) * c[e] + lx * d[e]);
         }
-        store4(dst + ((b * Hout + oy) * Wout + ox) * (long)ldd + c_off + cg * 4, acc);
+        stE<E>(dst + ((b * Hout + oy) * Wout + ox) * (long)ldd + c_off + cg * E, acc);
     }
 }
 
 // backward: dsrc[b, iy, ix, c] = (dres) + sum over the outputs that read this input pixel
-template <typename T>
+template <typename T, int E>
 __global__ __launch_bounds__(256) void pool_concat_bwd_kernel(const T* __restrict__ dcat, const T* __restrict__ dres,
                                                               T* __restrict__ dsrc, int B, int Hin, int Win, int C,
                                                               int Hout, int Wout, int ldd, int c_off, int mode) {
-    const int cgs = C >> 2;
-    const long total = (long)B * Hin * Win * cgs;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int cg = (int)(i % cgs);
-        long p = i / cgs;
-        const int ix = (int)(p % Win); p /= Win;
-        const int iy = (int)(p % Hin);
-        const long b = p / Hin;
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const T* db = dcat + b * Hout * Wout * ldd + c_off + cg * 4;
+    const unsigned cgs = (unsigned)C / E;
+    const unsigned total = (unsigned)B * Hin * Win * cgs;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cg = i % cgs;
+        unsigned p = i / cgs;
+        const int ix = (int)(p % (unsigned)Win); p /= (unsigned)Win;
+        const int iy = (int)(p % (unsigned)Hin);
+        const long b = p / (unsigned)Hin;
+        float acc[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) acc[e] = 0.f;
+        const T* db = dcat + b * Hout * Wout * ldd + c_off + cg * E;
         if (mode == 0) {
             const int f = Hin / Hout;
-            float v[4];
-            load4(db + ((long)(iy / f) * Wout + ix / f) * ldd, v);
+            float v[E];
+            ldE<E>(db + ((long)(iy / f) * Wout + ix / f) * ldd, v);
             const float inv = 1.f / (float)(f * f);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = v[e] * inv;
+            for (int e = 0; e < E; ++e) acc[e] = v[e] * inv;
         } else {
             for (int oy = max(0, 2 * iy - 2); oy <= min(Hout - 1, 2 * iy + 3); ++oy) {
                 int y0, y1;
@@ -102,21 +112,21 @@ __global__ __launch_bounds__(256) void pool_concat_bwd_kernel(const T* __restric
                     bil_coef(ox, Win, x0, x1, lx);
                     const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
                     if (wx == 0.f) continue;
-                    float v[4];
-                    load4(db + ((long)oy * Wout + ox) * ldd, v);
+                    float v[E];
+                    ldE<E>(db + ((long)oy * Wout + ox) * ldd, v);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[e] += wy * wx * v[e];
+                    for (int e = 0; e < E; ++e) acc[e] += wy * wx * v[e];
                 }
             }
         }
-        const long off = ((b * Hin + iy) * Win + ix) * (long)C + cg * 4;
+        const long off = ((b * Hin + iy) * Win + ix) * (long)C + cg * E;
         if (dres) {
-            float r[4];
-            load4(dres + off, r);
+            float r[E];
+            ldE<E>(dres + off, r);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += r[e];
+            for (int e = 0; e < E; ++e) acc[e] += r[e];
         }
-        store4(dsrc + off, acc);
+        stE<E>(dsrc + off, acc);
     }
 }
 
@@ -675,9 +685,21 @@ extern "C" int ga_pool_concat_fwd(const void* src, void* dst, int B, int Hin, in
                          : (Hout == 2 * Hin && Wout == 2 * Win),
                "ga_pool_concat_fwd: unsupported geometry %dx%d -> %dx%d mode %d", Hin, Win, Hout, Wout, mode);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long total = (long)B * Hout * Wout * (C / 4);
-    DISPATCH_T(dtype, pool_concat_kernel, dim3(nblk(total)), dim3(256), 0, s, (const T*)src, (T*)dst, B, Hin, Win, C,
-               Hout, Wout, ldd, c_off, mode);
+    const bool w8 = C % 8 == 0 && c_off % 8 == 0 && ldd % 8 == 0;
+    const long total = (long)B * Hout * Wout * (C / (w8 ? 8 : 4));
+    GA_REQUIRE(total < (1L << 32), "ga_pool_concat_fwd: tensor too large for 32-bit indexing");
+#define GA_PC(E_)                                                                                                     \
+    do {                                                                                                              \
+        if (dtype == GA_BF16)                                                                                         \
+            hipLaunchKernelGGL((pool_concat_kernel<bf16_t, E_>), dim3(nblk(total)), dim3(256), 0, s, (const bf16_t*)src, \
+                               (bf16_t*)dst, B, Hin, Win, C, Hout, Wout, ldd, c_off, mode);                            \
+        else                                                                                                          \
+            hipLaunchKernelGGL((pool_concat_kernel<float, E_>), dim3(nblk(total)), dim3(256), 0, s, (const float*)src,  \
+                               (float*)dst, B, Hin, Win, C, Hout, Wout, ldd, c_off, mode);                             \
+    } while (0)
+    if (w8) GA_PC(8);
+    else GA_PC(4);
+#undef GA_PC
     return ga_check_launch("ga_pool_concat_fwd");
 }
 
@@ -685,9 +707,23 @@ extern "C" int ga_pool_concat_bwd(const void* dcat, const void* dres, void* dsrc
                                   int Hout, int Wout, int ldd, int c_off, int mode, int dtype, ga_stream_t stream) {
     GA_REQUIRE(dcat && dsrc && C % 4 == 0 && c_off % 4 == 0 && ldd % 4 == 0, "ga_pool_concat_bwd: alignment");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long total = (long)B * Hin * Win * (C / 4);
-    DISPATCH_T(dtype, pool_concat_bwd_kernel, dim3(nblk(total)), dim3(256), 0, s, (const T*)dcat, (const T*)dres,
-               (T*)dsrc, B, Hin, Win, C, Hout, Wout, ldd, c_off, mode);
+    const bool w8 = C % 8 == 0 && c_off % 8 == 0 && ldd % 8 == 0;
+    const long total = (long)B * Hin * Win * (C / (w8 ? 8 : 4));
+    GA_REQUIRE(total < (1L << 32), "ga_pool_concat_bwd: tensor too large for 32-bit indexing");
+#define GA_PC(E_)                                                                                                      \
+    do {                                                                                                               \
+        if (dtype == GA_BF16)                                                                                          \
+            hipLaunchKernelGGL((pool_concat_bwd_kernel<bf16_t, E_>), dim3(nblk(total)), dim3(256), 0, s,                \
+                               (const bf16_t*)dcat, (const bf16_t*)dres, (bf16_t*)dsrc, B, Hin, Win, C, Hout, Wout, ldd, \
+                               c_off, mode);                                                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((pool_concat_bwd_kernel<float, E_>), dim3(nblk(total)), dim3(256), 0, s,                 \
+                               (const float*)dcat, (const float*)dres, (float*)dsrc, B, Hin, Win, C, Hout, Wout, ldd,   \
+                               c_off, mode);                                                                           \
+    } while (0)
+    if (w8) GA_PC(8);
+    else GA_PC(4);
+#undef GA_PC
     return ga_check_launch("ga_pool_concat_bwd");
 }
 
