@@ -263,6 +263,14 @@ int ga_class_attn_fwd(const void* q, const void* kv, void* out, float* P, int B,
                       int dtype, ga_stream_t stream);
 int ga_class_attn_bwd(const void* dout, const void* q, const void* kv, const float* P, void* dq, void* dkv, int B, int N,
                       int heads, int hd, float scale, int dtype, ga_stream_t stream);
+/* split form: the class-token row and the N-1 image-token rows of k|v in separate arrays (kv_cls [B][2E], kv_tok
+ * [B][N-1][2E]; N counts the class token).  The image tokens' LayerNorm (LayerScaleBlockClassAttn.norm1 on cat(x_cls, x),
+ * ga_convnext.py:244-246) is row-wise, so the normalised image tokens are shared by all heads and never concatenated. */
+int ga_class_attn_fwd2(const void* q, const void* kv_cls, const void* kv_tok, void* out, float* P, int B, int N, int heads,
+                       int hd, float scale, int dtype, ga_stream_t stream);
+int ga_class_attn_bwd2(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, const float* P, void* dq,
+                       void* dkv_cls, void* dkv_tok, int B, int N, int heads, int hd, float scale, int dtype,
+                       ga_stream_t stream);
 
 /* GA training loss, fused forward + gradient (GA/train.py:735-745):
  *   loss += sum_k L(out_k, y) + lam * sum_k KL_mean(log_softmax(out_k) || log_softmax(mean_j out_j))  (mean detached)

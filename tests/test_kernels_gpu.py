@@ -625,6 +625,17 @@ def test_class_attention(dt, hd):
     P.class_attn_bwd(DO, Q, KV, Pm, dq, dkv, Bn, N, heads, hd, scale, ops.ga_dtype(dt))
     assert_close(dq, lq.grad, tol(dt, 3), 'class attn dq')
     assert_close(dkv, lkv.grad, tol(dt, 3), 'class attn dkv')
+    # split form: class-token row and image-token rows in separate arrays (hd % 8 == 0 only)
+    if hd % 8 == 0:
+        KVc = KV[:, 0].contiguous(); KVt = KV[:, 1:].contiguous()
+        out2 = torch.empty_like(out); Pm2 = torch.empty_like(Pm)
+        P.class_attn_fwd2(Q, KVc, KVt, out2, Pm2, Bn, N, heads, hd, scale, ops.ga_dtype(dt))
+        assert_close(out2, o, tol(dt, 2), 'class attn fwd (split)')
+        assert_close(Pm2, attn.squeeze(2), tol(dt, 2), 'class attn P (split)')
+        dq2 = torch.empty_like(Q); dkc = torch.empty_like(KVc); dkt = torch.empty_like(KVt)
+        P.class_attn_bwd2(DO, Q, KVc, KVt, Pm2, dq2, dkc, dkt, Bn, N, heads, hd, scale, ops.ga_dtype(dt))
+        assert_close(dq2, lq.grad, tol(dt, 3), 'class attn dq (split)')
+        assert_close(torch.cat((dkc[:, None], dkt), 1), lkv.grad, tol(dt, 3), 'class attn dkv (split)')
     # token cat / split
     Cc = 64
     c, Cl = rnd((Bn, Cc), dt, g); t, Tk = rnd((Bn, 196, Cc), dt, g)
