@@ -233,6 +233,15 @@ class GAEngine:
         assert NC % 8 == 0, 'num_classes must be a multiple of 8 (pad the classifier)'
         self.logits = self.buf('logits', (K, B, NC), torch.float32)
         self.heads = []
+        # LayerScaleBlockClassAttn.norm1 acts row-wise on cat(x_cls, tokens) (ga_convnext.py:244-246): the normalised
+        # image tokens are the SAME for all heads (only the affine part differs, and that is folded into each head's
+        # k | v | q weights like the ConvNeXt block's LayerNorm into fc1).  One LayerNorm over the tokens instead of five
+        # over the concatenation, no concatenated copy, one backward LayerNorm over the summed gradient.
+        E_, nh_ = cfg['dim_embed'], cfg['num_heads']
+        self.shared_tok = E_ % nh_ == 0 and (E_ // nh_) % 8 == 0 and E_ <= 512   # what ga_class_attn_*2 supports
+        if self.shared_tok:
+            self.tok = dict(xn=self.act('ga.tok.xn', (M4, d[4])), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
+            F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, d[4], 1e-5, dt, label='ga.tok.ln')
         for k in range(K):
             self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
         # ---------------- backward ----------------
@@ -529,31 +538,55 @@ class GAEngine:
         # --- class-attention block
         pre = f'ga.{k}.'
         N = HW
-        h['u'] = self.act(pre + 'u', (B * (N + 1), cout))
-        F.token_cat(h['cls0'], x4, h['u'], B, N, cout, dt, label=pre + 'cat')
-        h['un'] = self.act(pre + 'un', (B * (N + 1), cout))
-        h['m1'] = self.act(pre + 'm1', (B * (N + 1),), torch.float32)
-        h['r1'] = self.act(pre + 'r1', (B * (N + 1),), torch.float32)
-        F.layernorm_fwd(h['u'], P[pre + 'norm1.weight'], P[pre + 'norm1.bias'], h['un'], h['m1'], h['r1'], B * (N + 1), cout,
-                        1e-5, dt, label=pre + 'ln1')
-        # k and v projections as one GEMM: attn.k.weight and attn.v.weight are adjacent in the flat parameter
-        # buffer, so together they already are the stacked [2E, cout] matrix
         pk, pv = P[pre + 'attn.k.weight'], P[pre + 'attn.v.weight']
         assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
-        Wkv = self.buf('w.' + pre + 'kv', (2 * E, cout))
-        WkvT = self.buf('wT.' + pre + 'kv', (cout, 2 * E)) if T else None
-        self.prep.weight_prep(pk, 1, 2 * E, cout, 1, 1, dt, out=Wkv, ldo=cout, outT=WkvT, ldt=2 * E if T else 0,
-                              label='prep.' + pre + 'kv')
-        h['Wkv'], h['WkvT'] = Wkv, WkvT
-        h['kv'] = self.act(pre + 'kv', (B * (N + 1), 2 * E))
-        F.gemm(h['un'], Wkv, h['kv'], B * (N + 1), 2 * E, cout, dt, label=pre + 'kv')
-        Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1)
-        h['q'] = self.act(pre + 'q', (B, E))
-        F.gemm(h['un'], Wq, h['q'], B, E, cout, dt, lda=(N + 1) * cout, label=pre + 'q')
         h['ao'] = self.act(pre + 'ao', (B, E))
         h['P'] = self.act(pre + 'P', (B, nh, N + 1), torch.float32)
         h['scale'] = hd ** -0.5
-        F.class_attn_fwd(h['q'], h['kv'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
+        if self.shared_tok:
+            # class-token row normalised on its own; norm1's affine part folded into the k | v and q operands
+            g1, b1 = P[pre + 'norm1.weight'], P[pre + 'norm1.bias']
+            h['cn'] = self.act(pre + 'cn', (B, cout))
+            h['rc'] = self.act(pre + 'rc', (B,), torch.float32)
+            F.layernorm_fwd(h['cls0'], None, None, h['cn'], None, h['rc'], B, cout, 1e-5, dt, label=pre + 'ln1c')
+            Wkv = self.buf('w.' + pre + 'kv', (2 * E, cout))
+            WkvT = self.buf('wT.' + pre + 'kv', (cout, 2 * E)) if T else None
+            self.prep.weight_prep(pk, 1, 2 * E, cout, 1, 1, dt, out=Wkv, ldo=cout, outT=WkvT, ldt=2 * E if T else 0, cs=g1,
+                                  label='prep.' + pre + 'kv')
+            bkv = self.buf('w.' + pre + 'bkv', (2 * E,), torch.float32)
+            self.prep.bias_fold(pk, None, None, b1, bkv, 2 * E, cout)
+            h['Wkv'], h['WkvT'] = Wkv, WkvT
+            h['kvt'] = self.act(pre + 'kvt', (M4, 2 * E))
+            h['kvc'] = self.act(pre + 'kvc', (B, 2 * E))
+            F.gemm(self.tok['xn'], Wkv, h['kvt'], M4, 2 * E, cout, dt, bias=bkv, label=pre + 'kv')
+            F.gemm(h['cn'], Wkv, h['kvc'], B, 2 * E, cout, dt, bias=bkv, label=pre + 'kvc')
+            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1)
+            bq = self.buf('w.' + pre + 'bq', (E,), torch.float32)
+            self.prep.bias_fold(P[pre + 'attn.q.weight'], None, None, b1, bq, E, cout)
+            h['q'] = self.act(pre + 'q', (B, E))
+            F.gemm(h['cn'], Wq, h['q'], B, E, cout, dt, bias=bq, label=pre + 'q')
+            F.class_attn_fwd2(h['q'], h['kvc'], h['kvt'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
+        else:
+            h['u'] = self.act(pre + 'u', (B * (N + 1), cout))
+            F.token_cat(h['cls0'], x4, h['u'], B, N, cout, dt, label=pre + 'cat')
+            h['un'] = self.act(pre + 'un', (B * (N + 1), cout))
+            h['m1'] = self.act(pre + 'm1', (B * (N + 1),), torch.float32)
+            h['r1'] = self.act(pre + 'r1', (B * (N + 1),), torch.float32)
+            F.layernorm_fwd(h['u'], P[pre + 'norm1.weight'], P[pre + 'norm1.bias'], h['un'], h['m1'], h['r1'], B * (N + 1),
+                            cout, 1e-5, dt, label=pre + 'ln1')
+            # k and v projections as one GEMM: attn.k.weight and attn.v.weight are adjacent in the flat parameter
+            # buffer, so together they already are the stacked [2E, cout] matrix
+            Wkv = self.buf('w.' + pre + 'kv', (2 * E, cout))
+            WkvT = self.buf('wT.' + pre + 'kv', (cout, 2 * E)) if T else None
+            self.prep.weight_prep(pk, 1, 2 * E, cout, 1, 1, dt, out=Wkv, ldo=cout, outT=WkvT, ldt=2 * E if T else 0,
+                                  label='prep.' + pre + 'kv')
+            h['Wkv'], h['WkvT'] = Wkv, WkvT
+            h['kv'] = self.act(pre + 'kv', (B * (N + 1), 2 * E))
+            F.gemm(h['un'], Wkv, h['kv'], B * (N + 1), 2 * E, cout, dt, label=pre + 'kv')
+            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1)
+            h['q'] = self.act(pre + 'q', (B, E))
+            F.gemm(h['un'], Wq, h['q'], B, E, cout, dt, lda=(N + 1) * cout, label=pre + 'q')
+            F.class_attn_fwd(h['q'], h['kv'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
         Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'])
         bpr = self.buf('w.' + pre + 'bproj', (cout,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'attn.proj.bias'], P[pre + 'gamma_1'], None, bpr, cout, E)
@@ -660,22 +693,49 @@ class GAEngine:
         dao = self.tmp('dao', (B, E))
         Bk.gemm(dpz, W[pre + 'attn.proj.weight.T'], dao, B, E, cout, dt, ldb=pad8(cout), label=pre + 'proj.dg')
         dq = self.tmp('dq', (B, E))
-        dkv = self.tmp('dkv', (B * (N + 1), 2 * E))
-        Bk.class_attn_bwd(dao, h['q'], h['kv'], h['P'], dq, dkv, B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attnb')
         # k, v are adjacent parameters -> their gradients form one [2E, cout] matrix in the flat gradient buffer
         gk, gv = self.grad(pre + 'attn.k.weight'), self.grad(pre + 'attn.v.weight')
         assert gv.data_ptr() == gk.data_ptr() + gk.numel() * 4, 'k/v gradients must be adjacent in the flat buffer'
-        Bk.wgrad(dkv, h['un'], gk, B * (N + 1), 2 * E, cout, dt, label=pre + 'kv.wg')
-        dun = self.tmp('dun', (B * (N + 1), cout))
-        Bk.gemm(dkv, h['WkvT'], dun, B * (N + 1), cout, 2 * E, dt, label=pre + 'kv.dg')
-        Bk.wgrad(dq, h['un'], self.grad(pre + 'attn.q.weight'), B, E, cout, dt, ldx=(N + 1) * cout, label=pre + 'q.wg')
-        Bk.gemm(dq, W[pre + 'attn.q.weight.T'], dun, B, cout, E, dt, ldb=pad8(E), ldc=(N + 1) * cout, R=dun,
-                ldr=(N + 1) * cout, label=pre + 'q.dg')
-        du = self.tmp('du_tok', (B * (N + 1), cout))
-        Bk.layernorm_bwd(dun, h['u'], h['m1'], h['r1'], P[pre + 'norm1.weight'], None, du, self.grad(pre + 'norm1.weight'),
-                         self.grad(pre + 'norm1.bias'), B * (N + 1), cout, False, dt, label=pre + 'ln1b')
-        # dcls0 = dcls1 + du[:,0];  dx4 (+)= du[:,1:]
-        Bk.token_split(du, dcls1, dx4, B, N, cout, True, not first, dt, label=pre + 'split')
+        if self.shared_tok:
+            g1, b1 = P[pre + 'norm1.weight'], P[pre + 'norm1.bias']
+            dg1, db1 = self.grad(pre + 'norm1.weight'), self.grad(pre + 'norm1.bias')
+            dkvc = self.tmp('dkvc', (B, 2 * E))
+            dkvt = self.tmp('dkvt', (M4, 2 * E))
+            Bk.class_attn_bwd2(dao, h['q'], h['kvc'], h['kvt'], h['P'], dq, dkvc, dkvt, B, N + 1, nh, hd, h['scale'], dt,
+                               label=pre + 'attnb')
+            # effective-weight gradients (token rows + class-token row), then un-fold norm1's affine part out of them
+            Gkv, gbkv = self.gbuf((2 * E, cout)), self.gbuf((2 * E,))
+            Bk.wgrad(dkvt, self.tok['xn'], Gkv, M4, 2 * E, cout, dt, dbias=gbkv, label=pre + 'kv.wg')
+            Bk.wgrad(dkvc, h['cn'], Gkv, B, 2 * E, cout, dt, dbias=gbkv, label=pre + 'kvc.wg')
+            Bk.weight_unfold(Gkv, cout, 2 * E, cout, gb=gbkv, W=P[pre + 'attn.k.weight'], cs=g1, v=b1, dW=gk, d_cs=dg1, d_v=db1,
+                             label=pre + 'kv.unf')
+            Gq, gbq = self.gbuf((E, cout)), self.gbuf((E,))
+            Bk.wgrad(dq, h['cn'], Gq, B, E, cout, dt, dbias=gbq, label=pre + 'q.wg')
+            Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=P[pre + 'attn.q.weight'], cs=g1, v=b1,
+                             dW=self.grad(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
+            # gradient wrt the normalised rows: the image-token part is summed over the heads, ONE LayerNorm backward
+            # over it follows the loop (_build_backward); the class-token row gets its own here
+            dxt = self.tmp('dxn_tok', (M4, cout))
+            Bk.gemm(dkvt, h['WkvT'], dxt, M4, cout, 2 * E, dt, R=None if first else dxt, ldr=cout, label=pre + 'kv.dg')
+            dcn = self.tmp('dcn', (B, cout))
+            Bk.gemm(dkvc, h['WkvT'], dcn, B, cout, 2 * E, dt, label=pre + 'kvc.dg')
+            Bk.gemm(dq, W[pre + 'attn.q.weight.T'], dcn, B, cout, E, dt, ldb=pad8(E), R=dcn, ldr=cout, label=pre + 'q.dg')
+            # dcls0 = dcls1 + LN'(dcn)
+            Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, dcls1, dcls1, None, None, B, cout, True, dt, label=pre + 'ln1cb')
+        else:
+            dkv = self.tmp('dkv', (B * (N + 1), 2 * E))
+            Bk.class_attn_bwd(dao, h['q'], h['kv'], h['P'], dq, dkv, B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attnb')
+            Bk.wgrad(dkv, h['un'], gk, B * (N + 1), 2 * E, cout, dt, label=pre + 'kv.wg')
+            dun = self.tmp('dun', (B * (N + 1), cout))
+            Bk.gemm(dkv, h['WkvT'], dun, B * (N + 1), cout, 2 * E, dt, label=pre + 'kv.dg')
+            Bk.wgrad(dq, h['un'], self.grad(pre + 'attn.q.weight'), B, E, cout, dt, ldx=(N + 1) * cout, label=pre + 'q.wg')
+            Bk.gemm(dq, W[pre + 'attn.q.weight.T'], dun, B, cout, E, dt, ldb=pad8(E), ldc=(N + 1) * cout, R=dun,
+                    ldr=(N + 1) * cout, label=pre + 'q.dg')
+            du = self.tmp('du_tok', (B * (N + 1), cout))
+            Bk.layernorm_bwd(dun, h['u'], h['m1'], h['r1'], P[pre + 'norm1.weight'], None, du, self.grad(pre + 'norm1.weight'),
+                             self.grad(pre + 'norm1.bias'), B * (N + 1), cout, False, dt, label=pre + 'ln1b')
+            # dcls0 = dcls1 + du[:,0];  dx4 (+)= du[:,1:]
+            Bk.token_split(du, dcls1, dx4, B, N, cout, True, not first, dt, label=pre + 'split')
         # gram_embedding BN + grouped conv
         pre = f'gram_embedding.{k}.'
         cg = cout // groups
@@ -700,7 +760,9 @@ class GAEngine:
         self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], dgc, M4, g)
         Bk.wgrad(dgc, self.bott['x4'], self.grad(pre + '0.weight'), M4, g, cout, dt, dbias=self.grad(pre + '0.bias'),
                  label=pre + 'wg')
-        Bk.gemm(dgc, W[pre + '0.weight.T'], dx4, M4, cout, g, dt, ldb=pad8(g), R=dx4, ldr=cout, label=pre + 'dg')
+        acc = not (first and self.shared_tok)      # old path: token_split of head 0 has already written dx4
+        Bk.gemm(dgc, W[pre + '0.weight.T'], dx4, M4, cout, g, dt, ldb=pad8(g), R=dx4 if acc else None, ldr=cout,
+                label=pre + 'dg')
 
     # ------------------------------------------------------------------------------------------
     # whole-network backward plan
@@ -714,6 +776,9 @@ class GAEngine:
         dx4 = self.tmp('dx4', (M4, d[4]))
         for k in range(K):
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
+        if self.shared_tok:   # dx4 += LayerNorm'(sum over heads of the gradient wrt the shared normalised tokens)
+            Bk.layernorm_bwd(self.tmp('dxn_tok', (M4, d[4])), self.tok['xn'], None, self.tok['rstd'], None, dx4, dx4, None, None,
+                             M4, d[4], True, dt, label='ga.tok.lnb')
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
         Bk.flush('heads.')
