@@ -49,7 +49,7 @@ class WprepDesc(C.Structure):
     _fields_ = [
         ('w', vp), ('G', i32), ('Co', i32), ('Ci', i32), ('KH', i32), ('KW', i32),
         ('rs', vp), ('cs', vp), ('row_perm', vp), ('dtype', i32),
-        ('out', vp), ('ldo', i64), ('outT', vp), ('ldt', i64), ('flip', i32), ('stem', i32),
+        ('out', vp), ('ldo', i64), ('outT', vp), ('ldt', i64), ('flip', i32), ('stem', i32), ('t_cols', i32),
     ]
 
 

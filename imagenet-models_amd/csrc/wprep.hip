@@ -232,7 +232,8 @@ __device__ void wprep_job_1x1(const ga_wprep_desc& d, int nblk, int blk, float (
     const int KK = d.Ci, Co = d.Co;
     T* out = reinterpret_cast<T*>(d.out);
     T* outT = reinterpret_cast<T*>(d.outT);
-    const int n_ext = outT ? max(Co, (int)d.ldt) : Co, k_ext = out ? max(KK, (int)d.ldo) : KK;
+    const int tcols = d.t_cols > 0 ? d.t_cols : (int)d.ldt;     // columns of an outT row this job owns
+    const int n_ext = outT ? max(Co, tcols) : Co, k_ext = out ? max(KK, (int)d.ldo) : KK;
     const int tn = (n_ext + 63) >> 6, tk = (k_ext + 63) >> 6;
     const int ntiles = d.G * tn * tk;
     const int tr = threadIdx.x >> 4, tc = threadIdx.x & 15;
@@ -262,7 +263,7 @@ __device__ void wprep_job_1x1(const ga_wprep_desc& d, int nblk, int blk, float (
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = k0 + tr + 16 * i, nc = n0 + tc * 4;
-                if (k < KK && nc < d.ldt) {
+                if (k < KK && nc < tcols) {
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = tile[tr + 16 * i][tc * 4 + j];
@@ -277,7 +278,7 @@ __device__ void wprep_job_1x1(const ga_wprep_desc& d, int nblk, int blk, float (
 __device__ __forceinline__ bool wprep_is_1x1(const ga_wprep_desc& d) {
     return d.KH == 1 && d.KW == 1 && !d.stem && !d.flip && d.Ci % 4 == 0 && (reinterpret_cast<uintptr_t>(d.w) & 15) == 0 &&
            (!d.cs || (reinterpret_cast<uintptr_t>(d.cs) & 15) == 0) && (!d.out || d.ldo % 4 == 0) &&
-           (!d.outT || d.ldt % 4 == 0);
+           (!d.outT || (d.ldt % 4 == 0 && d.t_cols % 4 == 0 && (reinterpret_cast<uintptr_t>(d.outT) & 7) == 0));
 }
 
 template <typename T>
@@ -302,10 +303,11 @@ __device__ void wprep_job(const ga_wprep_desc& d, int nblk, int blk) {
     if (d.outT) {
         T* outT = reinterpret_cast<T*>(d.outT);
         const int trows = d.flip ? d.Ci : KK;
-        const long total = (long)d.G * trows * d.ldt;
+        const long tcols = d.t_cols > 0 ? d.t_cols : d.ldt;
+        const long total = (long)d.G * trows * tcols;
         for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
-            const int col = (int)(i % d.ldt);
-            const long t = i / d.ldt;
+            const int col = (int)(i % tcols);
+            const long t = i / tcols;
             const int r = (int)(t % trows), g = (int)(t / trows);
             float v = 0.f;
             if (!d.flip) {
@@ -324,7 +326,7 @@ __device__ void wprep_job(const ga_wprep_desc& d, int nblk, int blk) {
                 if (d.rs) v *= d.rs[n];
                 if (d.cs) v *= d.cs[r];
             }
-            elt<T>::st(outT + i, v);
+            elt<T>::st(outT + t * d.ldt + col, v);
         }
     }
 }
@@ -467,6 +469,7 @@ extern "C" int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream) {
     GA_REQUIRE(d && d->w && d->G >= 1 && d->Co >= 1 && d->Ci >= 1 && d->KH >= 1 && d->KW >= 1, "ga_weight_prep: bad args");
     GA_REQUIRE(!(d->cs && d->G > 1), "ga_weight_prep: column scale with groups unsupported");
     GA_REQUIRE(!(d->flip && d->stem), "ga_weight_prep: flip+stem unsupported");
+    GA_REQUIRE(d->t_cols == 0 || d->t_cols == d->ldt, "ga_weight_prep: t_cols != ldt needs ga_weight_prep_batch");
     const int KK = d->Ci * d->KH * d->KW;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->out) {

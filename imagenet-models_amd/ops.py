@@ -155,11 +155,12 @@ class Plan:
         self._add('ga_wgrad', (C.byref(d),), label, keep=(d, Y, X, dW, dbias))
 
     def weight_prep(self, w, G, Co, Ci, KH, KW, dtype, out=None, ldo=0, outT=None, ldt=0, rs=None, cs=None, flip=False,
-                    stem=False, row_perm=None, label=None):
+                    stem=False, row_perm=None, t_cols=0, label=None):
         d = L.WprepDesc()
         d.w, d.G, d.Co, d.Ci, d.KH, d.KW = _ptr(w), G, Co, Ci, KH, KW
         d.rs, d.cs, d.row_perm, d.dtype = _ptr(rs), _ptr(cs), _ptr(row_perm), dtype
         d.out, d.ldo, d.outT, d.ldt, d.flip, d.stem = _ptr(out), ldo, _ptr(outT), ldt, int(flip), int(stem)
+        d.t_cols = t_cols
         if self.defer:
             self._pend['wprep'].append(d)
             self.keep.extend((w, out, outT, rs, cs, row_perm))

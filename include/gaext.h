@@ -149,6 +149,8 @@ typedef struct {
     void* outT; int64_t ldt;   /* may be NULL */
     int flip;
     int stem;
+    int t_cols;            /* columns of every outT row this job writes (incl. zero padding), 0 = ldt: several jobs
+                            * may fill column ranges of ONE stacked transposed operand of row stride ldt */
 } ga_wprep_desc;
 int ga_weight_prep(const ga_wprep_desc* d, ga_stream_t stream);
 /* be[n] = rs[m] * (b[m] + sum_c W[m][c] * v[c]), m = row_perm ? row_perm[n] : n   (W fp32 [N][C]; b, rs, v may be NULL) */

@@ -743,3 +743,26 @@ def test_clip_grad_flat(n):
     G = base.clone().cuda()
     ops.Plan(eager=True).clip_grad_f32(G, n, G, 0.3, 1)
     assert torch.equal(G.cpu(), base.clamp(-0.3, 0.3))
+
+
+@pytest.mark.parametrize('dt', DT)
+def test_weight_prep_stacked_transposed_operand(dt):
+    """several jobs fill column ranges of ONE transposed operand (t_cols): the stacked k|v weights of the five heads"""
+    ops = _imp()
+    g = gen(31)
+    heads, Co, Ci = 3, 40, 72                      # 1x1 fast path (Ci % 4 == 0) ...
+    for Ci in (72, 70):                            # ... and the generic path
+        ws = [torch.randn(Co, Ci, generator=g) for _ in range(heads)]
+        css = [torch.rand(Ci, generator=g) + 0.5 for _ in range(heads)]
+        ldt = heads * Co
+        outT = torch.full((Ci, ldt), 7.0, dtype=dt, device='cuda')
+        out = torch.empty(heads * Co, Ci + (-Ci) % 8, dtype=dt, device='cuda')
+        P = ops.Plan(defer_small=True)
+        for k in range(heads):
+            P.weight_prep(ws[k].cuda(), 1, Co, Ci, 1, 1, ops.ga_dtype(dt), out=out[k * Co:], ldo=out.shape[1],
+                          outT=outT[:, k * Co:], ldt=ldt, cs=css[k].cuda(), t_cols=Co)
+        P.flush()
+        P.run()
+        ref = torch.cat([w * c[None, :] for w, c in zip(ws, css)], 0)      # [heads*Co, Ci]
+        assert_close(outT, ref.t(), tol(dt, 0.5), 'stacked outT')
+        assert_close(out[:, :Ci], ref, tol(dt, 0.5), 'stacked out')
