@@ -96,8 +96,8 @@ _SIGS = {
     'ga_token_split': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_class_attn_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     'ga_class_attn_bwd': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
-    'ga_class_attn_fwd2': ([vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
-    'ga_class_attn_bwd2': ([vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_fwd2': ([vp, vp, vp, i64, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_bwd2': ([vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp], i32),
     'ga_loss_fwd_bwd': ([vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, i32, vp], i32),
     'ga_heads_topk': ([vp, i32, i32, i32, i32, vp, vp, vp], i32),
     'ga_sgd_step': ([vp, vp, vp, vp, i64, i32, f32, vp], i32),

@@ -510,7 +510,7 @@ constexpr int kCaWaves = 16, kCaThreads = 64 * kCaWaves;
 template <typename T>
 __global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T* __restrict__ q, const T* __restrict__ kv_cls,
                                                                          long cls_stride, const T* __restrict__ kv_tok,
-                                                                         long tok_stride, T* __restrict__ out,
+                                                                         long tok_stride, long tok_ld, T* __restrict__ out,
                                                                          float* __restrict__ P, int N, int heads, int hd,
                                                                          float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T
     // row n of the sample: n == 0 the class token (kv_cls), n >= 1 token n-1 (kv_tok); the two may be one array
     // ([B][N][2E]: cls_stride = tok_stride = N*2E, kv_tok = kv_cls + 2E) or separate ([B][2E] and [B][N-1][2E])
     const T* kvc = kv_cls + b * cls_stride;
-    const T* kvt = kv_tok + b * tok_stride - 2 * E;      // so that row n >= 1 is kvt + n * 2E
+    const T* kvt = kv_tok + b * tok_stride - tok_ld;     // so that row n >= 1 is kvt + n * tok_ld
     float qv[8];
     if (live) {
         load8(q + b * E + lane * 8, qv);
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T
     for (int n = wave; n < N; n += kCaWaves) {
         if (live) {
             float k[8];
-            load8((n == 0 ? kvc : kvt + (long)n * 2 * E) + lane * 8, k);
+            load8((n == 0 ? kvc : kvt + (long)n * tok_ld) + lane * 8, k);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = fmaf(qv[e], k[e], s);
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T
     for (int n = wave; n < N; n += kCaWaves) {
         if (live) {
             float v[8];
-            load8((n == 0 ? kvc : kvt + (long)n * 2 * E) + E + lane * 8, v);
+            load8((n == 0 ? kvc : kvt + (long)n * tok_ld) + E + lane * 8, v);
             const float p = pl[hl * N + n];
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] = fmaf(p, v[e], acc[e]);
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_fwd_rows_kernel(const T
 template <typename T>
 __global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T* __restrict__ dout, const T* __restrict__ q,
                                                                          const T* __restrict__ kv_cls, long cls_stride,
-                                                                         const T* __restrict__ kv_tok, long tok_stride,
+                                                                         const T* __restrict__ kv_tok, long tok_stride, long tok_ld,
                                                                          const float* __restrict__ P, T* __restrict__ dq,
                                                                          T* __restrict__ dkv_cls, T* __restrict__ dkv_tok,
                                                                          int N, int heads, int hd, float scale) {
@@ -607,9 +607,9 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool live = lane < NCH;
     const T* kvc = kv_cls + b * cls_stride;
-    const T* kvt = kv_tok + b * tok_stride - 2 * E;
+    const T* kvt = kv_tok + b * tok_stride - tok_ld;
     T* dkc = dkv_cls + b * cls_stride;
-    T* dkt = dkv_tok + b * tok_stride - 2 * E;
+    T* dkt = dkv_tok + b * tok_stride - tok_ld;
     float dov[8], qv[8];
     if (live) {
         load8(dout + b * E + lane * 8, dov);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T
     for (int n = wave; n < N; n += kCaWaves) {
         if (live) {
             float v[8];
-            load8((n == 0 ? kvc : kvt + (long)n * 2 * E) + E + lane * 8, v);
+            load8((n == 0 ? kvc : kvt + (long)n * tok_ld) + E + lane * 8, v);
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s = fmaf(dov[e], v[e], s);
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T
     for (int n = wave; n < N; n += kCaWaves) {
         if (live) {
             float k[8], dk[8], dv[8];
-            load8((n == 0 ? kvc : kvt + (long)n * 2 * E) + lane * 8, k);
+            load8((n == 0 ? kvc : kvt + (long)n * tok_ld) + lane * 8, k);
             const float ds = dsl[hl * N + n], p = pl[hl * N + n];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(kCaThreads) void class_attn_bwd_rows_kernel(const T
                 dk[e] = ds * qv[e];
                 dv[e] = p * dov[e];
             }
-            T* drow = n == 0 ? dkc : dkt + (long)n * 2 * E;
+            T* drow = n == 0 ? dkc : dkt + (long)n * tok_ld;
             store8(drow + lane * 8, dk);
             store8(drow + E + lane * 8, dv);
         }
@@ -814,24 +814,24 @@ extern "C" int ga_token_split(const void* du, void* dcls, void* dtok, int B, int
 // rows-form launchers; kv_cls / kv_tok may be two views of one [B][N][2E] array or two separate arrays
 template <typename T>
 static int class_attn_fwd_rows(const void* q, const void* kv_cls, long cls_stride, const void* kv_tok, long tok_stride,
-                               void* out, float* P, int B, int N, int heads, int hd, float scale, size_t lds,
+                               long tok_ld, void* out, float* P, int B, int N, int heads, int hd, float scale, size_t lds,
                                hipStream_t s) {
     auto k = class_attn_fwd_rows_kernel<T>;
     GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
                    hipSuccess, "ga_class_attn_fwd: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const T*)q, (const T*)kv_cls, cls_stride, (const T*)kv_tok,
-                       tok_stride, (T*)out, P, N, heads, hd, scale);
+                       tok_stride, tok_ld, (T*)out, P, N, heads, hd, scale);
     return ga_check_launch("ga_class_attn_fwd");
 }
 template <typename T>
 static int class_attn_bwd_rows(const void* dout, const void* q, const void* kv_cls, long cls_stride, const void* kv_tok,
-                               long tok_stride, const float* P, void* dq, void* dkv_cls, void* dkv_tok, int B, int N,
+                               long tok_stride, long tok_ld, const float* P, void* dq, void* dkv_cls, void* dkv_tok, int B, int N,
                                int heads, int hd, float scale, size_t lds, hipStream_t s) {
     auto k = class_attn_bwd_rows_kernel<T>;
     GA_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) ==
                    hipSuccess, "ga_class_attn_bwd: cannot reserve %zu B of LDS", lds);
     hipLaunchKernelGGL(k, dim3(B), dim3(kCaThreads), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, cls_stride,
-                       (const T*)kv_tok, tok_stride, P, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, N, heads, hd, scale);
+                       (const T*)kv_tok, tok_stride, tok_ld, P, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, N, heads, hd, scale);
     return ga_check_launch("ga_class_attn_bwd");
 }
 
@@ -842,8 +842,8 @@ extern "C" int ga_class_attn_fwd(const void* q, const void* kv, void* out, float
     const long E2 = 2L * heads * hd, esz = dtype == GA_BF16 ? 2 : 4;
     if (const size_t lds = class_attn_rows_lds(N, heads, hd, false)) {
         const void* tok = static_cast<const char*>(kv) + E2 * esz;
-        return dtype == GA_BF16 ? class_attn_fwd_rows<bf16_t>(q, kv, N * E2, tok, N * E2, out, P, B, N, heads, hd, scale, lds, s)
-                                : class_attn_fwd_rows<float>(q, kv, N * E2, tok, N * E2, out, P, B, N, heads, hd, scale, lds, s);
+        return dtype == GA_BF16 ? class_attn_fwd_rows<bf16_t>(q, kv, N * E2, tok, N * E2, E2, out, P, B, N, heads, hd, scale, lds, s)
+                                : class_attn_fwd_rows<float>(q, kv, N * E2, tok, N * E2, E2, out, P, B, N, heads, hd, scale, lds, s);
     }
     DISPATCH_T(dtype, class_attn_fwd_kernel, dim3(B), dim3(256), 4 * (N + 64) * sizeof(float), s, (const T*)q,
                (const T*)kv, (T*)out, P, N, heads, hd, scale);
@@ -859,8 +859,8 @@ extern "C" int ga_class_attn_bwd(const void* dout, const void* q, const void* kv
         const void* tok = static_cast<const char*>(kv) + E2 * esz;
         void* dtok = static_cast<char*>(dkv) + E2 * esz;
         return dtype == GA_BF16
-                   ? class_attn_bwd_rows<bf16_t>(dout, q, kv, N * E2, tok, N * E2, P, dq, dkv, dtok, B, N, heads, hd, scale, lds, s)
-                   : class_attn_bwd_rows<float>(dout, q, kv, N * E2, tok, N * E2, P, dq, dkv, dtok, B, N, heads, hd, scale, lds, s);
+                   ? class_attn_bwd_rows<bf16_t>(dout, q, kv, N * E2, tok, N * E2, E2, P, dq, dkv, dtok, B, N, heads, hd, scale, lds, s)
+                   : class_attn_bwd_rows<float>(dout, q, kv, N * E2, tok, N * E2, E2, P, dq, dkv, dtok, B, N, heads, hd, scale, lds, s);
     }
     DISPATCH_T(dtype, class_attn_bwd_kernel, dim3(B), dim3(256), 4 * (N + 128) * sizeof(float), s, (const T*)dout,
                (const T*)q, (const T*)kv, P, (T*)dq, (T*)dkv, N, heads, hd, scale);
@@ -870,27 +870,29 @@ extern "C" int ga_class_attn_bwd(const void* dout, const void* q, const void* kv
 // split form: the class-token row and the N-1 image-token rows of k | v live in separate arrays (kv_cls [B][2E],
 // kv_tok [B][N-1][2E]) -- the image tokens' LayerNorm is shared by all heads, so their k | v rows come from one GEMM over
 // the shared normalised tokens and are never concatenated with the per-head class token.  hd % 8 == 0, E <= 512.
-extern "C" int ga_class_attn_fwd2(const void* q, const void* kv_cls, const void* kv_tok, void* out, float* P, int B, int N,
-                                  int heads, int hd, float scale, int dtype, ga_stream_t stream) {
+extern "C" int ga_class_attn_fwd2(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P,
+                                  int B, int N, int heads, int hd, float scale, int dtype, ga_stream_t stream) {
     GA_REQUIRE(q && kv_cls && kv_tok && out && P && N >= 2, "ga_class_attn_fwd2: bad args");
     const size_t lds = class_attn_rows_lds(N, heads, hd, false);
     GA_REQUIRE(lds > 0, "ga_class_attn_fwd2: needs hd %% 8 == 0 and heads*hd <= 512 (hd=%d heads=%d N=%d)", hd, heads, N);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long E2 = 2L * heads * hd;
-    return dtype == GA_BF16 ? class_attn_fwd_rows<bf16_t>(q, kv_cls, E2, kv_tok, (N - 1) * E2, out, P, B, N, heads, hd, scale, lds, s)
-                            : class_attn_fwd_rows<float>(q, kv_cls, E2, kv_tok, (N - 1) * E2, out, P, B, N, heads, hd, scale, lds, s);
+    const long E2 = 2L * heads * hd, ld = tok_ld > 0 ? tok_ld : E2;
+    GA_REQUIRE(ld >= E2 && ld % 8 == 0, "ga_class_attn_fwd2: tok_ld must be a multiple of 8 and >= 2E");
+    return dtype == GA_BF16 ? class_attn_fwd_rows<bf16_t>(q, kv_cls, E2, kv_tok, (N - 1) * ld, ld, out, P, B, N, heads, hd, scale, lds, s)
+                            : class_attn_fwd_rows<float>(q, kv_cls, E2, kv_tok, (N - 1) * ld, ld, out, P, B, N, heads, hd, scale, lds, s);
 }
 
-extern "C" int ga_class_attn_bwd2(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, const float* P,
-                                  void* dq, void* dkv_cls, void* dkv_tok, int B, int N, int heads, int hd, float scale,
-                                  int dtype, ga_stream_t stream) {
+extern "C" int ga_class_attn_bwd2(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld,
+                                  const float* P, void* dq, void* dkv_cls, void* dkv_tok, int B, int N, int heads, int hd,
+                                  float scale, int dtype, ga_stream_t stream) {
     GA_REQUIRE(dout && q && kv_cls && kv_tok && P && dq && dkv_cls && dkv_tok && N >= 2, "ga_class_attn_bwd2: bad args");
     const size_t lds = class_attn_rows_lds(N, heads, hd, true);
     GA_REQUIRE(lds > 0, "ga_class_attn_bwd2: needs hd %% 8 == 0 and heads*hd <= 512 (hd=%d heads=%d N=%d)", hd, heads, N);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const long E2 = 2L * heads * hd;
-    return dtype == GA_BF16 ? class_attn_bwd_rows<bf16_t>(dout, q, kv_cls, E2, kv_tok, (N - 1) * E2, P, dq, dkv_cls, dkv_tok, B, N,
-                                                          heads, hd, scale, lds, s)
-                            : class_attn_bwd_rows<float>(dout, q, kv_cls, E2, kv_tok, (N - 1) * E2, P, dq, dkv_cls, dkv_tok, B, N,
-                                                         heads, hd, scale, lds, s);
+    const long E2 = 2L * heads * hd, ld = tok_ld > 0 ? tok_ld : E2;
+    GA_REQUIRE(ld >= E2 && ld % 8 == 0, "ga_class_attn_bwd2: tok_ld must be a multiple of 8 and >= 2E");
+    return dtype == GA_BF16 ? class_attn_bwd_rows<bf16_t>(dout, q, kv_cls, E2, kv_tok, (N - 1) * ld, ld, P, dq, dkv_cls, dkv_tok, B,
+                                                          N, heads, hd, scale, lds, s)
+                            : class_attn_bwd_rows<float>(dout, q, kv_cls, E2, kv_tok, (N - 1) * ld, ld, P, dq, dkv_cls, dkv_tok, B,
+                                                         N, heads, hd, scale, lds, s);
 }

@@ -242,6 +242,25 @@ class GAEngine:
         if self.shared_tok:
             self.tok = dict(xn=self.act('ga.tok.xn', (M4, d[4])), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
             F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, d[4], 1e-5, dt, label='ga.tok.ln')
+            # the k | v rows of the image tokens of ALL heads from one GEMM over the shared tokens: the heads' effective
+            # (norm1-folded) k|v weights are stacked along N; head k reads / writes the column slice [k*2E, (k+1)*2E)
+            E2, cout = 2 * E_, d[4]
+            tk = self.tok
+            tk['E2'], tk['ld'] = E2, K * E2
+            tk['W'] = self.buf('w.ga.kv_all', (K * E2, cout))
+            tk['WT'] = self.buf('wT.ga.kv_all', (cout, K * E2)) if T else None
+            tk['b'] = self.buf('w.ga.bkv_all', (K * E2,), torch.float32)
+            P = self.P
+            for k in range(K):
+                pre = f'ga.{k}.'
+                pk, pv = P[pre + 'attn.k.weight'], P[pre + 'attn.v.weight']
+                assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
+                self.prep.weight_prep(pk, 1, E2, cout, 1, 1, dt, out=tk['W'][k * E2:], ldo=cout,
+                                      outT=tk['WT'][:, k * E2:] if T else None, ldt=K * E2 if T else 0,
+                                      cs=P[pre + 'norm1.weight'], t_cols=E2, label='prep.' + pre + 'kv')
+                self.prep.bias_fold(pk, None, None, P[pre + 'norm1.bias'], tk['b'][k * E2:], E2, cout)
+            tk['kv'] = self.act('ga.kv_all', (M4, K * E2))
+            F.gemm(tk['xn'], tk['W'], tk['kv'], M4, K * E2, cout, dt, bias=tk['b'], label='ga.kv_all')
         for k in range(K):
             self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
         # ---------------- backward ----------------
@@ -549,23 +568,18 @@ class GAEngine:
             h['cn'] = self.act(pre + 'cn', (B, cout))
             h['rc'] = self.act(pre + 'rc', (B,), torch.float32)
             F.layernorm_fwd(h['cls0'], None, None, h['cn'], None, h['rc'], B, cout, 1e-5, dt, label=pre + 'ln1c')
-            Wkv = self.buf('w.' + pre + 'kv', (2 * E, cout))
-            WkvT = self.buf('wT.' + pre + 'kv', (cout, 2 * E)) if T else None
-            self.prep.weight_prep(pk, 1, 2 * E, cout, 1, 1, dt, out=Wkv, ldo=cout, outT=WkvT, ldt=2 * E if T else 0, cs=g1,
-                                  label='prep.' + pre + 'kv')
-            bkv = self.buf('w.' + pre + 'bkv', (2 * E,), torch.float32)
-            self.prep.bias_fold(pk, None, None, b1, bkv, 2 * E, cout)
-            h['Wkv'], h['WkvT'] = Wkv, WkvT
-            h['kvt'] = self.act(pre + 'kvt', (M4, 2 * E))
-            h['kvc'] = self.act(pre + 'kvc', (B, 2 * E))
-            F.gemm(self.tok['xn'], Wkv, h['kvt'], M4, 2 * E, cout, dt, bias=bkv, label=pre + 'kv')
-            F.gemm(h['cn'], Wkv, h['kvc'], B, 2 * E, cout, dt, bias=bkv, label=pre + 'kvc')
+            tk = self.tok
+            E2 = tk['E2']
+            h['kvt'] = tk['kv'][:, k * E2:]                       # column slice, row stride tk['ld']
+            h['kvc'] = self.act(pre + 'kvc', (B, E2))
+            F.gemm(h['cn'], tk['W'][k * E2:], h['kvc'], B, E2, cout, dt, bias=tk['b'][k * E2:], label=pre + 'kvc')
             Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1)
             bq = self.buf('w.' + pre + 'bq', (E,), torch.float32)
             self.prep.bias_fold(P[pre + 'attn.q.weight'], None, None, b1, bq, E, cout)
             h['q'] = self.act(pre + 'q', (B, E))
             F.gemm(h['cn'], Wq, h['q'], B, E, cout, dt, bias=bq, label=pre + 'q')
-            F.class_attn_fwd2(h['q'], h['kvc'], h['kvt'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
+            F.class_attn_fwd2(h['q'], h['kvc'], h['kvt'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, tok_ld=tk['ld'],
+                              label=pre + 'attn')
         else:
             h['u'] = self.act(pre + 'u', (B * (N + 1), cout))
             F.token_cat(h['cls0'], x4, h['u'], B, N, cout, dt, label=pre + 'cat')
@@ -699,26 +713,24 @@ class GAEngine:
         if self.shared_tok:
             g1, b1 = P[pre + 'norm1.weight'], P[pre + 'norm1.bias']
             dg1, db1 = self.grad(pre + 'norm1.weight'), self.grad(pre + 'norm1.bias')
-            dkvc = self.tmp('dkvc', (B, 2 * E))
-            dkvt = self.tmp('dkvt', (M4, 2 * E))
+            tk = self.tok
+            E2 = tk['E2']
+            if first:      # gradients of all heads' token k|v rows / stacked effective weights: consumed after the loop
+                tk['dkv'] = self.tmp('dkv_all', (M4, tk['ld']))
+                tk['G'], tk['gb'] = self.gbuf((tk['ld'], cout)), self.gbuf((tk['ld'],))
+            dkvc = self.tmp('dkvc', (B, E2))
+            dkvt = tk['dkv'][:, k * E2:]
             Bk.class_attn_bwd2(dao, h['q'], h['kvc'], h['kvt'], h['P'], dq, dkvc, dkvt, B, N + 1, nh, hd, h['scale'], dt,
-                               label=pre + 'attnb')
-            # effective-weight gradients (token rows + class-token row), then un-fold norm1's affine part out of them
-            Gkv, gbkv = self.gbuf((2 * E, cout)), self.gbuf((2 * E,))
-            Bk.wgrad(dkvt, self.tok['xn'], Gkv, M4, 2 * E, cout, dt, dbias=gbkv, label=pre + 'kv.wg')
-            Bk.wgrad(dkvc, h['cn'], Gkv, B, 2 * E, cout, dt, dbias=gbkv, label=pre + 'kvc.wg')
-            Bk.weight_unfold(Gkv, cout, 2 * E, cout, gb=gbkv, W=P[pre + 'attn.k.weight'], cs=g1, v=b1, dW=gk, d_cs=dg1, d_v=db1,
-                             label=pre + 'kv.unf')
+                               tok_ld=tk['ld'], label=pre + 'attnb')
+            # class-token row's share of the effective k|v weight gradient (the token rows' share: one wgrad after the loop)
+            Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], B, E2, cout, dt, dbias=tk['gb'][k * E2:], label=pre + 'kvc.wg')
             Gq, gbq = self.gbuf((E, cout)), self.gbuf((E,))
             Bk.wgrad(dq, h['cn'], Gq, B, E, cout, dt, dbias=gbq, label=pre + 'q.wg')
             Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=P[pre + 'attn.q.weight'], cs=g1, v=b1,
                              dW=self.grad(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
-            # gradient wrt the normalised rows: the image-token part is summed over the heads, ONE LayerNorm backward
-            # over it follows the loop (_build_backward); the class-token row gets its own here
-            dxt = self.tmp('dxn_tok', (M4, cout))
-            Bk.gemm(dkvt, h['WkvT'], dxt, M4, cout, 2 * E, dt, R=None if first else dxt, ldr=cout, label=pre + 'kv.dg')
+            # gradient wrt the normalised class-token row (the image-token rows: one GEMM over all heads after the loop)
             dcn = self.tmp('dcn', (B, cout))
-            Bk.gemm(dkvc, h['WkvT'], dcn, B, cout, 2 * E, dt, label=pre + 'kvc.dg')
+            Bk.gemm(dkvc, tk['WT'][:, k * E2:], dcn, B, cout, E2, dt, ldb=tk['ld'], label=pre + 'kvc.dg')
             Bk.gemm(dq, W[pre + 'attn.q.weight.T'], dcn, B, cout, E, dt, ldb=pad8(E), R=dcn, ldr=cout, label=pre + 'q.dg')
             # dcls0 = dcls1 + LN'(dcn)
             Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, dcls1, dcls1, None, None, B, cout, True, dt, label=pre + 'ln1cb')
@@ -776,9 +788,20 @@ class GAEngine:
         dx4 = self.tmp('dx4', (M4, d[4]))
         for k in range(K):
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
-        if self.shared_tok:   # dx4 += LayerNorm'(sum over heads of the gradient wrt the shared normalised tokens)
-            Bk.layernorm_bwd(self.tmp('dxn_tok', (M4, d[4])), self.tok['xn'], None, self.tok['rstd'], None, dx4, dx4, None, None,
-                             M4, d[4], True, dt, label='ga.tok.lnb')
+        if self.shared_tok:
+            tk = self.tok
+            E2 = tk['E2']
+            # token rows of all heads at once: effective k|v weight gradients, then each head's norm1 fold undone ...
+            Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], d[4], dt, dbias=tk['gb'], label='ga.kv_all.wg')
+            for k in range(K):
+                pre = f'ga.{k}.'
+                Bk.weight_unfold(tk['G'][k * E2:], d[4], E2, d[4], gb=tk['gb'][k * E2:], W=P[pre + 'attn.k.weight'],
+                                 cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self.grad(pre + 'attn.k.weight'),
+                                 d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'kv.unf')
+            # ... and dx4 += LayerNorm'(gradient wrt the shared normalised tokens, summed over the heads by the K = 5*2E GEMM)
+            dxt = self.tmp('dxn_tok', (M4, d[4]))
+            Bk.gemm(tk['dkv'], tk['WT'], dxt, M4, d[4], tk['ld'], dt, label='ga.kv_all.dg')
+            Bk.layernorm_bwd(dxt, tk['xn'], None, tk['rstd'], None, dx4, dx4, None, None, M4, d[4], True, dt, label='ga.tok.lnb')
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
         Bk.flush('heads.')

@@ -279,12 +279,14 @@ class Plan:
         self._add('ga_class_attn_bwd', (_ptr(dout), _ptr(q), _ptr(kv), _ptr(P), _ptr(dq), _ptr(dkv), B, N, heads, hd,
                                         scale, dtype), label, keep=(dout, q, kv, P, dq, dkv))
 
-    def class_attn_fwd2(self, q, kv_cls, kv_tok, out, P, B, N, heads, hd, scale, dtype, label=None):
-        self._add('ga_class_attn_fwd2', (_ptr(q), _ptr(kv_cls), _ptr(kv_tok), _ptr(out), _ptr(P), B, N, heads, hd, scale, dtype),
+    def class_attn_fwd2(self, q, kv_cls, kv_tok, out, P, B, N, heads, hd, scale, dtype, tok_ld=0, label=None):
+        self._add('ga_class_attn_fwd2', (_ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(out), _ptr(P), B, N, heads, hd, scale,
+                                         dtype),
                   label, keep=(q, kv_cls, kv_tok, out, P))
 
-    def class_attn_bwd2(self, dout, q, kv_cls, kv_tok, P, dq, dkv_cls, dkv_tok, B, N, heads, hd, scale, dtype, label=None):
-        self._add('ga_class_attn_bwd2', (_ptr(dout), _ptr(q), _ptr(kv_cls), _ptr(kv_tok), _ptr(P), _ptr(dq), _ptr(dkv_cls),
+    def class_attn_bwd2(self, dout, q, kv_cls, kv_tok, P, dq, dkv_cls, dkv_tok, B, N, heads, hd, scale, dtype, tok_ld=0,
+                        label=None):
+        self._add('ga_class_attn_bwd2', (_ptr(dout), _ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(P), _ptr(dq), _ptr(dkv_cls),
                                          _ptr(dkv_tok), B, N, heads, hd, scale, dtype), label,
                   keep=(dout, q, kv_cls, kv_tok, P, dq, dkv_cls, dkv_tok))
 

@@ -268,10 +268,12 @@ int ga_class_attn_bwd(const void* dout, const void* q, const void* kv, const flo
 /* split form: the class-token row and the N-1 image-token rows of k|v in separate arrays (kv_cls [B][2E], kv_tok
  * [B][N-1][2E]; N counts the class token).  The image tokens' LayerNorm (LayerScaleBlockClassAttn.norm1 on cat(x_cls, x),
  * ga_convnext.py:244-246) is row-wise, so the normalised image tokens are shared by all heads and never concatenated. */
-int ga_class_attn_fwd2(const void* q, const void* kv_cls, const void* kv_tok, void* out, float* P, int B, int N, int heads,
-                       int hd, float scale, int dtype, ga_stream_t stream);
-int ga_class_attn_bwd2(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, const float* P, void* dq,
-                       void* dkv_cls, void* dkv_tok, int B, int N, int heads, int hd, float scale, int dtype,
+/* tok_ld: row stride (elements) of kv_tok / dkv_tok, 0 = 2E: the five heads' k|v rows may be column slices of ONE
+ * [B*(N-1)][5*2E] matrix produced by a single GEMM over the shared normalised tokens. */
+int ga_class_attn_fwd2(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P, int B, int N,
+                       int heads, int hd, float scale, int dtype, ga_stream_t stream);
+int ga_class_attn_bwd2(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, const float* P,
+                       void* dq, void* dkv_cls, void* dkv_tok, int B, int N, int heads, int hd, float scale, int dtype,
                        ga_stream_t stream);
 
 /* GA training loss, fused forward + gradient (GA/train.py:735-745):

@@ -636,6 +636,15 @@ def test_class_attention(dt, hd):
         P.class_attn_bwd2(DO, Q, KVc, KVt, Pm2, dq2, dkc, dkt, Bn, N, heads, hd, scale, ops.ga_dtype(dt))
         assert_close(dq2, lq.grad, tol(dt, 3), 'class attn dq (split)')
         assert_close(torch.cat((dkc[:, None], dkt), 1), lkv.grad, tol(dt, 3), 'class attn dkv (split)')
+        # token rows as a column slice of a wider matrix (row stride tok_ld)
+        ld = 2 * E + 16
+        wide = torch.zeros(Bn, N - 1, ld, dtype=dt, device='cuda'); wide[:, :, 8:8 + 2 * E] = KVt
+        dwide = torch.zeros_like(wide)
+        P.class_attn_fwd2(Q, KVc, wide[:, :, 8:], out2, Pm2, Bn, N, heads, hd, scale, ops.ga_dtype(dt), tok_ld=ld)
+        assert_close(out2, o, tol(dt, 2), 'class attn fwd (strided tokens)')
+        P.class_attn_bwd2(DO, Q, KVc, wide[:, :, 8:], Pm2, dq2, dkc, dwide[:, :, 8:], Bn, N, heads, hd, scale, ops.ga_dtype(dt), tok_ld=ld)
+        assert_close(dwide[:, :, 8:8 + 2 * E], lkv.grad[:, 1:], tol(dt, 3), 'class attn dkv (strided tokens)')
+        assert float(dwide[:, :, :8].abs().max()) == 0.0 and float(dwide[:, :, 8 + 2 * E:].abs().max()) == 0.0
     # token cat / split
     Cc = 64
     c, Cl = rnd((Bn, Cc), dt, g); t, Tk = rnd((Bn, 196, Cc), dt, g)
