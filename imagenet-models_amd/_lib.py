@@ -81,9 +81,9 @@ _SIGS = {
     'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     'ga_bn_finalize': ([vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
-    'ga_affine_act': ([vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, vp], i32),
-    'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, vp], i32),
-    'ga_bn_bwd_apply': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, vp], i32),
+    'ga_affine_act': ([vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i64, vp], i32),
+    'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i64, vp], i32),
+    'ga_bn_bwd_apply': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, vp, i64, i32, i32, i64, i64, vp], i32),
     'ga_pool_concat_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_pool_concat_bwd': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_spatial_sum': ([vp, vp, vp, i32, i32, i32, f32, i32, vp], i32),

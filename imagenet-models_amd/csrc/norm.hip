@@ -262,7 +262,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, const T* __restrict__ res,
                                                          const float* __restrict__ rowscale, long elems_per_scale,
-                                                         T* __restrict__ y, long n8, int C, int relu) {
+                                                         T* __restrict__ y, long n8, int C, int relu, long ldx) {
     extern __shared__ __attribute__((aligned(16))) float coef[];      // [2][C]: scale, shift
     if (scale) {
         for (int c = threadIdx.x; c < C; c += 256) {
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ x
         const int c = (int)w.col << 3;
         const float rsc = rowscale ? rowscale[div_small(w.row, rps, inv_rps)] : 1.f;
         float v[8], r[8], sc[8], sh[8];
-        load8(x + e, v);
+        load8(x + (long)w.row * ldx + c, v);          // x may be a column slice of a wider matrix (row stride ldx)
         if (res) load8(res + e, r);
         if (scale) {
             load8(coef + c, sc);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const T* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const float* __restrict__ rowscale,
                                                             long rows_per_scale, float* __restrict__ s1,
-                                                            float* __restrict__ s2, long rows, int C) {
+                                                            float* __restrict__ s2, long rows, int C, long ldx) {
     __shared__ float red[2][16][64];
     const int c0 = blockIdx.y * 64;
     const int cgs = min(64, C - c0) >> 2;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             const long off = row * C + c0 + cg * 4;
             float g[4], xv[4];
             load4(dy + off, g);
-            load4(x + off, xv);
+            load4(x + row * ldx + c0 + cg * 4, xv);
             if (yrelu) {
                 float yv[4];
                 load4(yrelu + off, yv);
@@ -366,7 +366,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ rstd, const float* __restrict__ w,
                                                            const float* __restrict__ s1, const float* __restrict__ s2,
                                                            const float* __restrict__ rowscale, long elems_per_scale,
-                                                           float inv_n, T* __restrict__ dx, long n8, int C) {
+                                                           float inv_n, T* __restrict__ dx, long n8, int C, long ldx,
+                                                           long lddx) {
     extern __shared__ __attribute__((aligned(16))) float coef[];      // [4][C]
     for (int c = threadIdx.x; c < C; c += 256) {
         const float rs = rstd[c];
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const float rsc = rowscale ? rowscale[div_small(wk.row, rps, inv_rps)] : 1.f;
         float g[8], xv[8], yv[8], A[8], Bc[8], D[8], mu[8];
         load8(dy + e, g);
-        load8(x + e, xv);
+        load8(x + (long)wk.row * ldx + c, xv);        // x / dx may be column slices of wider matrices
         if (yrelu) load8(yrelu + e, yv);
         load8(coef + c, A);
         load8(coef + C + c, Bc);
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (yrelu && !(yv[j] > 0.f)) gg = 0.f;
             g[j] = fmaf(A[j], gg, fmaf(Bc[j], xv[j] - mu[j], D[j]));
         }
-        store8(dx + e, g);
+        store8(dx + (long)wk.row * lddx + c, g);
     }
 }
 
@@ -483,7 +484,9 @@ extern "C" int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, c
 
 extern "C" int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res,
                              const float* rowscale, int64_t rows_per_scale, void* y, int64_t rows, int C, int relu,
-                             int dtype, ga_stream_t stream) {
+                             int dtype, int64_t ldx, ga_stream_t stream) {
+    if (ldx == 0) ldx = C;
+    GA_REQUIRE(ldx >= C && ldx % 8 == 0, "ga_affine_act: ldx must be a multiple of 8 and >= C");
     GA_REQUIRE(x && y && rows > 0 && C % 8 == 0 && ((scale == nullptr) == (shift == nullptr)) &&
                    rows * C / 8 < (1L << 31), "ga_affine_act: bad args");
     GA_REQUIRE(C <= 8192, "ga_affine_act: C=%d too large for the LDS coefficient table", C);
@@ -493,33 +496,38 @@ extern "C" int ga_affine_act(const void* x, const float* scale, const float* shi
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(affine_act_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)x, scale, shift,
-                           (const bf16_t*)res, rowscale, (long)rows_per_scale * C, (bf16_t*)y, n8, C, relu);
+                           (const bf16_t*)res, rowscale, (long)rows_per_scale * C, (bf16_t*)y, n8, C, relu, (long)ldx);
     else
         hipLaunchKernelGGL(affine_act_kernel<float>, grid, block, lds, s, (const float*)x, scale, shift, (const float*)res,
-                           rowscale, (long)rows_per_scale * C, (float*)y, n8, C, relu);
+                           rowscale, (long)rows_per_scale * C, (float*)y, n8, C, relu, (long)ldx);
     return ga_check_launch("ga_affine_act");
 }
 
 extern "C" int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
                                 const float* rowscale, int64_t rows_per_scale, float* s1, float* s2, int64_t rows, int C,
-                                int dtype, ga_stream_t stream) {
+                                int dtype, int64_t ldx, ga_stream_t stream) {
+    if (ldx == 0) ldx = C;
+    GA_REQUIRE(ldx >= C && ldx % 4 == 0, "ga_bn_bwd_reduce: ldx must be a multiple of 4 and >= C");
     GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && rows > 0 && C % 4 == 0, "ga_bn_bwd_reduce: bad args");
     const int slices = cdiv(C, 64);
     dim3 grid(std::max(1, std::min<int>((int)((rows + 15) / 16), std::max(1, 1024 / slices))), slices), block(256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
-                           (const bf16_t*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C);
+                           (const bf16_t*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C, (long)ldx);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, block, 0, s, (const float*)dy, (const float*)y_relu,
-                           (const float*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C);
+                           (const float*)x, mean, rstd, rowscale, (long)rows_per_scale, s1, s2, (long)rows, C, (long)ldx);
     return ga_check_launch("ga_bn_bwd_reduce");
 }
 
 extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
                                const float* w, const float* s1, const float* s2, const float* rowscale,
                                int64_t rows_per_scale, int64_t n, void* dx, int64_t rows, int C, int dtype,
-                               ga_stream_t stream) {
+                               int64_t ldx, int64_t lddx, ga_stream_t stream) {
+    if (ldx == 0) ldx = C;
+    if (lddx == 0) lddx = C;
+    GA_REQUIRE(ldx >= C && lddx >= C && ldx % 8 == 0 && lddx % 8 == 0, "ga_bn_bwd_apply: ldx / lddx must be multiples of 8 and >= C");
     GA_REQUIRE(dy && x && mean && rstd && s1 && s2 && dx && rows > 0 && C % 8 == 0 && n > 0 && rows * C / 8 < (1L << 31),
                "ga_bn_bwd_apply: bad args");
     GA_REQUIRE(C <= 4096, "ga_bn_bwd_apply: C=%d too large for the LDS coefficient table", C);
@@ -530,10 +538,10 @@ extern "C" int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, grid, block, lds, s, (const bf16_t*)dy, (const bf16_t*)y_relu,
                            (const bf16_t*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
-                           (bf16_t*)dx, n8, C);
+                           (bf16_t*)dx, n8, C, (long)ldx, (long)lddx);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, grid, block, lds, s, (const float*)dy, (const float*)y_relu,
                            (const float*)x, mean, rstd, w, s1, s2, rowscale, (long)rows_per_scale * C, 1.f / (float)n,
-                           (float*)dx, n8, C);
+                           (float*)dx, n8, C, (long)ldx, (long)lddx);
     return ga_check_launch("ga_bn_bwd_apply");
 }

@@ -261,6 +261,23 @@ class GAEngine:
                 self.prep.bias_fold(pk, None, None, P[pre + 'norm1.bias'], tk['b'][k * E2:], E2, cout)
             tk['kv'] = self.act('ga.kv_all', (M4, K * E2))
             F.gemm(tk['xn'], tk['W'], tk['kv'], M4, K * E2, cout, dt, bias=tk['b'], label='ga.kv_all')
+        # gram_contraction (conv1x1 768 -> 192 + BN) of the five heads reads the same x4: ONE GEMM with the five weight
+        # matrices stacked along N; head k owns the column slice [k*g, (k+1)*g) of its output / statistics
+        g_ = cfg['gram_dim']
+        gc = self.gcon = dict(ld=K * g_)
+        gc['W'] = self.buf('w.gram_contraction.all', (K * g_, d[4]))
+        gc['WT'] = self.buf('wT.gram_contraction.all', (d[4], K * g_)) if T else None
+        gc['b'] = self.buf('w.gram_contraction.ball', (K * g_,), torch.float32)
+        gc['s'], gc['q'] = self._bn_pool(K * g_), self._bn_pool(K * g_)
+        for k in range(K):
+            pre = f'gram_contraction.{k}.'
+            self.prep.weight_prep(self.P[pre + '0.weight'], 1, g_, d[4], 1, 1, dt, out=gc['W'][k * g_:], ldo=d[4],
+                                  outT=gc['WT'][:, k * g_:] if T else None, ldt=K * g_ if T else 0, t_cols=g_,
+                                  label='prep.' + pre + 'w')
+            self.prep.bias_fold(None, self.P[pre + '0.bias'], None, None, gc['b'][k * g_:], g_, d[4])
+        gc['out'] = self.act('gram_contraction.all.out', (M4, K * g_))
+        F.gemm(x4, gc['W'], gc['out'], M4, K * g_, d[4], dt, bias=gc['b'], colsum=gc['s'] if T else None,
+               colsumsq=gc['q'] if T else None, label='gram_contraction.all')
         for k in range(K):
             self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
         # ---------------- backward ----------------
@@ -400,13 +417,13 @@ class GAEngine:
                              self.Bf[pre + 'running_mean'], self.Bf[pre + 'running_var'], bn['mean'], bn['rstd'],
                              bn['scale'], bn['shift'], C, self.training, label=pre + 'fin')
 
-    def _bn_bwd(self, pre, bn, dy, y_relu, x, dx, rows, C, rowscale=None, rps=1):
+    def _bn_bwd(self, pre, bn, dy, y_relu, x, dx, rows, C, rowscale=None, rps=1, ldx=0, lddx=0):
         Bk = self.bwd
         s1, s2 = self.gbuf((C,)), self.gbuf((C,))
         Bk.bn_bwd_reduce(dy, y_relu, x, bn['mean'], bn['rstd'], s1, s2, rows, C, self.dt, rowscale=rowscale,
-                         rows_per_scale=rps, label=pre + 'bnr')
+                         rows_per_scale=rps, ldx=ldx, label=pre + 'bnr')
         Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'], s1, s2, rows, dx, rows, C, self.dt,
-                        rowscale=rowscale, rows_per_scale=rps, label=pre + 'bna')
+                        rowscale=rowscale, rows_per_scale=rps, ldx=ldx, lddx=lddx, label=pre + 'bna')
         Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, C)
         Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, C)
 
@@ -515,16 +532,17 @@ class GAEngine:
         hd = E // nh
         assert E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0
         h = dict(k=k)
-        # --- gram_contraction: conv1x1 + BN
+        # --- gram_contraction: the conv output / batch sums are column slices of the stacked GEMM; BN per head
         pre = f'gram_contraction.{k}.'
-        Wgc = self._w_plain(pre + '0.weight', g, cout, 1, 1)
-        h['gc'] = self.act(pre + 'out', (M4, g))
-        h['bn_gc'] = self._bn_bufs(pre + '1.', g)
-        F.gemm(x4, Wgc, h['gc'], M4, g, cout, dt, bias=P[pre + '0.bias'], colsum=h['bn_gc']['s'] if T else None,
-               colsumsq=h['bn_gc']['q'] if T else None, label=pre + 'conv')
-        self._bn_finalize(pre + '1.', h['bn_gc'], M4, g)
+        gcn = self.gcon
+        h['gc'] = gcn['out'][:, k * g:]                      # [M4, g] view, row stride gcn['ld']
+        bn = dict(s=gcn['s'][k * g:(k + 1) * g], q=gcn['q'][k * g:(k + 1) * g],
+                  mean=self.buf(pre + '1.bmean', (g,), torch.float32), rstd=self.buf(pre + '1.brstd', (g,), torch.float32),
+                  scale=self.buf(pre + '1.scale', (g,), torch.float32), shift=self.buf(pre + '1.shift', (g,), torch.float32))
+        h['bn_gc'] = bn
+        self._bn_finalize(pre + '1.', bn, M4, g)
         h['g0'] = self.buf(pre + 'g0', (M4, g))
-        F.affine_act(h['gc'], h['bn_gc']['scale'], h['bn_gc']['shift'], None, h['g0'], M4, g, False, dt, label=pre + 'bn')
+        F.affine_act(h['gc'], bn['scale'], bn['shift'], None, h['g0'], M4, g, False, dt, ldx=gcn['ld'], label=pre + 'bn')
         # --- gram_layer: one ConvNeXt block at 14x14
         h['blk'] = f'gram_layer.{k}.blocks.0.'
         g1 = self._block_fwd(h['blk'], h['g0'], Hc, g)
@@ -767,14 +785,12 @@ class GAEngine:
                 label=f'gram.{k}.dx')
         dg0 = self.tmp('dg0', (M4, g))
         self._block_bwd(h['blk'], dg1, dg0)
+        # gram_contraction BN backward into this head's column slice; the conv's wgrad / dgrad run once for all heads
         pre = f'gram_contraction.{k}.'
-        dgc = self.tmp('dgc', (M4, g))
-        self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], dgc, M4, g)
-        Bk.wgrad(dgc, self.bott['x4'], self.grad(pre + '0.weight'), M4, g, cout, dt, dbias=self.grad(pre + '0.bias'),
-                 label=pre + 'wg')
-        acc = not (first and self.shared_tok)      # old path: token_split of head 0 has already written dx4
-        Bk.gemm(dgc, W[pre + '0.weight.T'], dx4, M4, cout, g, dt, ldb=pad8(g), R=dx4 if acc else None, ldr=cout,
-                label=pre + 'dg')
+        gcn = self.gcon
+        if first:
+            gcn['dout'] = self.tmp('dgc_all', (M4, gcn['ld']))
+        self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], gcn['dout'][:, k * g:], M4, g, ldx=gcn['ld'], lddx=gcn['ld'])
 
     # ------------------------------------------------------------------------------------------
     # whole-network backward plan
@@ -788,6 +804,17 @@ class GAEngine:
         dx4 = self.tmp('dx4', (M4, d[4]))
         for k in range(K):
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
+        # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
+        gcn, g_ = self.gcon, cfg['gram_dim']
+        Gc, gbc = self.gbuf((gcn['ld'], d[4])), self.gbuf((gcn['ld'],))
+        Bk.wgrad(gcn['dout'], x4, Gc, M4, gcn['ld'], d[4], dt, dbias=gbc, label='gram_contraction.all.wg')
+        for k in range(K):
+            pre = f'gram_contraction.{k}.'
+            Bk.axpy_f32(self.grad(pre + '0.weight'), Gc[k * g_:], 1.0, g_ * d[4])
+            Bk.axpy_f32(self.grad(pre + '0.bias'), gbc[k * g_:], 1.0, g_)
+        # the first writer of dx4 on the shared-token path (the per-head token_split of the other path has written it)
+        Bk.gemm(gcn['dout'], gcn['WT'], dx4, M4, d[4], gcn['ld'], dt, R=None if self.shared_tok else dx4, ldr=d[4],
+                label='gram_contraction.all.dg')
         if self.shared_tok:
             tk = self.tok
             E2 = tk['E2']

@@ -216,20 +216,20 @@ class Plan:
                                      _ptr(mean_out), _ptr(rstd_out), _ptr(scale), _ptr(shift), Cdim, int(training)),
                   label, keep=(ssum, ssq, w, b, rmean, rvar, mean_out, rstd_out, scale, shift))
 
-    def affine_act(self, x, scale, shift, res, y, rows, Cdim, relu, dtype, rowscale=None, rows_per_scale=1, label=None):
+    def affine_act(self, x, scale, shift, res, y, rows, Cdim, relu, dtype, rowscale=None, rows_per_scale=1, ldx=0, label=None):
         self._add('ga_affine_act', (_ptr(x), _ptr(scale), _ptr(shift), _ptr(res), _ptr(rowscale), rows_per_scale, _ptr(y),
-                                    rows, Cdim, int(relu), dtype), label, keep=(x, scale, shift, res, y, rowscale))
+                                    rows, Cdim, int(relu), dtype, ldx), label, keep=(x, scale, shift, res, y, rowscale))
 
-    def bn_bwd_reduce(self, dy, y_relu, x, mean, rstd, s1, s2, rows, Cdim, dtype, rowscale=None, rows_per_scale=1,
+    def bn_bwd_reduce(self, dy, y_relu, x, mean, rstd, s1, s2, rows, Cdim, dtype, rowscale=None, rows_per_scale=1, ldx=0,
                       label=None):
         self._add('ga_bn_bwd_reduce', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(rowscale),
-                                       rows_per_scale, _ptr(s1), _ptr(s2), rows, Cdim, dtype), label,
+                                       rows_per_scale, _ptr(s1), _ptr(s2), rows, Cdim, dtype, ldx), label,
                   keep=(dy, y_relu, x, mean, rstd, s1, s2, rowscale))
 
     def bn_bwd_apply(self, dy, y_relu, x, mean, rstd, w, s1, s2, n, dx, rows, Cdim, dtype, rowscale=None,
-                     rows_per_scale=1, label=None):
+                     rows_per_scale=1, ldx=0, lddx=0, label=None):
         self._add('ga_bn_bwd_apply', (_ptr(dy), _ptr(y_relu), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(s1), _ptr(s2),
-                                      _ptr(rowscale), rows_per_scale, n, _ptr(dx), rows, Cdim, dtype), label,
+                                      _ptr(rowscale), rows_per_scale, n, _ptr(dx), rows, Cdim, dtype, ldx, lddx), label,
                   keep=(dy, y_relu, x, mean, rstd, w, s1, s2, dx, rowscale))
 
     # -- head ---------------------------------------------------------------------------------------

@@ -212,14 +212,16 @@ int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const floa
 int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* w, const float* b, float eps,
                    float momentum, float* running_mean, float* running_var, float* mean_out, float* rstd_out,
                    float* scale, float* shift, int C, int training, ga_stream_t stream);
+/* ldx / lddx: row stride (elements) of x / dx when they are column slices of a wider matrix (the five heads'
+ * gram_contraction outputs come from ONE GEMM); 0 = C.  Every other operand is contiguous [rows][C]. */
 int ga_affine_act(const void* x, const float* scale, const float* shift, const void* res, const float* rowscale,
-                  int64_t rows_per_scale, void* y, int64_t rows, int C, int relu, int dtype, ga_stream_t stream);
+                  int64_t rows_per_scale, void* y, int64_t rows, int C, int relu, int dtype, int64_t ldx, ga_stream_t stream);
 int ga_bn_bwd_reduce(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
                      const float* rowscale, int64_t rows_per_scale, float* s1, float* s2, int64_t rows, int C, int dtype,
-                     ga_stream_t stream);
+                     int64_t ldx, ga_stream_t stream);
 int ga_bn_bwd_apply(const void* dy, const void* y_relu, const void* x, const float* mean, const float* rstd,
                     const float* w, const float* s1, const float* s2, const float* rowscale, int64_t rows_per_scale,
-                    int64_t n, void* dx, int64_t rows, int C, int dtype, ga_stream_t stream);
+                    int64_t n, void* dx, int64_t rows, int C, int dtype, int64_t ldx, int64_t lddx, ga_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Multi-scale aggregate (ga_convnext.py:396-397,479-483): write pool(src) into channels [c_off, c_off+C) of the
