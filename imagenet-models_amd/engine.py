@@ -278,8 +278,20 @@ class GAEngine:
         gc['out'] = self.act('gram_contraction.all.out', (M4, K * g_))
         F.gemm(x4, gc['W'], gc['out'], M4, K * g_, d[4], dt, bias=gc['b'], colsum=gc['s'] if T else None,
                colsumsq=gc['q'] if T else None, label='gram_contraction.all')
+        # classifiers: inputs of the five heads in one [K][B][cout] buffer, weights stacked -> one batched GEMM
+        fa = self.fc_all = dict(x=self.act('fc.all.x', (K, B, d[4])))
+        ldn = pad8(NC)
+        fa['W'] = self.buf('w.fc.all', (K, NC, d[4]))
+        fa['WT'] = self.buf('wT.fc.all', (K, d[4], ldn)) if T else None
+        fa['b'] = self.buf('w.fc.ball', (K, NC), torch.float32)
+        for k in range(K):
+            self.prep.weight_prep(self.P[f'fc.{k}.weight'], 1, NC, d[4], 1, 1, dt, out=fa['W'][k], ldo=d[4],
+                                  outT=fa['WT'][k] if T else None, ldt=ldn if T else 0, label=f'prep.fc.{k}')
+            self.prep.bias_fold(None, self.P[f'fc.{k}.bias'], None, None, fa['b'][k], NC, d[4])
         for k in range(K):
             self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
+        F.gemm(fa['x'], fa['W'], self.logits, B, NC, d[4], dt, batch=K, strideA=B * d[4], strideB=NC * d[4], strideC=B * NC,
+               bias=fa['b'], strideBias=NC, c_f32=True, label='fc.all')
         # ---------------- backward ----------------
         if T:
             self._build_backward(feats, taps, stage_in, x4, M4, ctot)
@@ -652,14 +664,11 @@ class GAEngine:
         Wm2 = self._w_plain(pre + 'mlp.fc2.weight', cin, gc_, 1, 1, groups=mg, rs=P[pre + 'gamma_2'])
         bm2 = self.buf('w.' + pre + 'bm2', (cout,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma_2'], None, bm2, cout, gc_)
-        h['cls2'] = self.act(pre + 'cls2', (B, cout))
+        h['cls2'] = self.fc_all['x'][k]                          # slice of [K][B][cout]: the five classifiers run as one GEMM
         F.gemm(h['am'], Wm2, h['cls2'], B, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
                ldb=pad8(gc_), ldc=cout, strideC=cin, bias=bm2, strideBias=cin, rowscale=dp,
                rows_per_scale=1, R=h['cls1'], ldr=cout, strideR=cin, label=pre + 'mlp.fc2')
         h.update(Hd=Hd, mlp_gc=gc_, Nv=Nv, cin=cin)
-        # --- classifier
-        Wfc = self._w_plain(f'fc.{k}.weight', NC, cout, 1, 1)
-        F.gemm(h['cls2'], Wfc, self.logits[k], B, NC, cout, dt, bias=P[f'fc.{k}.bias'], c_f32=True, label=f'fc.{k}')
         return h
 
     def _head_bwd(self, h, dlog, dx4, first):
@@ -675,11 +684,8 @@ class GAEngine:
         Hd, gc_, Nv, cin = h['Hd'], h['mlp_gc'], h['Nv'], h['cin']
         pre = f'ga.{k}.'
         dp = self.dp_scale.get(pre)
-        # classifier
-        Bk.wgrad(dlog, h['cls2'], self.grad(f'fc.{k}.weight'), B, NC, cout, dt, dbias=self.grad(f'fc.{k}.bias'),
-                 label=f'fc.{k}.wg')
-        dcls2 = self.tmp('dcls2', (B, cout))
-        Bk.gemm(dlog, W[f'fc.{k}.weight.T'], dcls2, B, cout, NC, dt, ldb=pad8(NC), label=f'fc.{k}.dg')
+        # classifier: done for all heads at once in _build_backward
+        dcls2 = self.fc_all['dx'][k]
         dmz = dcls2
         if dp is not None:
             dmz = self.tmp('dmz', (B, cout))
@@ -802,6 +808,17 @@ class GAEngine:
         self.dlogits = self.buf('dlogits', (K, B, NC))
         Bk.zero(self.arena, label='zero.arena')
         dx4 = self.tmp('dx4', (M4, d[4]))
+        # classifiers of the five heads: one batched wgrad and one batched dgrad
+        fa = self.fc_all
+        Gfc, gbfc = self.gbuf((K, NC, d[4])), self.gbuf((K, NC))
+        Bk.wgrad(self.dlogits, fa['x'], Gfc, B, NC, d[4], dt, batch=K, strideY=B * NC, strideX=B * d[4], strideW=NC * d[4],
+                 dbias=gbfc, strideDbias=NC, label='fc.all.wg')
+        for k in range(K):
+            Bk.axpy_f32(self.grad(f'fc.{k}.weight'), Gfc[k], 1.0, NC * d[4])
+            Bk.axpy_f32(self.grad(f'fc.{k}.bias'), gbfc[k], 1.0, NC)
+        fa['dx'] = self.tmp('dcls2_all', (K, B, d[4]))
+        Bk.gemm(self.dlogits, fa['WT'], fa['dx'], B, d[4], NC, dt, batch=K, strideA=B * NC, strideB=d[4] * pad8(NC),
+                ldb=pad8(NC), strideC=B * d[4], label='fc.all.dg')
         for k in range(K):
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
         # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
