@@ -15,6 +15,8 @@ block output of fc1 as a = gelu(h) and g = gelu'(h) (both written by the fc1 epi
 Reference semantics restated here: /root/reference/GA/ga_convnext.py:98-112 (block), :139-150 (stage + taps),
 :294-318 (Bottleneck), :452-467 (get_gram), :153-248 (class attention block), :469-505 (forward).
 """
+import os
+
 import torch
 
 from . import ops
@@ -109,7 +111,7 @@ class GAEngine:
     def tmp(self, tag, shape, dtype=None):
         """transient buffer shared by every call site with the same (tag, shape, dtype) -- stream order makes it safe"""
         dtype = dtype or self.tdt
-        key = (tag, tuple(shape), dtype)
+        key = (getattr(self, 'tmp_prefix', '') + tag, tuple(shape), dtype)   # per-head copies when the heads run concurrently
         if key not in self.tmps:
             self.tmps[key] = torch.empty(shape, dtype=dtype, device=self.dev)
         return self.tmps[key]
@@ -288,8 +290,14 @@ class GAEngine:
             self.prep.weight_prep(self.P[f'fc.{k}.weight'], 1, NC, d[4], 1, 1, dt, out=fa['W'][k], ldo=d[4],
                                   outT=fa['WT'][k] if T else None, ldt=ldn if T else 0, label=f'prep.fc.{k}')
             self.prep.bias_fold(None, self.P[f'fc.{k}.bias'], None, None, fa['b'][k], NC, d[4])
+        # the heads are independent chains of mostly small launches: with GAEXT_HEAD_STREAMS=n > 1 head k runs on side
+        # stream k % n (between a fork / join of the plan) with its own transient buffers
+        self.head_lanes = int(os.environ.get('GAEXT_HEAD_STREAMS', '3')) if self.shared_tok else 1
         for k in range(K):
+            if self.head_lanes > 1:
+                F.lane, self.tmp_prefix = 1 + k % self.head_lanes, f'h{k}.'
             self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
+        F.lane, self.tmp_prefix = 0, ''
         F.gemm(fa['x'], fa['W'], self.logits, B, NC, d[4], dt, batch=K, strideA=B * d[4], strideB=NC * d[4], strideC=B * NC,
                bias=fa['b'], strideBias=NC, c_f32=True, label='fc.all')
         # ---------------- backward ----------------
@@ -739,9 +747,6 @@ class GAEngine:
             dg1, db1 = self.grad(pre + 'norm1.weight'), self.grad(pre + 'norm1.bias')
             tk = self.tok
             E2 = tk['E2']
-            if first:      # gradients of all heads' token k|v rows / stacked effective weights: consumed after the loop
-                tk['dkv'] = self.tmp('dkv_all', (M4, tk['ld']))
-                tk['G'], tk['gb'] = self.gbuf((tk['ld'], cout)), self.gbuf((tk['ld'],))
             dkvc = self.tmp('dkvc', (B, E2))
             dkvt = tk['dkv'][:, k * E2:]
             Bk.class_attn_bwd2(dao, h['q'], h['kvc'], h['kvt'], h['P'], dq, dkvc, dkvt, B, N + 1, nh, hd, h['scale'], dt,
@@ -794,8 +799,6 @@ class GAEngine:
         # gram_contraction BN backward into this head's column slice; the conv's wgrad / dgrad run once for all heads
         pre = f'gram_contraction.{k}.'
         gcn = self.gcon
-        if first:
-            gcn['dout'] = self.tmp('dgc_all', (M4, gcn['ld']))
         self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], gcn['dout'][:, k * g:], M4, g, ldx=gcn['ld'], lddx=gcn['ld'])
 
     # ------------------------------------------------------------------------------------------
@@ -819,8 +822,16 @@ class GAEngine:
         fa['dx'] = self.tmp('dcls2_all', (K, B, d[4]))
         Bk.gemm(self.dlogits, fa['WT'], fa['dx'], B, d[4], NC, dt, batch=K, strideA=B * NC, strideB=d[4] * pad8(NC),
                 ldb=pad8(NC), strideC=B * d[4], label='fc.all.dg')
+        if self.shared_tok:     # written slice-wise by the heads, consumed after the loop
+            tk = self.tok
+            tk['dkv'] = self.tmp('dkv_all', (M4, tk['ld']))
+            tk['G'], tk['gb'] = self.gbuf((tk['ld'], d[4])), self.gbuf((tk['ld'],))
+        self.gcon['dout'] = self.tmp('dgc_all', (M4, self.gcon['ld']))
         for k in range(K):
+            if self.head_lanes > 1:
+                Bk.lane, self.tmp_prefix = 1 + k % self.head_lanes, f'h{k}.'
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
+        Bk.lane, self.tmp_prefix = 0, ''
         # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
         gcn, g_ = self.gcon, cfg['gram_dim']
         Gc, gbc = self.gbuf((gcn['ld'], d[4])), self.gbuf((gcn['ld'],))

@@ -46,6 +46,20 @@ def current_stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+_SIDE_POOL = {}    # device index -> (side streams, their "done" events, fork event): shared by every plan of the process
+
+
+def _side_pool(n):
+    dev = torch.cuda.current_device()
+    streams, done, fork = _SIDE_POOL.get(dev, ([], [], None))
+    while len(streams) < n:
+        streams.append(torch.cuda.Stream())
+        done.append(torch.cuda.Event())
+    fork = fork or torch.cuda.Event()
+    _SIDE_POOL[dev] = (streams, done, fork)
+    return streams, done, fork
+
+
 class Plan:
     def __init__(self, eager=False, name='', defer_small=False):
         self.lib = L.load()
@@ -58,6 +72,12 @@ class Plan:
         # as ONE batched launch per kind over a device-resident descriptor array
         self.defer = defer_small and not eager
         self._pend = {'wprep': [], 'small': [], 'unfold': []}
+        # lanes: calls recorded while lane > 0 form a PARALLEL REGION -- independent chains (the five GA heads) that
+        # run() puts on side streams between a fork (side streams wait for the main stream) and a join (the main stream
+        # waits for them).  Lane 0 is the stream run() is called on.
+        self.lane = 0
+        self.lanes = []      # lane of every call
+        self._side = None    # number of side lanes (streams come from a process-wide pool)
 
     def flush(self, label=''):
         for kind, fname, cls in (('wprep', 'ga_weight_prep_batch', L.WprepDesc), ('small', 'ga_small_batch', L.SmallDesc),
@@ -80,6 +100,7 @@ class Plan:
     def _add(self, fname, args, label=None, keep=()):
         fn = getattr(self.lib, fname)
         self.calls.append((fn, args, label or fname))
+        self.lanes.append(self.lane)
         self.keep.extend(keep)
         if self.eager:
             L.check(fn(*args, current_stream_ptr()), label or fname)
@@ -92,10 +113,43 @@ class Plan:
                 L.check(fn(*args, s), f'{self.name}:{label}')
                 torch.cuda.synchronize()
             return
+        if any(self.lanes):
+            return self._run_lanes(0, len(self.calls))
         for fn, args, label in self.calls:
             rc = fn(*args, s)
             if rc != 0:
                 L.check(rc, f'{self.name}:{label}')
+
+    def _run_lanes(self, start, end):
+        """calls[start:end] with the parallel regions on side streams (the current torch stream is lane 0)"""
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = max(self.lanes)
+        streams, done, fork = _side_pool(self._side)
+        s0 = main.cuda_stream
+        used = []
+        for i in range(start, end):
+            fn, args, label = self.calls[i]
+            lane = self.lanes[i]
+            if lane == 0:
+                if used:                          # join: everything after this point sees the side streams' work
+                    for ln in used:
+                        done[ln - 1].record(streams[ln - 1])
+                        main.wait_event(done[ln - 1])
+                    used = []
+                rc = fn(*args, s0)
+            else:
+                if not used:                      # fork: the side streams start from the main stream's current point
+                    fork.record(main)
+                if lane not in used:
+                    streams[lane - 1].wait_event(fork)
+                    used.append(lane)
+                rc = fn(*args, streams[lane - 1].cuda_stream)
+            if rc != 0:
+                L.check(rc, f'{self.name}:{label}')
+        for ln in used:                           # a region that runs to the end of the range
+            done[ln - 1].record(streams[ln - 1])
+            main.wait_event(done[ln - 1])
 
     def __len__(self):
         return len(self.calls)
@@ -106,6 +160,8 @@ class Plan:
 
     def run_range(self, start, end, stream=None):
         s = current_stream_ptr() if stream is None else stream
+        if any(self.lanes[start:end]):
+            return self._run_lanes(start, end)
         for fn, args, label in self.calls[start:end]:
             rc = fn(*args, s)
             if rc != 0:
