@@ -217,8 +217,10 @@ enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_FC1 = 1, EPI_FC2 = 2, EPI_DG2 = 3 };
 // staging area of the epilogue, one barrier per slab; the stream of slabs runs across tile boundaries, so the first
 // slab of the next tile lands while this tile's epilogue runs.  No staging registers and no ds_write pass: with
 // register staging the 8 ds_write_b128 per thread and slab (~79 B/clk/CU) cost more LDS time than the MFMAs take.
+// 96-column tiles without the epilogue prefetch fit 168 VGPRs without spilling: three resident workgroups per CU
+// instead of two (same-box A/B: -0.2 ms/step; the 128-column forms spill at that bound and lose)
 template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI, bool DMA = false>
-__global__ __launch_bounds__(128 * NWM) void gemm_nt_kernel(const ga_gemm_desc d) {
+__global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 && sizeof(T) == 2 && TNW == 3) ? 3 : 1) void gemm_nt_kernel(const ga_gemm_desc d) {
 #define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
 #define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
 #define F_C2 (EPI < 0 ? d.C2 != nullptr : EPI == EPI_FC1)

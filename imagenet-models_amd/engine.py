@@ -20,7 +20,7 @@ import os
 import torch
 
 from . import ops
-from .ops import (A_CONV3, A_PATCH2, A_STEM4_NCHW, ACT_GELU, C_UNPATCH2, GA_BF16, GA_F32, Plan)
+from .ops import (A_CONV3, A_PATCH2, A_STEM4_NCHW, ACT_GELU, ASYNC_LANE, C_UNPATCH2, GA_BF16, GA_F32, Plan)
 
 
 def pad8(n):
@@ -66,6 +66,8 @@ class GAEngine:
         self.Bf = dict(model.named_buffers())
         self.bufs = {}
         self.tmps = {}
+        # trunk weight-gradient launches on the backward plan's asynchronous lane (GAEXT_ASYNC_WGRAD=0: in line)
+        self.async_wgrad = os.environ.get('GAEXT_ASYNC_WGRAD', '1') != '0'
         self.W = {}
         self.weights_dirty = True
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
@@ -391,24 +393,38 @@ class GAEngine:
         M = B * res * res
         dp = self.dp_scale.get(pre)
         dyz = dy
+        if self.async_wgrad and Bk.lane == 0:
+            Bk.join_async()
         if dp is not None:
             dyz = self.tmp('dyz', (M, C))
             Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
+        # the weight-gradient launches read only what the dgrad chain has already produced and nothing on the chain
+        # reads their results: on the trunk they go to the plan's asynchronous lane and fill the tails of the chain's
+        # launches (the next block joins before it overwrites dyz / dh / du)
+        side = self.async_wgrad and Bk.lane == 0
+        wl = ASYNC_LANE if side else Bk.lane
+        ml = Bk.lane
         G2, gb2 = self.gbuf((C, 4 * C)), self.gbuf((C,))
+        Bk.lane = wl
         Bk.wgrad(dyz, b['a'], G2, M, C, 4 * C, dt, dbias=gb2, label=pre + 'wg2')
+        Bk.lane = ml
         dh = self.tmp('dh', (M, 4 * C))
         gb1 = self.gbuf((4 * C,))
         Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['g'], ldh=4 * C, h_is_deriv=True, colsum=gb1,
                 label=pre + 'dg2')
         G1 = self.gbuf((4 * C, C))
+        Bk.lane = wl
         Bk.wgrad(dh, b['xn'], G1, M, 4 * C, C, dt, label=pre + 'wg1')
+        Bk.lane = ml
         g = self.tmp('g', (M, C))
         Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], g, M, C, 4 * C, dt, label=pre + 'dg1')
         du = self.tmp('du', (M, C))
         Bk.layernorm_bwd(g, b['xn'], None, b['rstd'], None, None, du, None, None, M, C, True, dt, label=pre + 'lnb')
-        Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, label=pre + 'dwd')
         dw49 = self.gbuf((49, C))
+        Bk.lane = wl
         Bk.dwconv7_bwd_weight(du, b['x'], dw49, self.grad(pre + 'conv_dw.bias'), B, res, res, C, dt, label=pre + 'dww')
+        Bk.lane = ml
+        Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, label=pre + 'dwd')
         Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
                          rs=P[pre + 'gamma'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
                          d_rs=self.grad(pre + 'gamma'), label=pre + 'unf2')
@@ -901,6 +917,8 @@ class GAEngine:
                                  seed[i - 1], dprev, self.grad(pre + '0.weight'), self.grad(pre + '0.bias'), Mp, d[i - 1],
                                  False, dt, label=pre + 'lnb')
                 dy = dprev
+            if self.async_wgrad:
+                Bk.join_async()
             Bk.flush(f'stage{i}.')
             Bk.mark(f'stage{i}')  # gradients of stages.i (incl. its downsample) are final
         # stem

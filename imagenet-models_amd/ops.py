@@ -60,6 +60,24 @@ def _side_pool(n):
     return streams, done, fork
 
 
+_ASYNC_POOL = {}   # device index -> (stream, done event, fork event) of the asynchronous lane
+
+
+def _async_pool():
+    dev = torch.cuda.current_device()
+    if dev not in _ASYNC_POOL:
+        _ASYNC_POOL[dev] = (torch.cuda.Stream(), torch.cuda.Event(), torch.cuda.Event())
+    return _ASYNC_POOL[dev]
+
+
+def _join_marker(*_):
+    """pseudo call recorded by Plan.join_async(); a no-op wherever a plan's calls are replayed one by one"""
+    return 0
+
+
+ASYNC_LANE = -1
+
+
 class Plan:
     def __init__(self, eager=False, name='', defer_small=False):
         self.lib = L.load()
@@ -75,6 +93,9 @@ class Plan:
         # lanes: calls recorded while lane > 0 form a PARALLEL REGION -- independent chains (the five GA heads) that
         # run() puts on side streams between a fork (side streams wait for the main stream) and a join (the main stream
         # waits for them).  Lane 0 is the stream run() is called on.
+        # Lane -1 (ASYNC_LANE) is different: such a call runs on ONE extra stream after everything recorded before it on
+        # lane 0, and lane 0 does not wait for it until join_async() (or the end of the range being run).  The trunk's
+        # weight-gradient launches go there: nothing on the dgrad chain reads their results.
         self.lane = 0
         self.lanes = []      # lane of every call
         self._side = None    # number of side lanes (streams come from a process-wide pool)
@@ -120,18 +141,40 @@ class Plan:
             if rc != 0:
                 L.check(rc, f'{self.name}:{label}')
 
+    def join_async(self):
+        """lane 0 waits here for everything recorded on the asynchronous lane so far"""
+        self.calls.append((_join_marker, (), 'join_async'))
+        self.lanes.append(0)
+
     def _run_lanes(self, start, end):
         """calls[start:end] with the parallel regions on side streams (the current torch stream is lane 0)"""
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = max(self.lanes)
+            self._side = max(max(self.lanes), 0)
         streams, done, fork = _side_pool(self._side)
+        astream, adone, afork = _async_pool()
+        apend = False
         s0 = main.cuda_stream
         used = []
+
+        def ajoin():
+            adone.record(astream)
+            main.wait_event(adone)
+
         for i in range(start, end):
             fn, args, label = self.calls[i]
             lane = self.lanes[i]
-            if lane == 0:
+            if fn is _join_marker:
+                if apend:
+                    ajoin()
+                    apend = False
+                continue
+            if lane == ASYNC_LANE:
+                afork.record(main)
+                astream.wait_event(afork)
+                apend = True
+                rc = fn(*args, astream.cuda_stream)
+            elif lane == 0:
                 if used:                          # join: everything after this point sees the side streams' work
                     for ln in used:
                         done[ln - 1].record(streams[ln - 1])
@@ -140,6 +183,9 @@ class Plan:
                 rc = fn(*args, s0)
             else:
                 if not used:                      # fork: the side streams start from the main stream's current point
+                    if apend:
+                        ajoin()
+                        apend = False
                     fork.record(main)
                 if lane not in used:
                     streams[lane - 1].wait_event(fork)
@@ -150,6 +196,8 @@ class Plan:
         for ln in used:                           # a region that runs to the end of the range
             done[ln - 1].record(streams[ln - 1])
             main.wait_event(done[ln - 1])
+        if apend:
+            ajoin()
 
     def __len__(self):
         return len(self.calls)
