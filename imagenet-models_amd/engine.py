@@ -15,6 +15,7 @@ block output of fc1 as a = gelu(h) and g = gelu'(h) (both written by the fc1 epi
 Reference semantics restated here: /root/reference/GA/ga_convnext.py:98-112 (block), :139-150 (stage + taps),
 :294-318 (Bottleneck), :452-467 (get_gram), :153-248 (class attention block), :469-505 (forward).
 """
+import contextlib
 import os
 
 import torch
@@ -109,6 +110,19 @@ class GAEngine:
         t = self.bufs[name]
         assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, name
         return t
+
+    @contextlib.contextmanager
+    def _wlane(self):
+        """weight-gradient launches recorded inside go to the backward plan's asynchronous lane (trunk / shared parts
+        only: inside a head's lane they stay in that lane)"""
+        Bk = self.bwd
+        prev = Bk.lane
+        if self.async_wgrad and prev == 0:
+            Bk.lane = ASYNC_LANE
+        try:
+            yield
+        finally:
+            Bk.lane = prev
 
     def tmp(self, tag, shape, dtype=None):
         """transient buffer shared by every call site with the same (tag, shape, dtype) -- stream order makes it safe"""
@@ -305,6 +319,8 @@ class GAEngine:
         # ---------------- backward ----------------
         if T:
             self._build_backward(feats, taps, stage_in, x4, M4, ctot)
+            if self.async_wgrad:
+                self.bwd.join_async()
             self.bwd.flush('end.')
         self.prep.flush('prep.')
 
@@ -526,7 +542,8 @@ class GAEngine:
         dsc = self.tmp('bott.dsc', (M4, cout))
         self._bn_bwd(pre + 'downsample.1.', st['bnd'], dx4, st['x4'], st['sc'], dsc, M4, cout)
         # conv3
-        Bk.wgrad(dc3, st['z'], self.grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
+        with self._wlane():
+            Bk.wgrad(dc3, st['z'], self.grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
         dz = self.tmp('bott.dz', (M4, w))
         Bk.gemm(dc3, W[pre + 'conv3.weight.T'], dz, M4, w, cout, dt, label=pre + 'conv3.dg')
         # squeeze-excite
@@ -542,7 +559,8 @@ class GAEngine:
         self._bn_bwd(pre + 'bn2.', st['bn2'], dy2, st['y2'], st['c2'], dc2, M4, w)
         # conv2 3x3
         G = self.gbuf((w, 9 * w))
-        Bk.wgrad(dc2, st['y1'], G, M4, w, 9 * w, dt, x_kind=A_CONV3, x_dims=(14, 14, w), label=pre + 'conv2.wg')
+        with self._wlane():
+            Bk.wgrad(dc2, st['y1'], G, M4, w, 9 * w, dt, x_kind=A_CONV3, x_dims=(14, 14, w), label=pre + 'conv2.wg')
         Bk.weight_unfold(G, 9 * w, w, w, 3, 3, dW=self.grad(pre + 'conv2.weight'), label=pre + 'conv2.unf')
         dy1 = self.tmp('bott.dy1', (M4, w))
         Bk.gemm(dc2, W[pre + 'conv2.weight.T'], dy1, M4, w, 9 * w, dt, a_kind=A_CONV3, a_dims=(14, 14, w),
@@ -550,10 +568,12 @@ class GAEngine:
         dc1 = self.tmp('bott.dc1', (M4, w))
         self._bn_bwd(pre + 'bn1.', st['bn1'], dy1, st['y1'], st['c1'], dc1, M4, w)
         # conv1 and the shortcut conv both read `cat`
-        Bk.wgrad(dc1, st['cat'], self.grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
+        with self._wlane():
+            Bk.wgrad(dc1, st['cat'], self.grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
         Bk.gemm(dc1, W[pre + 'conv1.weight.T'], dcat, M4, ctot, w, dt, ldb=pad8(w), label=pre + 'conv1.dg')
-        Bk.wgrad(dsc, st['cat'], self.grad(pre + 'downsample.0.weight'), M4, cout, ctot, dt,
-                 dbias=self.grad(pre + 'downsample.0.bias'), label=pre + 'ds.wg')
+        with self._wlane():
+            Bk.wgrad(dsc, st['cat'], self.grad(pre + 'downsample.0.weight'), M4, cout, ctot, dt,
+                     dbias=self.grad(pre + 'downsample.0.bias'), label=pre + 'ds.wg')
         Bk.gemm(dsc, W[pre + 'downsample.0.weight.T'], dcat, M4, ctot, cout, dt, ldb=pad8(cout), R=dcat, ldr=ctot,
                 label=pre + 'ds.dg')
 
@@ -851,7 +871,8 @@ class GAEngine:
         # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
         gcn, g_ = self.gcon, cfg['gram_dim']
         Gc, gbc = self.gbuf((gcn['ld'], d[4])), self.gbuf((gcn['ld'],))
-        Bk.wgrad(gcn['dout'], x4, Gc, M4, gcn['ld'], d[4], dt, dbias=gbc, label='gram_contraction.all.wg')
+        with self._wlane():
+            Bk.wgrad(gcn['dout'], x4, Gc, M4, gcn['ld'], d[4], dt, dbias=gbc, label='gram_contraction.all.wg')
         for k in range(K):
             pre = f'gram_contraction.{k}.'
             Bk.axpy_f32(self.grad(pre + '0.weight'), Gc[k * g_:], 1.0, g_ * d[4])
@@ -863,7 +884,8 @@ class GAEngine:
             tk = self.tok
             E2 = tk['E2']
             # token rows of all heads at once: effective k|v weight gradients, then each head's norm1 fold undone ...
-            Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], d[4], dt, dbias=tk['gb'], label='ga.kv_all.wg')
+            with self._wlane():
+                Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], d[4], dt, dbias=tk['gb'], label='ga.kv_all.wg')
             for k in range(K):
                 pre = f'ga.{k}.'
                 Bk.weight_unfold(tk['G'][k * E2:], d[4], E2, d[4], gb=tk['gb'][k * E2:], W=P[pre + 'attn.k.weight'],
@@ -875,6 +897,8 @@ class GAEngine:
             Bk.layernorm_bwd(dxt, tk['xn'], None, tk['rstd'], None, dx4, dx4, None, None, M4, d[4], True, dt, label='ga.tok.lnb')
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
+        if self.async_wgrad:
+            Bk.join_async()
         Bk.flush('heads.')
         Bk.mark('heads')      # every gradient of stages.4 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
@@ -906,8 +930,9 @@ class GAEngine:
                 x_prev, Hp = stage_in[i - 1]
                 Mp = B * Hp * Hp
                 G = self.gbuf((d[i], 4 * d[i - 1]))
-                Bk.wgrad(dy, self.bufs[pre + 'ln'], G, Mi, d[i], 4 * d[i - 1], dt, x_kind=A_PATCH2,
-                         x_dims=(Hp, Hp, d[i - 1]), dbias=self.grad(pre + '1.bias'), label=pre + 'wg')
+                with self._wlane():
+                    Bk.wgrad(dy, self.bufs[pre + 'ln'], G, Mi, d[i], 4 * d[i - 1], dt, x_kind=A_PATCH2,
+                             x_dims=(Hp, Hp, d[i - 1]), dbias=self.grad(pre + '1.bias'), label=pre + 'wg')
                 Bk.weight_unfold(G, 4 * d[i - 1], d[i], d[i - 1], 2, 2, dW=self.grad(pre + '1.weight'), label=pre + 'unf')
                 dln = self.tmp('dln', (Mp, d[i - 1]))
                 Bk.gemm(dy, W[pre + '1.weight.T'], dln, Mi, 4 * d[i - 1], d[i], dt, ldb=pad8(d[i]), c_kind=C_UNPATCH2,
@@ -926,8 +951,9 @@ class GAEngine:
         dpre = self.tmp('dstem', (M0, d[0]))
         Bk.layernorm_bwd(dy, self.bufs['stem.pre'], self.bufs['stem.mean'], self.bufs['stem.rstd'], P['stem.1.weight'], None,
                          dpre, self.grad('stem.1.weight'), self.grad('stem.1.bias'), M0, d[0], False, dt, label='stem.lnb')
-        Bk.wgrad(dpre, self.x_placeholder, self.grad('stem.0.weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
-                 x_dims=(self.img, self.img, 3), dbias=self.grad('stem.0.bias'), label='stem.wg')
+        with self._wlane():
+            Bk.wgrad(dpre, self.x_placeholder, self.grad('stem.0.weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
+                     x_dims=(self.img, self.img, 3), dbias=self.grad('stem.0.bias'), label='stem.wg')
         self.input_descs.append(self._last_desc(Bk))
 
     # ------------------------------------------------------------------------------------------

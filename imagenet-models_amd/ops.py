@@ -170,6 +170,11 @@ class Plan:
                     apend = False
                 continue
             if lane == ASYNC_LANE:
+                if used:                          # the asynchronous lane starts from lane 0's point: close the region first
+                    for ln in used:
+                        done[ln - 1].record(streams[ln - 1])
+                        main.wait_event(done[ln - 1])
+                    used = []
                 afork.record(main)
                 astream.wait_event(afork)
                 apend = True
