@@ -69,6 +69,9 @@ class GAEngine:
         self.tmps = {}
         # trunk weight-gradient launches on the backward plan's asynchronous lane (GAEXT_ASYNC_WGRAD=0: in line)
         self.async_wgrad = os.environ.get('GAEXT_ASYNC_WGRAD', '1') != '0'
+        self.fwd_split = max(1, int(os.environ.get('GAEXT_FWD_SPLIT', '2')))
+        self.fwd_split_from = int(os.environ.get('GAEXT_FWD_SPLIT_FROM', '0'))   # first trunk stage that is split
+        self._cur_stage = 0
         self.W = {}
         self.weights_dirty = True
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
@@ -110,6 +113,17 @@ class GAEngine:
         t = self.bufs[name]
         assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, name
         return t
+
+    def _fsplits(self, HW):
+        """(lane, first row, end row, first image, end image) of the forward trunk's independent batch parts: with
+        GAEXT_FWD_SPLIT=n > 1 stages 0-3 run as n chains on side streams (rows of different images never mix before
+        the stage-4 BatchNorm), so that one chain's launches fill the tails of the other's"""
+        n = self.fwd_split if self.B >= 2 * self.fwd_split and self._cur_stage >= self.fwd_split_from else 1
+        if n <= 1:
+            return [(0, 0, self.B * HW, 0, self.B)]
+        per = self.B // n
+        cuts = [s_ * per for s_ in range(n)] + [self.B]
+        return [(1 + s_, cuts[s_] * HW, cuts[s_ + 1] * HW, cuts[s_], cuts[s_ + 1]) for s_ in range(n)]
 
     @contextlib.contextmanager
     def _wlane(self):
@@ -206,6 +220,7 @@ class GAEngine:
         res = S0
         stage_in = []
         for i in range(4):
+            self._cur_stage = i
             if i > 0:
                 Hp = res
                 res //= 2
@@ -215,12 +230,15 @@ class GAEngine:
                 ln = self.act(pre + 'ln', (Mp, d[i - 1]))
                 mean = self.act(pre + 'mean', (Mp,), torch.float32)
                 rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
-                F.layernorm_fwd(x, self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln, mean, rstd, Mp, d[i - 1], 1e-6, dt,
-                                label=pre + 'ln')
                 Wd = self._w_plain(pre + '1.weight', d[i], d[i - 1], 2, 2)
                 xo = self.buf(pre + 'out', (Mi, d[i]))
-                F.gemm(ln, Wd, xo, Mi, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2, a_dims=(Hp, Hp, d[i - 1]),
-                       bias=self.P[pre + '1.bias'], label=pre + 'conv')
+                for lane, r0, r1, b0, b1 in self._fsplits(Hp * Hp):
+                    F.lane = lane
+                    F.layernorm_fwd(x[r0:r1], self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln[r0:r1], mean[r0:r1],
+                                    rstd[r0:r1], r1 - r0, d[i - 1], 1e-6, dt, label=pre + 'ln')
+                    F.gemm(ln[r0:r1], Wd, xo[r0 // 4:r1 // 4], (r1 - r0) // 4, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2,
+                           a_dims=(Hp, Hp, d[i - 1]), bias=self.P[pre + '1.bias'], label=pre + 'conv')
+                F.lane = 0
                 stage_in.append((x, Hp))
                 x = xo
             tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
@@ -385,19 +403,26 @@ class GAEngine:
         self._block_weights(pre, C)
         W = self.W
         u = self.tmp('u', (M, C))
-        F.dwconv7_fwd(x, W[pre + 'w49'], self.P[pre + 'conv_dw.bias'], u, B, res, res, C, dt, label=pre + 'dw')
         xn = self.blk_act(pre + 'xn', (M, C))
         rstd = self.blk_act(pre + 'rstd', (M,), torch.float32)
-        F.layernorm_fwd(u, None, None, xn, None, rstd, M, C, 1e-6, dt, label=pre + 'ln')
         # fc1 stores a = gelu(h) and, when training, g = gelu'(h): backward never re-evaluates erf, and neither the
         # fc2 operand loader nor the wgrad loader has to (they used to, once per N tile)
         a = self.blk_act(pre + 'a', (M, 4 * C))
         g = self.buf(pre + 'g', (M, 4 * C)) if self.training else None
-        F.gemm(xn, W[pre + 'mlp.fc1.weight'], a, M, 4 * C, C, dt, bias=W[pre + 'b1e'], act=ACT_GELU, C2=g,
-               c2_mode=2 if g is not None else 0, label=pre + 'fc1')
         y = self.buf(pre + 'y', (M, C))
-        F.gemm(a, W[pre + 'mlp.fc2.weight'], y, M, C, 4 * C, dt, bias=W[pre + 'b2e'],
-               rowscale=self.dp_scale.get(pre), rows_per_scale=res * res, R=x, ldr=C, label=pre + 'fc2')
+        dp = self.dp_scale.get(pre)
+        cur = F.lane      # inside a head's lane: one chain in that lane
+        for lane, r0, r1, b0, b1 in (self._fsplits(res * res) if cur == 0 else [(cur, 0, M, 0, B)]):
+            F.lane = lane
+            F.dwconv7_fwd(x[r0:r1], W[pre + 'w49'], self.P[pre + 'conv_dw.bias'], u[r0:r1], b1 - b0, res, res, C, dt,
+                          label=pre + 'dw')
+            F.layernorm_fwd(u[r0:r1], None, None, xn[r0:r1], None, rstd[r0:r1], r1 - r0, C, 1e-6, dt, label=pre + 'ln')
+            F.gemm(xn[r0:r1], W[pre + 'mlp.fc1.weight'], a[r0:r1], r1 - r0, 4 * C, C, dt, bias=W[pre + 'b1e'], act=ACT_GELU,
+                   C2=g[r0:r1] if g is not None else None, c2_mode=2 if g is not None else 0, label=pre + 'fc1')
+            F.gemm(a[r0:r1], W[pre + 'mlp.fc2.weight'], y[r0:r1], r1 - r0, C, 4 * C, dt, bias=W[pre + 'b2e'],
+                   rowscale=dp[b0:b1] if dp is not None else None, rows_per_scale=res * res, R=x[r0:r1], ldr=C,
+                   label=pre + 'fc2')
+        F.lane = cur
         self.blocks[pre] = dict(x=x, xn=xn, rstd=rstd, a=a, g=g, y=y, res=res, C=C)
         return y
 
