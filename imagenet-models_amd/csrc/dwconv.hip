@@ -893,8 +893,9 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             const char* e = getenv("GAEXT_DW_MFMA");        // 0: never, 1: heuristic (default), 2: every 14 x 14-tiled launch
             const int use_mfma = e ? atoi(e) : 1;           // read per call so that a test can switch it
             // the MFMA form pays a long prologue (Toeplitz fragments) per workgroup: ahead of the dot2 form only when
-            // a workgroup walks many tiles (56 x 56 maps: 0.169 vs 0.192 ms; 28 x 28 and 14 x 14: 5-10 % behind)
-            const bool many = ntiles * cdiv(C, DWM::CS) >= 32L * num_cus();
+            // a workgroup walks many tiles (56 x 56 maps, also as half batches: 0.169 vs 0.192 ms; 28 x 28 and 14 x 14:
+            // 5-10 % behind)
+            const bool many = H * W >= 56 * 56 && ntiles * cdiv(C, DWM::CS) >= 16L * num_cus();
             if (big && (use_mfma == 2 || (use_mfma == 1 && many))) {
                 const int slm = cdiv(C, DWM::CS);
                 const int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));

@@ -1278,7 +1278,11 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
         GA_REQUIRE(attr_ok, "ga_wgrad: cannot reserve %d bytes of LDS", kTn2Smem);
         const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
         const int stages = d->M / 32;
-        int split = std::max(1, std::min(stages / 8, num_cus() / tiles));         // one workgroup per CU
+        static const int wg_budget = [] { const char* e = getenv("GAEXT_TN2_WGS"); return e ? atoi(e) : 0; }();
+        // 3/4 of the CUs: in the train step these launches share the chip with the dgrad chain (asynchronous lane), and
+        // fewer row splits mean fewer partial tiles to write and reduce (same-box A/B: 192 vs 256 workgroups -0.13 ms/step)
+        const int cus = wg_budget > 0 ? wg_budget : num_cus() * 3 / 4;
+        int split = std::max(1, std::min(stages / 8, cus / tiles));               // one workgroup per CU
         split = cdiv(stages, cdiv(stages, split));                                // no empty row range
         dim3 grid2(cdiv(d->N, 256) * cdiv(d->K, 256) * split, 1, d->batch), block2(kTn2Threads);
         float* part = nullptr;

@@ -72,6 +72,7 @@ class GAEngine:
         self.fwd_split = max(1, int(os.environ.get('GAEXT_FWD_SPLIT', '2')))
         self.fwd_split_from = int(os.environ.get('GAEXT_FWD_SPLIT_FROM', '0'))   # first trunk stage that is split
         self._cur_stage = 0
+        self._bwd_seq = 0        # trunk blocks recorded on the backward plan so far
         self.W = {}
         self.weights_dirty = True
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
@@ -326,7 +327,7 @@ class GAEngine:
             self.prep.bias_fold(None, self.P[f'fc.{k}.bias'], None, None, fa['b'][k], NC, d[4])
         # the heads are independent chains of mostly small launches: with GAEXT_HEAD_STREAMS=n > 1 head k runs on side
         # stream k % n (between a fork / join of the plan) with its own transient buffers
-        self.head_lanes = int(os.environ.get('GAEXT_HEAD_STREAMS', '3')) if self.shared_tok else 1
+        self.head_lanes = int(os.environ.get('GAEXT_HEAD_STREAMS', '5')) if self.shared_tok else 1
         for k in range(K):
             if self.head_lanes > 1:
                 F.lane, self.tmp_prefix = 1 + k % self.head_lanes, f'h{k}.'
@@ -434,10 +435,15 @@ class GAEngine:
         M = B * res * res
         dp = self.dp_scale.get(pre)
         dyz = dy
+        par = ''
         if self.async_wgrad and Bk.lane == 0:
-            Bk.join_async()
+            # two sets of the transients the weight-gradient launches read (dyz, dh, du; the caller rotates three dx
+            # buffers): this block only has to wait for the asynchronous launches of the block before the previous one
+            self._bwd_seq += 1
+            par = str(self._bwd_seq & 1)
+            Bk.join_async(f'blk{self._bwd_seq - 2}')
         if dp is not None:
-            dyz = self.tmp('dyz', (M, C))
+            dyz = self.tmp('dyz' + par, (M, C))
             Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
         # the weight-gradient launches read only what the dgrad chain has already produced and nothing on the chain
         # reads their results: on the trunk they go to the plan's asynchronous lane and fill the tails of the chain's
@@ -449,7 +455,7 @@ class GAEngine:
         Bk.lane = wl
         Bk.wgrad(dyz, b['a'], G2, M, C, 4 * C, dt, dbias=gb2, label=pre + 'wg2')
         Bk.lane = ml
-        dh = self.tmp('dh', (M, 4 * C))
+        dh = self.tmp('dh' + par, (M, 4 * C))
         gb1 = self.gbuf((4 * C,))
         Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['g'], ldh=4 * C, h_is_deriv=True, colsum=gb1,
                 label=pre + 'dg2')
@@ -459,12 +465,14 @@ class GAEngine:
         Bk.lane = ml
         g = self.tmp('g', (M, C))
         Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], g, M, C, 4 * C, dt, label=pre + 'dg1')
-        du = self.tmp('du', (M, C))
+        du = self.tmp('du' + par, (M, C))
         Bk.layernorm_bwd(g, b['xn'], None, b['rstd'], None, None, du, None, None, M, C, True, dt, label=pre + 'lnb')
         dw49 = self.gbuf((49, C))
         Bk.lane = wl
         Bk.dwconv7_bwd_weight(du, b['x'], dw49, self.grad(pre + 'conv_dw.bias'), B, res, res, C, dt, label=pre + 'dww')
         Bk.lane = ml
+        if side:
+            Bk.async_mark(f'blk{self._bwd_seq}')
         Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, label=pre + 'dwd')
         Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
                          rs=P[pre + 'gamma'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
@@ -942,12 +950,14 @@ class GAEngine:
         for i in (3, 2, 1, 0):
             res = feats[i][1]
             Mi = B * res * res
-            pp = [self.tmp(f'dxA{i}', (Mi, d[i])), self.tmp(f'dxB{i}', (Mi, d[i]))]
+            pp = [self.tmp(f'dxA{i}', (Mi, d[i])), self.tmp(f'dxB{i}', (Mi, d[i])), self.tmp(f'dxC{i}', (Mi, d[i]))]
+            turn = 0
             for j in reversed(range(dep[i])):
                 if i == 2 and j in tap_at:
                     dtap = d_taps[tap_at.index(j)]
                     Bk.affine_act(dy, None, None, dtap, dy, Mi, d[i], False, dt, label=f'tap.add.{j}')
-                dx = pp[0] if dy is not pp[0] else pp[1]
+                dx = pp[turn % 3]          # not this block's dy nor the previous block's (still read by its wgrad)
+                turn += 1
                 self._block_bwd(f'stages.{i}.blocks.{j}.', dy, dx)
                 dy = dx
             if i > 0:

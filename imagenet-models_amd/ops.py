@@ -75,6 +75,11 @@ def _join_marker(*_):
     return 0
 
 
+def _amark_marker(*_):
+    """pseudo call recorded by Plan.async_mark(): a named point of the asynchronous lane that join_async(tag) waits for"""
+    return 0
+
+
 ASYNC_LANE = -1
 
 
@@ -99,6 +104,7 @@ class Plan:
         self.lane = 0
         self.lanes = []      # lane of every call
         self._side = None    # number of side lanes (streams come from a process-wide pool)
+        self._aevents = {}   # async_mark tag -> event
 
     def flush(self, label=''):
         for kind, fname, cls in (('wprep', 'ga_weight_prep_batch', L.WprepDesc), ('small', 'ga_small_batch', L.SmallDesc),
@@ -141,9 +147,13 @@ class Plan:
             if rc != 0:
                 L.check(rc, f'{self.name}:{label}')
 
-    def join_async(self):
-        """lane 0 waits here for everything recorded on the asynchronous lane so far"""
-        self.calls.append((_join_marker, (), 'join_async'))
+    def join_async(self, tag=None):
+        """lane 0 waits here for everything recorded on the asynchronous lane so far (tag: up to async_mark(tag) only)"""
+        self.calls.append((_join_marker, () if tag is None else (tag,), 'join_async'))
+        self.lanes.append(0)
+
+    def async_mark(self, tag):
+        self.calls.append((_amark_marker, (tag,), 'async_mark'))
         self.lanes.append(0)
 
     def _run_lanes(self, start, end):
@@ -154,6 +164,7 @@ class Plan:
         streams, done, fork = _side_pool(self._side)
         astream, adone, afork = _async_pool()
         apend = False
+        aev = {}                                  # named points recorded in THIS run (a range may start after a mark)
         s0 = main.cuda_stream
         used = []
 
@@ -165,9 +176,21 @@ class Plan:
             fn, args, label = self.calls[i]
             lane = self.lanes[i]
             if fn is _join_marker:
-                if apend:
+                if args:                          # up to a named point of the asynchronous lane (recorded in this run)
+                    ev = aev.get(args[0])
+                    if ev is not None:
+                        main.wait_event(ev)
+                elif apend:
                     ajoin()
                     apend = False
+                continue
+            if fn is _amark_marker:
+                if apend:
+                    ev = self._aevents.get(args[0])
+                    if ev is None:
+                        ev = self._aevents[args[0]] = torch.cuda.Event()
+                    ev.record(astream)
+                    aev[args[0]] = ev
                 continue
             if lane == ASYNC_LANE:
                 if used:                          # the asynchronous lane starts from lane 0's point: close the region first
