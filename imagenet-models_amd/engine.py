@@ -70,7 +70,8 @@ class GAEngine:
         # trunk weight-gradient launches on the backward plan's asynchronous lane (GAEXT_ASYNC_WGRAD=0: in line)
         self.async_wgrad = os.environ.get('GAEXT_ASYNC_WGRAD', '1') != '0'
         self.fwd_split = max(1, int(os.environ.get('GAEXT_FWD_SPLIT', '2')))
-        self.fwd_split_from = int(os.environ.get('GAEXT_FWD_SPLIT_FROM', '0'))   # first trunk stage that is split
+        self.fwd_skew = int(os.environ.get('GAEXT_FWD_SKEW', '-1'))   # chain k+1 starts when chain k has passed this stage
+        self._chain = None
         self._cur_stage = 0
         self._bwd_seq = 0        # trunk blocks recorded on the backward plan so far
         self.W = {}
@@ -115,16 +116,24 @@ class GAEngine:
         assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, name
         return t
 
-    def _fsplits(self, HW):
-        """(lane, first row, end row, first image, end image) of the forward trunk's independent batch parts: with
-        GAEXT_FWD_SPLIT=n > 1 stages 0-3 run as n chains on side streams (rows of different images never mix before
-        the stage-4 BatchNorm), so that one chain's launches fill the tails of the other's"""
-        n = self.fwd_split if self.B >= 2 * self.fwd_split and self._cur_stage >= self.fwd_split_from else 1
+    def _chains(self):
+        """(lane, first image, end image) of the forward trunk's independent batch parts: with GAEXT_FWD_SPLIT=n > 1
+        stages 0-3 run as n chains on side streams (rows of different images never mix before the stage-4 BatchNorm),
+        so that one chain's launches fill the tails of the other's"""
+        n = self.fwd_split if self.B >= 2 * self.fwd_split else 1
         if n <= 1:
-            return [(0, 0, self.B * HW, 0, self.B)]
+            return [(0, 0, self.B)]
         per = self.B // n
         cuts = [s_ * per for s_ in range(n)] + [self.B]
-        return [(1 + s_, cuts[s_] * HW, cuts[s_ + 1] * HW, cuts[s_], cuts[s_ + 1]) for s_ in range(n)]
+        return [(1 + s_, cuts[s_], cuts[s_ + 1]) for s_ in range(n)]
+
+    def _fsplits(self, HW):
+        """(lane, first row, end row, first image, end image) the current pass of the trunk records"""
+        ch = getattr(self, '_chain', None)
+        if ch is None:
+            return [(0, 0, self.B * HW, 0, self.B)]
+        lane, b0, b1 = ch
+        return [(lane, b0 * HW, b1 * HW, b0, b1)]
 
     @contextlib.contextmanager
     def _wlane(self):
@@ -217,37 +226,50 @@ class GAEngine:
         F.layernorm_fwd(stem_pre, self.P['stem.1.weight'], self.P['stem.1.bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
                         label='stem.ln')
         # ---------------- stages 0..3 ----------------
-        feats, taps = [], []
-        res = S0
-        stage_in = []
-        for i in range(4):
-            self._cur_stage = i
-            if i > 0:
-                Hp = res
-                res //= 2
-                Mi = B * res * res
-                Mp = B * Hp * Hp
-                pre = f'stages.{i}.downsample.'
-                ln = self.act(pre + 'ln', (Mp, d[i - 1]))
-                mean = self.act(pre + 'mean', (Mp,), torch.float32)
-                rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
-                Wd = self._w_plain(pre + '1.weight', d[i], d[i - 1], 2, 2)
-                xo = self.buf(pre + 'out', (Mi, d[i]))
-                for lane, r0, r1, b0, b1 in self._fsplits(Hp * Hp):
-                    F.lane = lane
-                    F.layernorm_fwd(x[r0:r1], self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln[r0:r1], mean[r0:r1],
-                                    rstd[r0:r1], r1 - r0, d[i - 1], 1e-6, dt, label=pre + 'ln')
-                    F.gemm(ln[r0:r1], Wd, xo[r0 // 4:r1 // 4], (r1 - r0) // 4, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2,
-                           a_dims=(Hp, Hp, d[i - 1]), bias=self.P[pre + '1.bias'], label=pre + 'conv')
-                F.lane = 0
-                stage_in.append((x, Hp))
-                x = xo
-            tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
-            for j in range(dep[i]):
-                x = self._block_fwd(f'stages.{i}.blocks.{j}.', x, res, d[i])
-                if j in tap_at:
-                    taps.append(x)
-            feats.append((x, res))
+        # one pass per chain (batch part): with GAEXT_FWD_SPLIT > 1 the chains run on side streams; every pass names
+        # the same full-batch buffers and records its own rows only
+        x_stem = x
+        chains = self._chains()
+        skew_ev = None
+        for ci, chain in enumerate(chains):
+            self._chain = chain if len(chains) > 1 else None
+            if self._chain is not None and skew_ev is not None:
+                F.lane_wait(chain[0], skew_ev)       # start this chain when the previous one has passed stage fwd_skew
+                skew_ev = None
+            feats, taps = [], []
+            x = x_stem
+            res = S0
+            stage_in = []
+            for i in range(4):
+                if i > 0:
+                    Hp = res
+                    res //= 2
+                    Mi = B * res * res
+                    Mp = B * Hp * Hp
+                    pre = f'stages.{i}.downsample.'
+                    ln = self.act(pre + 'ln', (Mp, d[i - 1]))
+                    mean = self.act(pre + 'mean', (Mp,), torch.float32)
+                    rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
+                    Wd = self._w_plain(pre + '1.weight', d[i], d[i - 1], 2, 2)
+                    xo = self.buf(pre + 'out', (Mi, d[i]))
+                    for lane, r0, r1, b0, b1 in self._fsplits(Hp * Hp):
+                        F.lane = lane
+                        F.layernorm_fwd(x[r0:r1], self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln[r0:r1], mean[r0:r1],
+                                        rstd[r0:r1], r1 - r0, d[i - 1], 1e-6, dt, label=pre + 'ln')
+                        F.gemm(ln[r0:r1], Wd, xo[r0 // 4:r1 // 4], (r1 - r0) // 4, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2,
+                               a_dims=(Hp, Hp, d[i - 1]), bias=self.P[pre + '1.bias'], label=pre + 'conv')
+                    F.lane = 0
+                    stage_in.append((x, Hp))
+                    x = xo
+                tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
+                for j in range(dep[i]):
+                    x = self._block_fwd(f'stages.{i}.blocks.{j}.', x, res, d[i])
+                    if j in tap_at:
+                        taps.append(x)
+                feats.append((x, res))
+                if self._chain is not None and i == self.fwd_skew and ci + 1 < len(chains):
+                    skew_ev = F.lane_signal(chain[0])
+        self._chain = None
         # ---------------- aggregate (ga_convnext.py:479-483) ----------------
         Hc = 14
         M4 = B * Hc * Hc

@@ -80,6 +80,16 @@ def _amark_marker(*_):
     return 0
 
 
+def _lsig_marker(*_):
+    """pseudo call of Plan.lane_signal(): an event recorded on a side lane's stream"""
+    return 0
+
+
+def _lwait_marker(*_):
+    """pseudo call of Plan.lane_wait(): a side lane waits for an event of another lane"""
+    return 0
+
+
 ASYNC_LANE = -1
 
 
@@ -152,6 +162,17 @@ class Plan:
         self.calls.append((_join_marker, () if tag is None else (tag,), 'join_async'))
         self.lanes.append(0)
 
+    def lane_signal(self, lane):
+        """a point of side lane `lane` (inside a parallel region) that lane_wait() of another lane can wait for"""
+        ev = torch.cuda.Event()
+        self.calls.append((_lsig_marker, (lane, ev), 'lane_signal'))
+        self.lanes.append(lane)
+        return ev
+
+    def lane_wait(self, lane, ev):
+        self.calls.append((_lwait_marker, (lane, ev), 'lane_wait'))
+        self.lanes.append(lane)
+
     def async_mark(self, tag):
         self.calls.append((_amark_marker, (tag,), 'async_mark'))
         self.lanes.append(0)
@@ -165,6 +186,7 @@ class Plan:
         astream, adone, afork = _async_pool()
         apend = False
         aev = {}                                  # named points recorded in THIS run (a range may start after a mark)
+        lsig = set()
         s0 = main.cuda_stream
         used = []
 
@@ -191,6 +213,20 @@ class Plan:
                         ev = self._aevents[args[0]] = torch.cuda.Event()
                     ev.record(astream)
                     aev[args[0]] = ev
+                continue
+            if fn is _lsig_marker:
+                if args[0] in used:
+                    args[1].record(streams[args[0] - 1])
+                    lsig.add(args[1])
+                continue
+            if fn is _lwait_marker:
+                if args[1] in lsig:               # recorded in this run
+                    if not used:
+                        fork.record(main)
+                    if args[0] not in used:
+                        streams[args[0] - 1].wait_event(fork)
+                        used.append(args[0])
+                    streams[args[0] - 1].wait_event(args[1])
                 continue
             if lane == ASYNC_LANE:
                 if used:                          # the asynchronous lane starts from lane 0's point: close the region first
