@@ -223,7 +223,7 @@ template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI, bool DMA 
 __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 && sizeof(T) == 2 && TNW == 3) ? 3 : 1) void gemm_nt_kernel(const ga_gemm_desc d) {
 #define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
 #define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
-#define F_C2 (EPI < 0 ? d.C2 != nullptr : EPI == EPI_FC1)
+#define F_C2 (EPI < 0 ? d.C2 != nullptr : (EPI == EPI_FC1 && d.C2 != nullptr))   // eval: fc1 without the GELU' output
 #define F_H (EPI < 0 ? Hb != nullptr : EPI == EPI_DG2)
 #define F_HDERIV (EPI < 0 ? d.h_is_deriv != 0 : true)
 #define F_RS (EPI < 0 ? d.rowscale != nullptr : (EPI == EPI_FC2 && d.rowscale != nullptr))
@@ -567,7 +567,14 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
                     }
                 } else if (F_GELU) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+                    for (int j = 0; j < 8; ++j) {
+                        if constexpr (sizeof(T) == 2 && EPI == EPI_FC1) {
+                            float unused;
+                            gelu_both_fast(v[j], v[j], unused);
+                        } else {
+                            v[j] = gelu_f(v[j]);
+                        }
+                    }
                 } else if (F_RELU) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
@@ -1113,7 +1120,7 @@ int classify_epilogue(const ga_gemm_desc* d) {
         d->relu_after)
         return EPI_GENERIC;
     const bool act0 = d->act == GA_ACT_NONE;
-    if (d->act == GA_ACT_GELU && d->C2 && d->c2_mode == 2 && !d->H && !d->R && !d->rowscale && !d->colsum) return EPI_FC1;
+    if (d->act == GA_ACT_GELU && (!d->C2 || d->c2_mode == 2) && !d->H && !d->R && !d->rowscale && !d->colsum) return EPI_FC1;
     if (act0 && !d->C2 && !d->H && d->R && !d->colsum) return EPI_FC2;
     if (act0 && !d->C2 && d->H && d->h_is_deriv && !d->R && !d->rowscale) return EPI_DG2;
     if (act0 && !d->C2 && !d->H && !d->R && !d->rowscale) return EPI_PLAIN;
