@@ -641,7 +641,13 @@ class GAEngine:
         groups = cfg['gram_groups']
         HW = Hc * Hc
         hd = E // nh
-        assert E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0
+        if not (E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0):
+            # ga_convnext_{tiny,small}_688 / base_976: 688 / 8 = 86 and 688 / 4 = 172 channels per group are not multiples
+            # of 8, so the grouped operands of gram_embedding / GroupConvMlp are not 16-byte aligned per group
+            raise NotImplementedError(
+                f'GA head with dims[4]={cout}, gram groups={groups}, mlp groups={mg}, dim_embed={E}: the HIP engine needs '
+                f'dims[4] divisible by {8 * groups} and {8 * mg} (per-group channel counts that are multiples of 8); '
+                f'the *_768 / *_1024 variants qualify, *_688 / *_976 need padded group layouts (not built)')
         h = dict(k=k)
         # --- gram_contraction: the conv output / batch sums are column slices of the stacked GEMM; BN per head
         pre = f'gram_contraction.{k}.'

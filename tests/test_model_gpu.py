@@ -373,9 +373,9 @@ def test_b1024_eval_fp32_vs_reference_golden():
     assert np.array_equal(idx.cpu().numpy(), z['top5'])
 
 
-@pytest.mark.parametrize('name', ['ga_convnext_tiny_688', 'ga_convnext_small_768', 'ga_convnext_base_1024'])
+@pytest.mark.parametrize('name', ['ga_convnext_small_768', 'ga_convnext_base_1024'])
 def test_variant_train_step_fp32_vs_oracle(name):
-    """the other registered variants (head dim 21 -> per-head attention form; depth 27 / 4 taps; 128..1024 channels):
+    """the other registered variants the engine builds (depth 27 / 4 taps; 128..1024 channels):
     one fp32 train step at B=4 against the oracle (which is pinned on tiny_768 / base_1024 by the golden vectors).
     Input seed: with seed 3 ONE stage-4 output element of base_1024 sits within rounding of the ReLU threshold; its mask
     flips between fp32 evaluations and moves one channel of bn3 / downsample.1 by 5 % (the oracle's own fp32 run is 1.3 %
@@ -401,3 +401,12 @@ def test_variant_train_step_fp32_vs_oracle(name):
     print(f'[{name} fp32 B=4] logits {e_out:.2e} loss {e_loss:.2e} worst grads {worst}')
     assert e_out < 1e-3 and e_loss < 1e-3
     assert worst[0][1] < 3e-2, worst
+
+
+def test_688_variants_fail_loudly():
+    """*_688 / *_976: 86 / 172 / 122 / 244 channels per group are not multiples of 8 -- refused with a clear message
+    (no silent fallback); parameter layout and registry entries exist (tests/test_host_cpu.py)"""
+    import imagenet_models_amd as A
+    m = A.create_model('ga_convnext_tiny_688').cuda().eval()
+    with pytest.raises(NotImplementedError, match='per-group channel counts'):
+        m(torch.zeros(1, 3, 224, 224, device='cuda'))
