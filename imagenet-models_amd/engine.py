@@ -70,6 +70,7 @@ class GAEngine:
         # trunk weight-gradient launches on the backward plan's asynchronous lane (GAEXT_ASYNC_WGRAD=0: in line)
         self.async_wgrad = os.environ.get('GAEXT_ASYNC_WGRAD', '1') != '0'
         self.fwd_split = max(1, int(os.environ.get('GAEXT_FWD_SPLIT', '2')))
+        self.par_branch = os.environ.get('GAEXT_PAR_BRANCH', '1') != '0'   # stage-4 shortcut branch beside the main branch (forward)
         self.fwd_skew = int(os.environ.get('GAEXT_FWD_SKEW', '-1'))   # chain k+1 starts when chain k has passed this stage
         self._chain = None
         self._cur_stage = 0
@@ -553,6 +554,14 @@ class GAEngine:
             self._bn_finalize(pre + bnname + '.', bn, M4, N)
             return c, bn
 
+        # the shortcut branch (conv 1x1 of the 2208-channel concat + BN) only needs `cat`: it runs on the plan's
+        # asynchronous lane beside the main branch and is joined before the sum
+        F.lane = ASYNC_LANE if self.par_branch else 0
+        Wds = self._w_plain(pre + 'downsample.0.weight', cout, ctot, 1, 1)
+        st['sc'], st['bnd'] = conv_bn('downsample.0', 'downsample.1', cat, Wds, cout, ctot, bias=P[pre + 'downsample.0.bias'])
+        t = self.tmp('bott.t', (M4, cout))
+        F.affine_act(st['sc'], st['bnd']['scale'], st['bnd']['shift'], None, t, M4, cout, False, dt, label=pre + 'bnd')
+        F.lane = 0
         Wc1 = self._w_plain(pre + 'conv1.weight', w, ctot, 1, 1)
         st['c1'], st['bn1'] = conv_bn('conv1', 'bn1', cat, Wc1, w, ctot)
         st['y1'] = self.act(pre + 'y1', (M4, w))
@@ -574,11 +583,9 @@ class GAEngine:
         F.chan_scale(st['y2'], st['gate'], None, st['z'], B, HW, w, dt, label=pre + 'se.scale')
         Wc3 = self._w_plain(pre + 'conv3.weight', cout, w, 1, 1)
         st['c3'], st['bn3'] = conv_bn('conv3', 'bn3', st['z'], Wc3, cout, w)
-        Wds = self._w_plain(pre + 'downsample.0.weight', cout, ctot, 1, 1)
-        st['sc'], st['bnd'] = conv_bn('downsample.0', 'downsample.1', cat, Wds, cout, ctot, bias=P[pre + 'downsample.0.bias'])
-        t = self.tmp('bott.t', (M4, cout))
-        F.affine_act(st['sc'], st['bnd']['scale'], st['bnd']['shift'], None, t, M4, cout, False, dt, label=pre + 'bnd')
         x4 = self.buf(pre + 'out', (M4, cout))
+        if self.par_branch:
+            F.join_async()
         F.affine_act(st['c3'], st['bn3']['scale'], st['bn3']['shift'], t, x4, M4, cout, True, dt,
                      rowscale=self.dp_scale.get(pre), rows_per_scale=HW, label=pre + 'bn3+add')
         st['x4'] = x4
@@ -594,8 +601,13 @@ class GAEngine:
         dp = self.dp_scale.get(pre)
         dc3 = self.tmp('bott.dc3', (M4, cout))
         self._bn_bwd(pre + 'bn3.', st['bn3'], dx4, st['x4'], st['c3'], dc3, M4, cout, rowscale=dp, rps=HW)
+        # shortcut branch on the asynchronous lane: BN backward, weight gradient and the FIRST write of dcat
         dsc = self.tmp('bott.dsc', (M4, cout))
-        self._bn_bwd(pre + 'downsample.1.', st['bnd'], dx4, st['x4'], st['sc'], dsc, M4, cout)
+        with self._wlane():
+            self._bn_bwd(pre + 'downsample.1.', st['bnd'], dx4, st['x4'], st['sc'], dsc, M4, cout)
+            Bk.wgrad(dsc, st['cat'], self.grad(pre + 'downsample.0.weight'), M4, cout, ctot, dt,
+                     dbias=self.grad(pre + 'downsample.0.bias'), label=pre + 'ds.wg')
+            Bk.gemm(dsc, W[pre + 'downsample.0.weight.T'], dcat, M4, ctot, cout, dt, ldb=pad8(cout), label=pre + 'ds.dg')
         # conv3
         with self._wlane():
             Bk.wgrad(dc3, st['z'], self.grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
@@ -622,15 +634,12 @@ class GAEngine:
                 ldb=pad8(9 * w), label=pre + 'conv2.dg')
         dc1 = self.tmp('bott.dc1', (M4, w))
         self._bn_bwd(pre + 'bn1.', st['bn1'], dy1, st['y1'], st['c1'], dc1, M4, w)
-        # conv1 and the shortcut conv both read `cat`
+        # conv1 and the shortcut conv both read `cat`; conv1's dgrad adds onto the shortcut's (already written) dcat
         with self._wlane():
             Bk.wgrad(dc1, st['cat'], self.grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
-        Bk.gemm(dc1, W[pre + 'conv1.weight.T'], dcat, M4, ctot, w, dt, ldb=pad8(w), label=pre + 'conv1.dg')
-        with self._wlane():
-            Bk.wgrad(dsc, st['cat'], self.grad(pre + 'downsample.0.weight'), M4, cout, ctot, dt,
-                     dbias=self.grad(pre + 'downsample.0.bias'), label=pre + 'ds.wg')
-        Bk.gemm(dsc, W[pre + 'downsample.0.weight.T'], dcat, M4, ctot, cout, dt, ldb=pad8(cout), R=dcat, ldr=ctot,
-                label=pre + 'ds.dg')
+        if self.async_wgrad:
+            Bk.join_async()
+        Bk.gemm(dc1, W[pre + 'conv1.weight.T'], dcat, M4, ctot, w, dt, ldb=pad8(w), R=dcat, ldr=ctot, label=pre + 'conv1.dg')
 
     # ------------------------------------------------------------------------------------------
     # one GA head (ga_convnext.py:491-504)
