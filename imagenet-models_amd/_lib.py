@@ -77,6 +77,7 @@ _SIGS = {
     'ga_weight_unfold': ([C.POINTER(WunfoldDesc), vp], i32),
     'ga_dwconv7_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_dwconv7_bwd_data': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwconv7_bwd_data2': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_dwconv7_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),

@@ -42,11 +42,13 @@ template <> struct elt<float> {
     static constexpr int EPC = 4;  // elements per 16-byte chunk
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
     __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }   // value as stored
 };
 template <> struct elt<bf16_t> {
     static constexpr int EPC = 8;
     __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float round(float v) { return bf2f(f2bf(v)); }
 };
 
 // 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for f32). Pointers must be 16-B aligned.

@@ -77,7 +77,8 @@ __device__ __forceinline__ void stage_halo(const T* src, T* lds, long img_base, 
 template <typename T, int TH, int TW, int NT>
 __global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, const float* __restrict__ w49,
                                                      const float* __restrict__ bias, const T* __restrict__ res,
-                                                     T* __restrict__ y, int H, int W, int C, int flip) {
+                                                     T* __restrict__ y, int H, int W, int C, int flip,
+                                                     T* __restrict__ y2, const float* __restrict__ y2scale) {
     constexpr int PW = TW + 6, PH = TH + 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T* xs = reinterpret_cast<T*>(smem);                                    // [PH*PW][kCSF]
@@ -152,6 +153,13 @@ __global__ __launch_bounds__(NT) void dwconv7_kernel(const T* __restrict__ x, co
                         for (int c = 0; c < 4; ++c) acc[o][c] += rv[c];
                     }
                     store4(y + off, acc[o]);
+                    if (y2) {   // second output: the stored value times a per-image factor (the next block's DropPath scale)
+                        const float sc = y2scale[b];
+                        float a2[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) a2[c] = elt<T>::round(acc[o][c]) * sc;
+                        store4(y2 + off, a2);
+                    }
                 }
             }
         }
@@ -563,7 +571,8 @@ __global__ __launch_bounds__((DWF<TH, TW>::NT)) void dwconv7_dot2_kernel(const b
                                                                        const float* __restrict__ bias,
                                                                        const bf16_t* __restrict__ res,
                                                                        bf16_t* __restrict__ y, int B, int H, int W, int C,
-                                                                       int flip) {
+                                                                       int flip, bf16_t* __restrict__ y2,
+                                                                       const float* __restrict__ y2scale) {
     using G = DWF<TH, TW>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;                                   // [64 planes][PH rows of ROWX bytes]
@@ -693,6 +702,12 @@ __global__ __launch_bounds__((DWF<TH, TW>::NT)) void dwconv7_dot2_kernel(const b
 #pragma unroll
                         for (int e = 0; e < 8; ++e) a[e] += r[e];
                         store8(y + off, a);
+                        if (y2) {
+                            const float sc = y2scale[img / ((long)H * W)];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(a[e])) * sc;
+                            store8(y2 + off, a);
+                        }
                     } else {
                         *reinterpret_cast<uint4*>(y + off) = v;
                     }
@@ -728,7 +743,8 @@ struct DWM {
 
 __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w49,
                                                             const float* __restrict__ bias, const bf16_t* __restrict__ res,
-                                                            bf16_t* __restrict__ y, int B, int H, int W, int C, int flip) {
+                                                            bf16_t* __restrict__ y, int B, int H, int W, int C, int flip,
+                                                            bf16_t* __restrict__ y2, const float* __restrict__ y2scale) {
     using G = DWM;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* xs = smem;
@@ -861,6 +877,12 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const bf16_t* __restr
 #pragma unroll
                     for (int e = 0; e < 8; ++e) a[e] += rr[e];
                     store8(y + off, a);
+                    if (y2) {
+                        const float sc = y2scale[tt / tiles_y];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(a[e])) * sc;
+                        store8(y2 + off, a);
+                    }
                 } else {
                     *reinterpret_cast<uint4*>(y + off) = v;
                 }
@@ -871,7 +893,7 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const bf16_t* __restr
 
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
-                  int C, int flip, hipStream_t s) {
+                  int C, int flip, hipStream_t s, void* y2 = nullptr, const float* y2scale = nullptr) {
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0) {
             using G14 = DWF<14, 14>;
@@ -900,13 +922,13 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
                 const int slm = cdiv(C, DWM::CS);
                 const int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));
                 hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(gxm, slm), dim3(DWM::NT), DWM::LDS, s, (const bf16_t*)x, w49, bias,
-                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip, (bf16_t*)y2, y2scale);
             } else if (big)
                 hipLaunchKernelGGL(k14, dim3(gx, sl), dim3(G14::NT), G14::LDS, s, (const bf16_t*)x, w49, bias,
-                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip, (bf16_t*)y2, y2scale);
             else
                 hipLaunchKernelGGL(k7, dim3(gx, sl), dim3(G7::NT), G7::LDS, s, (const bf16_t*)x, w49, bias,
-                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip);
+                                   (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip, (bf16_t*)y2, y2scale);
             return ga_check_launch("ga_dwconv7");
         }
     }
@@ -925,13 +947,13 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             once = true;
         }
         dim3 grid(B * (H / TH) * (W / TW) * slices);
-        hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, (const T*)x, w49, bias, (const T*)res, (T*)y, H, W, C, flip);
+        hipLaunchKernelGGL(k, grid, dim3(NT), lds, s, (const T*)x, w49, bias, (const T*)res, (T*)y, H, W, C, flip, (T*)y2, y2scale);
     } else {
         constexpr int TH = 7, TW = 7, NT = 128;
         const size_t lds = (TH + 6) * (TW + 6) * kCSF * sizeof(T) + 49 * kCSF * 4;
         dim3 grid(B * cdiv(H, TH) * cdiv(W, TW) * slices);
         hipLaunchKernelGGL((dwconv7_kernel<T, TH, TW, NT>), grid, dim3(NT), lds, s, (const T*)x, w49, bias,
-                           (const T*)res, (T*)y, H, W, C, flip);
+                           (const T*)res, (T*)y, H, W, C, flip, (T*)y2, y2scale);
     }
     return ga_check_launch("ga_dwconv7");
 }
@@ -1015,6 +1037,15 @@ extern "C" int ga_dwconv7_bwd_data(const void* dy, const float* w49, const void*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == GA_BF16 ? launch_dwconv<bf16_t>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s)
                             : launch_dwconv<float>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s);
+}
+
+extern "C" int ga_dwconv7_bwd_data2(const void* dy, const float* w49, const void* res, void* dx, void* dx2,
+                                    const float* scale2, int B, int H, int W, int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && w49 && res && dx && dx2 && scale2 && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0,
+               "ga_dwconv7_bwd_data2: bad args (the second output needs the residual form)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? launch_dwconv<bf16_t>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s, dx2, scale2)
+                            : launch_dwconv<float>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s, dx2, scale2);
 }
 
 extern "C" int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W,

@@ -75,6 +75,8 @@ class GAEngine:
         self._chain = None
         self._cur_stage = 0
         self._bwd_seq = 0        # trunk blocks recorded on the backward plan so far
+        self._pre_dyz = {}       # block prefix -> DropPath-scaled dy already written by the block before it (backward order)
+        self.fuse_dp = os.environ.get('GAEXT_FUSE_DP', '1') != '0'
         self.W = {}
         self.weights_dirty = True
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
@@ -450,24 +452,31 @@ class GAEngine:
         self.blocks[pre] = dict(x=x, xn=xn, rstd=rstd, a=a, g=g, y=y, res=res, C=C)
         return y
 
-    def _block_bwd(self, pre, dy, dx):
-        """dy: grad wrt the block output; writes dx (a different buffer) = grad wrt the block input"""
+    def _block_bwd(self, pre, dy, dx, next_pre=None):
+        """dy: grad wrt the block output; writes dx (a different buffer) = grad wrt the block input.  next_pre: the block
+        whose backward follows and takes dx as its dy unchanged -- its DropPath-scaled copy is written here, by the
+        depthwise backward-data kernel that produces dx, instead of by a separate pass"""
         Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
         b = self.blocks[pre]
         res, C = b['res'], b['C']
         M = B * res * res
         dp = self.dp_scale.get(pre)
         dyz = dy
-        par = ''
+        par, dz_tag = '', 'dyz'
         if self.async_wgrad and Bk.lane == 0:
-            # two sets of the transients the weight-gradient launches read (dyz, dh, du; the caller rotates three dx
-            # buffers): this block only has to wait for the asynchronous launches of the block before the previous one
+            # two sets of the transients the weight-gradient launches read (dh, du; three of dyz; the caller rotates
+            # three dx buffers): this block only has to wait for the asynchronous launches of the block before the
+            # previous one
             self._bwd_seq += 1
             par = str(self._bwd_seq & 1)
+            dz_tag = f'dyz{self._bwd_seq % 3}'
             Bk.join_async(f'blk{self._bwd_seq - 2}')
         if dp is not None:
-            dyz = self.tmp('dyz' + par, (M, C))
-            Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
+            if pre in self._pre_dyz:
+                dyz = self._pre_dyz.pop(pre)          # written by the previous block's depthwise backward
+            else:
+                dyz = self.tmp(dz_tag, (M, C))
+                Bk.rowscale(dy, dp, dyz, M * C, res * res * C, dt, label=pre + 'dp')
         # the weight-gradient launches read only what the dgrad chain has already produced and nothing on the chain
         # reads their results: on the trunk they go to the plan's asynchronous lane and fill the tails of the chain's
         # launches (the next block joins before it overwrites dyz / dh / du)
@@ -496,7 +505,13 @@ class GAEngine:
         Bk.lane = ml
         if side:
             Bk.async_mark(f'blk{self._bwd_seq}')
-        Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, label=pre + 'dwd')
+        dx2 = dp_next = None
+        if next_pre is not None and self.fuse_dp:
+            dp_next = self.dp_scale.get(next_pre)
+            if dp_next is not None:
+                nxt = f'dyz{(self._bwd_seq + 1) % 3}' if side else 'dyz'
+                dx2 = self._pre_dyz[next_pre] = self.tmp(nxt, (M, C))
+        Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, dx2=dx2, scale2=dp_next, label=pre + 'dwd')
         Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
                          rs=P[pre + 'gamma'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
                          d_rs=self.grad(pre + 'gamma'), label=pre + 'unf2')
@@ -995,7 +1010,8 @@ class GAEngine:
                     Bk.affine_act(dy, None, None, dtap, dy, Mi, d[i], False, dt, label=f'tap.add.{j}')
                 dx = pp[turn % 3]          # not this block's dy nor the previous block's (still read by its wgrad)
                 turn += 1
-                self._block_bwd(f'stages.{i}.blocks.{j}.', dy, dx)
+                nxt = f'stages.{i}.blocks.{j - 1}.' if j > 0 and not (i == 2 and (j - 1) in tap_at) else None
+                self._block_bwd(f'stages.{i}.blocks.{j}.', dy, dx, next_pre=nxt)
                 dy = dx
             if i > 0:
                 pre = f'stages.{i}.downsample.'

@@ -361,7 +361,11 @@ class Plan:
         self._add('ga_dwconv7_fwd', (_ptr(x), _ptr(w49), _ptr(bias), _ptr(y), B, H, W, Cdim, dtype), label,
                   keep=(x, w49, bias, y))
 
-    def dwconv7_bwd_data(self, dy, w49, res, dx, B, H, W, Cdim, dtype, label=None):
+    def dwconv7_bwd_data(self, dy, w49, res, dx, B, H, W, Cdim, dtype, dx2=None, scale2=None, label=None):
+        if dx2 is not None:
+            self._add('ga_dwconv7_bwd_data2', (_ptr(dy), _ptr(w49), _ptr(res), _ptr(dx), _ptr(dx2), _ptr(scale2), B, H, W,
+                                               Cdim, dtype), label, keep=(dy, w49, res, dx, dx2, scale2))
+            return
         self._add('ga_dwconv7_bwd_data', (_ptr(dy), _ptr(w49), _ptr(res), _ptr(dx), B, H, W, Cdim, dtype), label,
                   keep=(dy, w49, res, dx))
 

@@ -182,6 +182,11 @@ int ga_dwconv7_fwd(const void* x, const float* w49, const float* bias, void* y, 
 /* dx = res + conv7x7(dy, flipped w)   (res may be NULL) */
 int ga_dwconv7_bwd_data(const void* dy, const float* w49, const void* res, void* dx, int B, int H, int W, int C,
                         int dtype, ga_stream_t stream);
+/* the same with a second output dx2[b,...] = dx[b,...] (as stored) * scale2[b]: the next block's DropPath row scale
+ * (x.div(keep) * mask, timm DropPath behind GA/ga_convnext.py:111) applied where dx is produced instead of by a
+ * separate pass over it; res is required */
+int ga_dwconv7_bwd_data2(const void* dy, const float* w49, const void* res, void* dx, void* dx2, const float* scale2,
+                         int B, int H, int W, int C, int dtype, ga_stream_t stream);
 /* dw49[49][C] += sum dy * shifted x ; dbias[C] += sum dy   (per-workgroup partial sums in a per-stream scratch
  * buffer owned by the library, then one reduction launch; deterministic for a fixed grid) */
 int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,

@@ -404,6 +404,13 @@ def test_dwconv7(dt, geom, monkeypatch):
     DX = torch.empty_like(X)
     P.dwconv7_bwd_data(DY, w49, R, DX, Bn, H, W, Cc, ops.ga_dtype(dt))
     assert_close(DX, xx.grad.permute(0, 2, 3, 1) + r, tol(dt), 'dwconv bwd data')
+    # second output: the stored dx times a per-image factor (the next block's DropPath scale), bit-identical to a
+    # separate ga_rowscale pass over dx
+    sc = torch.tensor([0.0, 1.25, 2.0, 1.0][:Bn], device='cuda')
+    DXa, DX2, REF2 = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
+    P.dwconv7_bwd_data(DY, w49, R, DXa, Bn, H, W, Cc, ops.ga_dtype(dt), dx2=DX2, scale2=sc)
+    P.rowscale(DXa, sc, REF2, DXa.numel(), H * W * Cc, ops.ga_dtype(dt))
+    assert torch.equal(DXa, DX) and torch.equal(DX2, REF2)
     dw49 = torch.zeros(49, Cc, device='cuda')
     db = torch.zeros(Cc, device='cuda')
     P.dwconv7_bwd_weight(DY, X, dw49, db, Bn, H, W, Cc, ops.ga_dtype(dt))
