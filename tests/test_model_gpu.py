@@ -410,3 +410,40 @@ def test_688_variants_fail_loudly():
     m = A.create_model('ga_convnext_tiny_688').cuda().eval()
     with pytest.raises(NotImplementedError, match='per-group channel counts'):
         m(torch.zeros(1, 3, 224, 224, device='cuda'))
+
+
+def _train_losses(monkeypatch, lanes_on, steps=6, batch=16):
+    import imagenet_models_amd as A
+    for k, v in (('GAEXT_ASYNC_WGRAD', '1' if lanes_on else '0'), ('GAEXT_HEAD_STREAMS', '5' if lanes_on else '1'),
+                 ('GAEXT_FWD_SPLIT', '2' if lanes_on else '1'), ('GAEXT_PAR_BRANCH', '1' if lanes_on else '0'),
+                 ('GAEXT_FUSE_DP', '1' if lanes_on else '0')):
+        monkeypatch.setenv(k, v)
+    torch.manual_seed(7)
+    m = A.create_model('ga_convnext_tiny_768', drop_path_rate=0.1, math_mode='fp32').cuda().train()
+    opt = A.create_optimizer_v2(m, opt='adamw', lr=1e-3, weight_decay=0.05)
+    step = A.TrainStep(m, opt, batch, lam=-0.8, loss='ce')
+    eng = step.eng
+    g = torch.Generator().manual_seed(3)
+    masks = {pre: (torch.rand(batch, generator=g) < 1 - eng.dp_rates[pre]).float() / (1 - eng.dp_rates[pre])
+             for pre in eng.dp_scale}
+    eng.set_drop_path_masks(masks)
+    eng.fixed_masks = True
+    x = torch.randn(batch, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 1000, (batch,), generator=g).cuda()
+    losses = [float(step(x, y)) for _ in range(steps)]
+    return losses, m.flat_state()['params'].double().sum().item(), m.flat_state()['params'].clone()
+
+
+def test_lanes_do_not_change_the_training_trajectory(monkeypatch):
+    """six AdamW steps of ga_convnext_tiny_768 (fp32 mode, fixed DropPath masks) with every stream-level feature on
+    (head lanes, asynchronous weight gradients with lagged joins, two forward chains, parallel shortcut branch, fused
+    DropPath copy) against the same steps on ONE stream: a missing dependency between lanes shows up as a different
+    loss / parameter trajectory (atomics reorder sums, hence tolerances instead of equality)"""
+    l_off, s_off, p_off = _train_losses(monkeypatch, False)
+    l_on, s_on, p_on = _train_losses(monkeypatch, True)
+    print('one stream :', l_off, '\\nwith lanes :', l_on)
+    for a, b in zip(l_off, l_on):
+        assert abs(a - b) <= 2e-4 * abs(a), (l_off, l_on)
+    # AdamW moves a parameter whose gradient is rounding noise (biases feeding a train-mode BatchNorm) by +-lr per step
+    # whatever the noise, so two runs differ by ~2e-3 in L2 even on one stream: the losses above are the sharp check
+    assert float((p_on - p_off).double().norm() / p_off.double().norm()) < 5e-3
