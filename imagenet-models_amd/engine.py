@@ -667,7 +667,10 @@ class GAEngine:
         hd = E // nh
         if not (E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0):
             # ga_convnext_{tiny,small}_688 / base_976: 688 / 8 = 86 and 688 / 4 = 172 channels per group are not multiples
-            # of 8, so the grouped operands of gram_embedding / GroupConvMlp are not 16-byte aligned per group
+            # of 8, so the grouped operands of gram_embedding / GroupConvMlp are not 16-byte aligned per group -- and the
+            # stage-4 Bottleneck is 688 / 4 = 172 channels wide (rows of 344 bytes).  Tried in round 1: padded group
+            # layouts around the head GEMMs work, the 172-wide Bottleneck activations need padded leading dimensions in
+            # the BatchNorm / 3x3-gather / squeeze-excite kernels as well (not built)
             raise NotImplementedError(
                 f'GA head with dims[4]={cout}, gram groups={groups}, mlp groups={mg}, dim_embed={E}: the HIP engine needs '
                 f'dims[4] divisible by {8 * groups} and {8 * mg} (per-group channel counts that are multiples of 8); '
