@@ -197,10 +197,13 @@ template <int TNW, int NWM> struct NTCfg {
     // flight while one is multiplied.  Otherwise two slots behind the padded 64-row staging area (which must also hold
     // the [2][RG][BN] column-sum scratch).
     static constexpr bool DMA3 = TNW == 4 && NWM == 4;
+    static constexpr bool SWZ = TNW == 4 || TNW == 8;         // 128 / 256-column tiles: XOR-swizzled staging pieces of 16 KiB
     static constexpr int NS = DMA3 ? 3 : 2;
-    static constexpr int PR = DMA3 ? 32 : 64;                 // rows per staged piece (LDS-DMA form)
+    static constexpr int PR = TNW == 8 ? 16 : (SWZ ? 32 : 64);   // rows per staged piece (LDS-DMA form)
     static constexpr int CSUM_BYTES = 2 * RG * BN * 4;
-    static constexpr int STAGE_DMA = DMA3 ? 32 * BN * 4 : (SMEM_C > CSUM_BYTES ? SMEM_C : CSUM_BYTES);
+    // 128 x 128 / 4 waves: 16 KiB + two 32 KiB slots = 80 KiB -> TWO workgroups per CU (one's epilogue under the other's K loop)
+    // 256 x 256 / 8 waves (TNW = 8): 16 KiB + two 64 KiB slots = 144 KiB, half the operand bytes per FLOP of 128 x 128
+    static constexpr int STAGE_DMA = SWZ ? PR * BN * 4 : (SMEM_C > CSUM_BYTES ? SMEM_C : CSUM_BYTES);
     static constexpr int RING0 = (STAGE_DMA + 1023) & ~1023;
     static constexpr int SMEM_DMA = RING0 + NS * SMEM_AB;
     static constexpr int NW = 2 * NWM;                        // waves
@@ -220,7 +223,7 @@ enum { EPI_GENERIC = -1, EPI_PLAIN = 0, EPI_FC1 = 1, EPI_FC2 = 2, EPI_DG2 = 3 };
 // 96-column tiles without the epilogue prefetch fit 168 VGPRs without spilling: three resident workgroups per CU
 // instead of two (same-box A/B: -0.2 ms/step; the 128-column forms spill at that bound and lose)
 template <typename T, int TNW, int NWM, bool PLAIN, bool PRE, int EPI, bool DMA = false>
-__global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 && sizeof(T) == 2 && TNW == 3) ? 3 : 1) void gemm_nt_kernel(const ga_gemm_desc d) {
+__global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 && sizeof(T) == 2 && TNW == 3) ? 3 : (NWM == 2 && DMA) ? 2 : 1) void gemm_nt_kernel(const ga_gemm_desc d) {
 #define F_GELU (EPI < 0 ? d.act == GA_ACT_GELU : EPI == EPI_FC1)
 #define F_RELU (EPI < 0 ? d.act == GA_ACT_RELU : false)
 #define F_C2 (EPI < 0 ? d.C2 != nullptr : (EPI == EPI_FC1 && d.C2 != nullptr))   // eval: fc1 without the GELU' output
@@ -500,8 +503,8 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
     }
     // staged piece: 64 padded rows, or (3-slot LDS-DMA form) 32 unpadded rows whose 16-byte units are XOR-swizzled with
     // the row (conflict-free fragment writes, 2-way on the row reads)
-    constexpr bool SW = DMA && CF::DMA3;
-    constexpr int PRr = SW ? 32 : 64, NSUB = 64 / PRr, TMP = PRr / 16, NRP = SW ? 1 : NR;
+    constexpr bool SW = DMA && CF::SWZ;
+    constexpr int PRr = SW ? CF::PR : 64, NSUB = 64 / PRr, TMP = PRr / 16, NRP = SW ? PRr / CF::RG : NR;
 #pragma unroll
     for (int half = 0; half < NWM; ++half) {
 #pragma unroll
@@ -1152,6 +1155,26 @@ bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
     return mode == 2 || (epi == EPI_FC2 && tnw == 4 && d->K >= 1024);
 }
 
+// 128 x 128 tile, 4 waves, LDS-DMA into a 2-slot ring, 80 KiB: two workgroups per CU without the ds_write staging pass
+bool want_dma2(const ga_gemm_desc* d, int epi) {
+    const char* e = getenv("GAEXT_NT_DMA2");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
+    const int mask = e ? atoi(e) : 0;
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC) return false;
+    const char* k = getenv("GAEXT_NT_DMA2_MINK");
+    if (d->K < (k ? atoi(k) : 256)) return false;
+    return (mask >> epi) & 1;
+}
+
+// 256 x 256 tile, 8 waves (64 x 128 each), LDS-DMA into a 2-slot ring: wide-N launches
+bool want_t256(const ga_gemm_desc* d, int epi) {
+    const char* e = getenv("GAEXT_NT_T256");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
+    const int mask = e ? atoi(e) : 0;
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC) return false;
+    if (d->N % 256 != 0 || d->K < 256) return false;
+    if ((long)cdiv(d->M, 256) * (d->N / 256) * d->batch < num_cus()) return false;
+    return (mask >> epi) & 1;
+}
+
 template <typename T, int TNW, int NWM>
 void launch_nt(const ga_gemm_desc* d, hipStream_t s) {
     constexpr bool BF = sizeof(T) == 2;   // the epilogue-operand prefetch exists for bf16 only (32 extra VGPRs)
@@ -1240,6 +1263,20 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
                 case EPI_FC2: launch_nt_<bf16_t, 3, 4, true, true, EPI_FC2, true>(d, s); break;
                 default: launch_nt_<bf16_t, 3, 4, true, true, EPI_DG2, true>(d, s); break;
             }
+        }
+    } else if (want_t256(d, epi)) {
+        switch (epi) {
+            case EPI_PLAIN: launch_nt_<bf16_t, 8, 4, true, false, EPI_PLAIN, true>(d, s); break;
+            case EPI_FC1: launch_nt_<bf16_t, 8, 4, true, false, EPI_FC1, true>(d, s); break;
+            case EPI_FC2: launch_nt_<bf16_t, 8, 4, true, false, EPI_FC2, true>(d, s); break;
+            default: launch_nt_<bf16_t, 8, 4, true, false, EPI_DG2, true>(d, s); break;
+        }
+    } else if (tnw == 4 && want_dma2(d, epi)) {
+        switch (epi) {
+            case EPI_PLAIN: launch_nt_<bf16_t, 4, 2, true, false, EPI_PLAIN, true>(d, s); break;
+            case EPI_FC1: launch_nt_<bf16_t, 4, 2, true, false, EPI_FC1, true>(d, s); break;
+            case EPI_FC2: launch_nt_<bf16_t, 4, 2, true, true, EPI_FC2, true>(d, s); break;
+            default: launch_nt_<bf16_t, 4, 2, true, true, EPI_DG2, true>(d, s); break;
         }
     } else if (tnw == 4) {
         if (want_big_tile(d, epi)) {
