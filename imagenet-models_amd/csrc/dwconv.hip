@@ -920,7 +920,11 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             const bool many = H * W >= 56 * 56 && ntiles * cdiv(C, DWM::CS) >= 16L * num_cus();
             if (big && (use_mfma == 2 || (use_mfma == 1 && many))) {
                 const int slm = cdiv(C, DWM::CS);
-                const int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));
+                // grid.x a multiple of 8: workgroup (x, y) then sits on XCD x % 8 for every slice y, so the 32-channel slices of
+                // one tile (64 of the 128 bytes of every line each) share one L2 instead of fetching the line once per slice
+                static const int xcd8 = [] { const char* e8 = getenv("GAEXT_DW_XCD8"); return e8 ? atoi(e8) : 1; }();
+                int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));
+                if (xcd8 && gxm >= 16) gxm = gxm / 8 * 8;
                 hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(gxm, slm), dim3(DWM::NT), DWM::LDS, s, (const bf16_t*)x, w49, bias,
                                    (const bf16_t*)res, (bf16_t*)y, B, H, W, C, flip, (bf16_t*)y2, y2scale);
             } else if (big)
