@@ -199,8 +199,18 @@ def main():
         launches = max(f['launches'], 1)
         achieved = f['flops'] / (f['ms'] * 1e-3) / 1e12 if f['ms'] > 0 else 0.0
         per_gpu = value / world
+        # HBM bytes per launch of the family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE over one step of THIS
+        # workload, tools/pmc_step_traffic.py): a PMC run cannot be nested inside the timed bench
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, 'profiles', 'r01_pmc_step_traffic.json')
+        if name == 'gemm_nt' and a.model == MODEL and a.batch == 256 and a.math == 'bf16' and os.path.exists(tj):
+            with open(tj) as fh:
+                g_ = json.load(fh)['gemm_nt']
+            traffic = round((g_['fetch_mb'] + g_['write_mb']) * 1e6 / max(g_['launches'], 1))
+            traffic_src = f"profiles/r01_pmc_step_traffic.json: {g_['launches']} gemm_nt dispatches per step, bytes per dispatch"
         out['roofline'] = dict(bound='mfma', kernel=name, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
-                               unit='TFLOP/s', frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                               unit='TFLOP/s', frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                               traffic_source=traffic_src,
                                launches_per_step=f['launches'], avg_launch_us=round(f['ms'] * 1e3 / launches, 2),
                                algorithmic_gflop_per_launch=round(f['flops'] / launches / 1e9, 3),
                                share_of_step_device_time=round(f['ms'] / total_ms, 3),
