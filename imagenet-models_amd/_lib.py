@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('GAEXT_LIB') or os.path.join(_HERE, 'csrc', 'libgaext.
 
 GA_F32, GA_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-A_PLAIN, A_PATCH2, A_STEM4_NCHW, A_CONV3 = 0, 1, 2, 3
+A_PLAIN, A_PATCH2, A_STEM4_NCHW, A_CONV3, A_CONV3S2, A_NEIGH2 = 0, 1, 2, 3, 4, 5
 C_PLAIN, C_UNPATCH2 = 0, 1
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -66,6 +66,12 @@ class SmallDesc(C.Structure):
                 ('b', vp), ('rs', vp), ('v', vp), ('row_perm', vp)]
 
 
+class CswinAttnDesc(C.Structure):
+    _fields_ = [('B', i32), ('reso', i32), ('C', i32), ('heads', i32), ('nbranch', i32),
+                ('Hs', i32 * 2), ('Ws', i32 * 2), ('lepe_w', vp * 2), ('lepe_b', vp * 2),
+                ('scale', f32), ('dtype', i32), ('qkv', vp), ('ldq', i64), ('out', vp), ('ldo', i64)]
+
+
 _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
@@ -106,6 +112,13 @@ _SIGS = {
     'ga_weight_prep_batch': ([vp, i32, vp], i32),
     'ga_weight_unfold_batch': ([vp, i32, vp], i32),
     'ga_small_batch': ([vp, i32, vp], i32),
+    'ga_cswin_attn_fwd': ([C.POINTER(CswinAttnDesc), vp], i32),
+    'ga_cswin_attn_bwd': ([C.POINTER(CswinAttnDesc), vp, vp, vp], i32),
+    'ga_cswin_lepe_wgrad': ([C.POINTER(CswinAttnDesc), vp, vp, vp, vp, vp, vp], i32),
+    'ga_nchw3_to_nhwc8': ([vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_convw_pack': ([vp, vp, i32, i32, i32, i32, i64, i32, vp], i32),
+    'ga_convw_unpack_grad': ([vp, vp, i32, i32, i32, i32, i64, vp], i32),
+    'ga_conv3s2_dgrad_prep': ([vp, vp, i32, i32, i64, i32, vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),

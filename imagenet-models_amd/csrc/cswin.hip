@@ -1,0 +1,875 @@
+// GA-CSWin kernels for gfx950: cross-shaped (stripe) window attention with the LePE depthwise 3x3 of V
+// (LePEAttention.forward, /root/reference/GA/ga_cswin.py:110-136; get_lepe :95-108; img2windows / windows2img
+// :215-233), its backward, the LePE weight gradient, and the small layout helpers of the deep stem.
+//
+// Layout: q | k | v are the three C-wide column blocks of ONE [B*L][ldq] matrix (the qkv GEMM output, tokens in image
+// raster order); branch i of a CSWinBlock owns channels [i*C/nb, (i+1)*C/nb) of each block and its own stripe shape
+// Hs x Ws.  Window partition / merge (img2windows, windows2img) never materialise: a workgroup = one (image, window,
+// head) and addresses its tokens in place.
+//
+// Two forms of each kernel:
+//   * generic (any dtype, head_dim 8 / 16 / 32, N = Hs*Ws <= 128 tokens): one thread per query / key row, scores in
+//     LDS, fp32 arithmetic -- the parity math mode and every narrow configuration;
+//   * bf16, head_dim 32 (every stage of the GA-CSWin models): Q.K^T and P.V on v_mfma_f32_16x16x32_bf16, softmax by
+//     wave shuffles in the S^T accumulator layout, V / K / dO / Q consumed column-wise with ds_read_b64_tr_b16.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+struct WinGeom {
+    int b, head, branch, hb;       // image, global head, branch, head inside the branch
+    int Hs, Ws, N;                 // stripe shape, tokens per window
+    int y0, x0;                    // window origin in the image
+    int ch;                        // first channel of this head inside a C-wide block
+    int chb;                       // first channel of this head inside its branch (LePE weight row)
+};
+
+__device__ __forceinline__ WinGeom win_geom(const ga_cswin_attn_desc& d, int item) {
+    WinGeom g;
+    const int hpb = d.heads / d.nbranch;
+    const int hd = d.C / d.heads;
+    g.head = item % d.heads;
+    const int t = item / d.heads;
+    g.branch = g.head / hpb;
+    g.hb = g.head - g.branch * hpb;
+    g.Hs = d.Hs[g.branch];
+    g.Ws = d.Ws[g.branch];
+    g.N = g.Hs * g.Ws;
+    const int nwx = d.reso / g.Ws, nwin = (d.reso / g.Hs) * nwx;
+    const int win = t % nwin;
+    g.b = t / nwin;
+    g.y0 = (win / nwx) * g.Hs;
+    g.x0 = (win % nwx) * g.Ws;
+    g.ch = g.head * hd;
+    g.chb = g.hb * hd;
+    return g;
+}
+
+// image row (token index in [0, B*L)) of window token t
+__device__ __forceinline__ long tok_row(const ga_cswin_attn_desc& d, const WinGeom& g, int t) {
+    const int ty = t / g.Ws, tx = t - ty * g.Ws;
+    return ((long)g.b * d.reso + g.y0 + ty) * d.reso + g.x0 + tx;
+}
+
+__device__ __forceinline__ int xcd_walk(int bid, int nwg) {   // bijective XCD-aware remap (heads of a window share lines)
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// =================================================================================================================
+// generic forward: 128 threads, thread t = token t of the window
+// LDS: q k v [N][HD+1] fp32, scores [N][N+1] fp32
+// =================================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(128) void cswin_attn_fwd_simple(const ga_cswin_attn_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const WinGeom g = win_geom(d, blockIdx.x);
+    const int N = g.N, LD = HD + 1;
+    float* qs = sm;
+    float* ks = qs + 128 * LD;
+    float* vs = ks + 128 * LD;
+    float* sc = vs + 128 * LD;           // [N][N+1]
+    const int t = threadIdx.x;
+    const T* qkv = reinterpret_cast<const T*>(d.qkv);
+    long row = 0;
+    if (t < N) {
+        row = tok_row(d, g, t);
+        const T* p = qkv + row * d.ldq + g.ch;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            qs[t * LD + c] = elt<T>::ld(p + c);
+            ks[t * LD + c] = elt<T>::ld(p + d.C + c);
+            vs[t * LD + c] = elt<T>::ld(p + 2 * d.C + c);
+        }
+    }
+    __syncthreads();
+    if (t >= N) return;
+    float q[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) q[c] = qs[t * LD + c] * d.scale;   // q * scale, then q @ k^T (ga_cswin.py:125-126)
+    float m = -3.0e38f;
+    for (int j = 0; j < N; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) s = fmaf(q[c], ks[j * LD + c], s);
+        sc[t * (N + 1) + j] = s;
+        m = fmaxf(m, s);
+    }
+    float o[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = 0.f;
+    float l = 0.f;
+    for (int j = 0; j < N; ++j) {
+        const float p = __expf(sc[t * (N + 1) + j] - m);
+        l += p;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) o[c] = fmaf(p, vs[j * LD + c], o[c]);
+    }
+    const float inv = 1.f / l;
+    // LePE: depthwise 3x3 of v inside the window, zero padded at the window border (ga_cswin.py:101-104)
+    const float* w = d.lepe_w[g.branch] + (long)g.chb * 9;
+    const float* bb = d.lepe_b[g.branch] + g.chb;
+    const int ty = t / g.Ws, tx = t - ty * g.Ws;
+    T* op = reinterpret_cast<T*>(d.out) + row * d.ldo + g.ch;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+        float a = bb[c];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws)
+                    a = fmaf(w[c * 9 + (dy + 1) * 3 + dx + 1], vs[(yy * g.Ws + xx) * LD + c], a);
+            }
+        elt<T>::st(op + c, fmaf(o[c], inv, a));
+    }
+}
+
+// =================================================================================================================
+// generic backward: dq, dk, dv (incl. the LePE transpose) of one (image, window, head)
+// LDS: q k v do [128][HD+1] fp32; P, dS [N][N+1] fp32
+// =================================================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(128) void cswin_attn_bwd_simple(const ga_cswin_attn_desc d, const void* dout_, void* dqkv_) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const WinGeom g = win_geom(d, blockIdx.x);
+    const int N = g.N, LD = HD + 1, LS = N + 1;
+    float* qs = sm;
+    float* ks = qs + 128 * LD;
+    float* vs = ks + 128 * LD;
+    float* gs = vs + 128 * LD;           // dO
+    float* P = gs + 128 * LD;
+    float* dS = P + N * LS;
+    const int t = threadIdx.x;
+    const T* qkv = reinterpret_cast<const T*>(d.qkv);
+    const T* dout = reinterpret_cast<const T*>(dout_);
+    T* dqkv = reinterpret_cast<T*>(dqkv_);
+    long row = 0;
+    if (t < N) {
+        row = tok_row(d, g, t);
+        const T* p = qkv + row * d.ldq + g.ch;
+        const T* pg = dout + row * d.ldo + g.ch;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            qs[t * LD + c] = elt<T>::ld(p + c);
+            ks[t * LD + c] = elt<T>::ld(p + d.C + c);
+            vs[t * LD + c] = elt<T>::ld(p + 2 * d.C + c);
+            gs[t * LD + c] = elt<T>::ld(pg + c);
+        }
+    }
+    __syncthreads();
+    if (t < N) {                          // query row t
+        float q[HD], go[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            q[c] = qs[t * LD + c] * d.scale;
+            go[c] = gs[t * LD + c];
+        }
+        float m = -3.0e38f;
+        for (int j = 0; j < N; ++j) {
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) {
+                s = fmaf(q[c], ks[j * LD + c], s);
+                dp = fmaf(go[c], vs[j * LD + c], dp);
+            }
+            P[t * LS + j] = s;
+            dS[t * LS + j] = dp;
+            m = fmaxf(m, s);
+        }
+        float l = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float p = __expf(P[t * LS + j] - m);
+            P[t * LS + j] = p;
+            l += p;
+        }
+        const float inv = 1.f / l;
+        float delta = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float p = P[t * LS + j] * inv;
+            P[t * LS + j] = p;
+            delta = fmaf(p, dS[t * LS + j], delta);
+        }
+        float dq[HD];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+        for (int j = 0; j < N; ++j) {
+            const float ds = P[t * LS + j] * (dS[t * LS + j] - delta);
+            dS[t * LS + j] = ds;
+#pragma unroll
+            for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, ks[j * LD + c], dq[c]);
+        }
+        T* o = dqkv + row * d.ldq + g.ch;
+#pragma unroll
+        for (int c = 0; c < HD; ++c) elt<T>::st(o + c, dq[c] * d.scale);
+    }
+    __syncthreads();
+    if (t >= N) return;                   // key row t
+    float dk[HD], dv[HD];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dk[c] = dv[c] = 0.f;
+    for (int i = 0; i < N; ++i) {
+        const float p = P[i * LS + t], ds = dS[i * LS + t];
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+            dv[c] = fmaf(p, gs[i * LD + c], dv[c]);
+            dk[c] = fmaf(ds, qs[i * LD + c], dk[c]);
+        }
+    }
+    // LePE transpose: dv[s] += sum_taps w[tap] * dO[s - tap]  (inside the window)
+    const float* w = d.lepe_w[g.branch] + (long)g.chb * 9;
+    const int ty = t / g.Ws, tx = t - ty * g.Ws;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = ty - dy, xx = tx - dx;
+            if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
+#pragma unroll
+                for (int c = 0; c < HD; ++c)
+                    dv[c] = fmaf(w[c * 9 + (dy + 1) * 3 + dx + 1], gs[(yy * g.Ws + xx) * LD + c], dv[c]);
+            }
+        }
+    T* o = dqkv + row * d.ldq + g.ch;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+        elt<T>::st(o + d.C + c, dk[c] * d.scale);
+        elt<T>::st(o + 2 * d.C + c, dv[c]);
+    }
+}
+
+// =================================================================================================================
+// bf16, head_dim 32, MFMA.  One workgroup (4 waves) per (image, window, head); NT = 16-token tiles (4: N <= 64,
+// 7: N <= 112), KS = 32-key steps, KP = KS*32 rows per LDS tile (pad rows zero).
+// LDS tiles are [KP][32] bf16 (64-byte rows); the 16-byte chunk c of row r sits at chunk c ^ ((r >> 2) & 3) so that the
+// 16 rows x one chunk of a ds_read_b128 fragment read cover all 16 slots of the 256-byte bank row.
+// =================================================================================================================
+template <int NT> struct AT {
+    static constexpr int KS = (NT + 1) / 2;
+    static constexpr int KP = KS * 32;
+    static constexpr int TILE = KP * 64;              // bytes
+};
+
+__device__ __forceinline__ unsigned tile_off(int r, int chunk) { return r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4); }
+
+// global [tokens][32 channels] bf16 column slice -> LDS tile (zero rows beyond N)
+template <int NT>
+__device__ __forceinline__ void load_tile(unsigned char* dst, const bf16_t* src, long ld, const ga_cswin_attn_desc& d,
+                                          const WinGeom& g) {
+    constexpr int KP = AT<NT>::KP;
+    for (int i = threadIdx.x; i < KP * 4; i += 256) {
+        const int r = i >> 2, c = i & 3;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < g.N) v = *reinterpret_cast<const uint4*>(src + tok_row(d, g, r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(dst + tile_off(r, c)) = v;
+    }
+}
+
+// A / B fragment of the 16x16x32 MFMA taken row-wise: row = r0 + (lane & 15), elements 8*(lane>>4) .. +7 of the 32 channels
+__device__ __forceinline__ bf16x8_t row_frag(const unsigned char* tile, int r0, int lane) {
+    const int r = r0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8_t*>(tile + tile_off(r, lane >> 4));
+}
+
+// B fragment taken column-wise (transposing LDS read): element j of lane (g = lane>>4, i = lane&15) is
+// tile[row = k0 + 16*(j>>2) + 4g + (j&3)][col = 16*dt + i] -- the k order in which an S^T accumulator pair presents
+// its rows when it is used as the A operand (cdna guide, "an accumulator tile as the next MFMA's operand")
+__device__ __forceinline__ bf16x8_t col_frag_acc(const unsigned char* tile, int k0, int dt, int lane) {
+    const int gq = lane >> 4, i = lane & 15;
+    s16x4_t lo, hi;
+    {
+        const int r = k0 + 4 * gq + (i >> 2);
+        const unsigned a = tile_off(r, 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1);
+        lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + a));
+    }
+    {
+        const int r = k0 + 16 + 4 * gq + (i >> 2);
+        const unsigned a = tile_off(r, 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1);
+        hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(tile + a));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return *reinterpret_cast<const bf16x8_t*>(&v);
+}
+
+// two accumulator tiles (rows 4g+r of tile a = k slots 0..3, of tile b = k slots 4..7) -> one A fragment
+__device__ __forceinline__ bf16x8_t acc_pair_frag(const f32x4_t& a, const f32x4_t& b) {
+    uint4 u;
+    u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
+    return *reinterpret_cast<const bf16x8_t*>(&u);
+}
+
+// S^T tiles of one 16-query tile: st[kt][r] = scale * sum_d K[16kt + 4g + r][d] * Q[q0 + (lane&15)][d]; keys >= N masked
+template <int NT>
+__device__ __forceinline__ void st_tiles(const unsigned char* Kt, const unsigned char* Qt, int q0, int N, float scale, int lane,
+                                         f32x4_t (&st)[NT]) {
+    const bf16x8_t qf = row_frag(Qt, q0, lane);
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Kt, 16 * kt, lane), qf, f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * (lane >> 4) + r;
+            st[kt][r] = key < N ? st[kt][r] * scale : -3.0e38f;
+        }
+    }
+}
+
+// softmax over the keys of each query column (in-lane over r / kt, then lanes l, l^16, l^32 hold the other key rows)
+template <int NT>
+__device__ __forceinline__ void softmax_cols(f32x4_t (&st)[NT], float& m_out, float& l_out) {
+    float m = -3.0e38f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, st[kt][r]);
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float p = __expf(st[kt][r] - m);    // masked keys: exp(-huge) = 0
+            st[kt][r] = p;
+            l += p;
+        }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[kt][r] *= inv;
+    m_out = m;
+    l_out = l;
+}
+
+// out tile [16 rows q0..][32 ch] fp32 accumulators (o[dt][r]: row 4g+r, col 16dt + (lane&15)) -> bf16 rows of `stage`
+// (this wave's own 1 KiB) -> 16-byte global stores, one token row per 4 lanes
+__device__ __forceinline__ void store_tile(unsigned char* stage, const f32x4_t (&o)[2], int q0, bf16_t* dst, long ld,
+                                           const ga_cswin_attn_desc& d, const WinGeom& g, int lane) {
+    bf16_t* st = reinterpret_cast<bf16_t*>(stage);
+    asm volatile("" ::: "memory");                        // the previous use of this staging piece is complete
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * (lane >> 4) + r) * 32 + 16 * dt + (lane & 15)] = f2bf(o[dt][r]);
+    // LDS accesses of one wave complete in order: the reads below see the writes above (the asm statement keeps the
+    // compiler from re-ordering the differently typed accesses)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int r = lane >> 2, c = lane & 3;
+    const uint4 v = *reinterpret_cast<const uint4*>(stage + r * 64 + c * 16);
+    const int t = q0 + r;
+    if (t < g.N) *reinterpret_cast<uint4*>(dst + tok_row(d, g, t) * ld + c * 8) = v;
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_desc d, const int nwg) {
+    using A = AT<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qt = smem;
+    unsigned char* Kt = Qt + A::TILE;
+    unsigned char* Vt = Kt + A::TILE;
+    unsigned char* Stage = Vt + A::TILE;              // 4 x 1 KiB
+    const WinGeom g = win_geom(d, xcd_walk(blockIdx.x, nwg));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + g.ch;
+    load_tile<NT>(Qt, qkv, d.ldq, d, g);
+    load_tile<NT>(Kt, qkv + d.C, d.ldq, d, g);
+    load_tile<NT>(Vt, qkv + 2 * d.C, d.ldq, d, g);
+    // LePE taps of this lane's two channels (16*dt + lane&15)
+    float w[2][9], bias[2];
+    {
+        const float* wp = d.lepe_w[g.branch] + (long)g.chb * 9;
+        const float* bp = d.lepe_b[g.branch] + g.chb;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const int c = 16 * dt + (lane & 15);
+            bias[dt] = bp[c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[dt][k] = wp[c * 9 + k];
+        }
+    }
+    __syncthreads();
+    const bf16_t* V16 = reinterpret_cast<const bf16_t*>(Vt);
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int q0 = 16 * qt;
+        if (q0 >= g.N) break;
+        f32x4_t st[NT];
+        st_tiles<NT>(Kt, Qt, q0, g.N, d.scale, lane, st);
+        float m, l;
+        softmax_cols<NT>(st, m, l);
+        f32x4_t o[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            const bf16x8_t pf = acc_pair_frag(st[2 * ks], 2 * ks + 1 < NT ? st[2 * ks + 1 < NT ? 2 * ks + 1 : 0] : zero);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Vt, 32 * ks, dt, lane), o[dt], 0, 0, 0);
+        }
+        // + LePE (rows 4g + r of this tile, channels 16dt + lane&15)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = q0 + 4 * (lane >> 4) + r;
+            if (t < g.N) {
+                const int ty = t / g.Ws, tx = t - ty * g.Ws;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    float a = bias[dt];
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int yy = ty + dy, xx = tx + dx;
+                            if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
+                                const int rr = yy * g.Ws + xx, ch = 16 * dt + (lane & 15);
+                                a = fmaf(w[dt][(dy + 1) * 3 + dx + 1], bf2f(V16[(tile_off(rr, ch >> 3) >> 1) + (ch & 7)]), a);
+                            }
+                        }
+                    o[dt][r] += a;
+                }
+            }
+        }
+        store_tile(Stage + wave * 1024, o, q0, reinterpret_cast<bf16_t*>(d.out) + g.ch, d.ldo, d, g, lane);
+    }
+}
+
+// backward, bf16 hd 32.  Phase A (per 16-query tile): S^T, P^T, dP^T = V.dO^T, delta, dS^T -> dQ = scale * dS.K; the
+// row statistics lse / delta go to LDS.  Phase B (per 16-key tile): S = Q.K^T and dP = dO.V^T recomputed in the
+// [query][key] layout, whose accumulators are directly the A operands of dV += P^T.dO and dK += dS^T.Q.
+template <int NT>
+__global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_desc d, const void* dout_, void* dqkv_,
+                                                           const int nwg) {
+    using A = AT<NT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qt = smem;
+    unsigned char* Kt = Qt + A::TILE;
+    unsigned char* Vt = Kt + A::TILE;
+    unsigned char* Gt = Vt + A::TILE;                 // dO
+    unsigned char* Stage = Gt + A::TILE;              // 4 x 1 KiB
+    float* lse = reinterpret_cast<float*>(Stage + 4096);   // [KP]
+    float* dlt = lse + A::KP;                              // [KP]
+    const WinGeom g = win_geom(d, xcd_walk(blockIdx.x, nwg));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + g.ch;
+    bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + g.ch;
+    load_tile<NT>(Qt, qkv, d.ldq, d, g);
+    load_tile<NT>(Kt, qkv + d.C, d.ldq, d, g);
+    load_tile<NT>(Vt, qkv + 2 * d.C, d.ldq, d, g);
+    load_tile<NT>(Gt, reinterpret_cast<const bf16_t*>(dout_) + g.ch, d.ldo, d, g);
+    for (int i = threadIdx.x; i < 2 * A::KP; i += 256) lse[i] = 0.f;
+    __syncthreads();
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    // ---------------- phase A ----------------
+    for (int qt = wave; qt < NT; qt += 4) {
+        const int q0 = 16 * qt;
+        if (q0 >= g.N) break;
+        f32x4_t st[NT], dp[NT];
+        st_tiles<NT>(Kt, Qt, q0, g.N, d.scale, lane, st);
+        float m, l;
+        softmax_cols<NT>(st, m, l);
+        const bf16x8_t gf = row_frag(Gt, q0, lane);
+        float delta = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vt, 16 * kt, lane), gf, zero, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) delta = fmaf(st[kt][r], dp[kt][r], delta);
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dp[kt][r] = st[kt][r] * (dp[kt][r] - delta);     // dS^T
+        if (lane < 16) {
+            lse[q0 + lane] = m + __logf(l);
+            dlt[q0 + lane] = delta;
+        }
+        f32x4_t o[2] = {zero, zero};
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            const bf16x8_t sf = acc_pair_frag(dp[2 * ks], 2 * ks + 1 < NT ? dp[2 * ks + 1 < NT ? 2 * ks + 1 : 0] : zero);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Kt, 32 * ks, dt, lane), o[dt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[dt][r] *= d.scale;
+        store_tile(Stage + wave * 1024, o, q0, dqkv, d.ldq, d, g, lane);
+    }
+    __syncthreads();
+    // ---------------- phase B ----------------
+    float w[2][9];
+    {
+        const float* wp = d.lepe_w[g.branch] + (long)g.chb * 9;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) w[dt][k] = wp[(16 * dt + (lane & 15)) * 9 + k];
+    }
+    const bf16_t* G16 = reinterpret_cast<const bf16_t*>(Gt);
+    for (int kt = wave; kt < NT; kt += 4) {
+        const int k0 = 16 * kt;
+        if (k0 >= g.N) break;
+        const bf16x8_t kf = row_frag(Kt, k0, lane), vf = row_frag(Vt, k0, lane);
+        const bool key_ok = k0 + (lane & 15) < g.N;
+        f32x4_t dv[2] = {zero, zero}, dk[2] = {zero, zero};
+#pragma unroll
+        for (int qs = 0; qs < A::KS; ++qs) {
+            f32x4_t p[2], ds[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qt = 2 * qs + h;
+                if (qt < NT) {
+                    const int q0 = 16 * qt;
+                    // [query 4g + r][key lane&15]
+                    p[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qt, q0, lane), kf, zero, 0, 0, 0);
+                    ds[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Gt, q0, lane), vf, zero, 0, 0, 0);
+                    const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(lse + q0 + 4 * (lane >> 4));
+                    const f32x4_t de = *reinterpret_cast<const f32x4_t*>(dlt + q0 + 4 * (lane >> 4));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = key_ok ? __expf(p[h][r] * d.scale - ls[r]) : 0.f;
+                        p[h][r] = pv;
+                        ds[h][r] = pv * (ds[h][r] - de[r]);
+                    }
+                } else {
+                    p[h] = zero;
+                    ds[h] = zero;
+                }
+            }
+            const bf16x8_t pf = acc_pair_frag(p[0], p[1]), sf = acc_pair_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Gt, 32 * qs, dt, lane), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Qt, 32 * qs, dt, lane), dk[dt], 0, 0, 0);
+            }
+        }
+        // dv += LePE^T(dO); dk *= scale
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = k0 + 4 * (lane >> 4) + r;
+            if (t < g.N) {
+                const int ty = t / g.Ws, tx = t - ty * g.Ws;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            const int yy = ty - dy, xx = tx - dx;
+                            if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
+                                const int rr = yy * g.Ws + xx, ch = 16 * dt + (lane & 15);
+                                a = fmaf(w[dt][(dy + 1) * 3 + dx + 1], bf2f(G16[(tile_off(rr, ch >> 3) >> 1) + (ch & 7)]), a);
+                            }
+                        }
+                    dv[dt][r] += a;
+                    dk[dt][r] *= d.scale;
+                }
+            }
+        }
+        store_tile(Stage + wave * 1024, dk, k0, dqkv + d.C, d.ldq, d, g, lane);
+        store_tile(Stage + wave * 1024, dv, k0, dqkv + 2 * d.C, d.ldq, d, g, lane);
+    }
+}
+
+// =================================================================================================================
+// LePE weight gradient: dw[ch][tap] += sum_tokens dO[t][ch] * v[t + tap][ch] (inside the window), db[ch] += sum dO
+// thread = one 8-channel chunk x a strided set of tokens; workgroup partials through LDS, then fp32 atomics
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void lepe_wgrad_kernel(const ga_cswin_attn_desc d, const void* dout_, float* dw0, float* db0,
+                                                         float* dw1, float* db1) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [rows per block][C8][80]
+    const int C8 = d.C / 8;
+    const int cc = threadIdx.x % C8, rib = threadIdx.x / C8, rpb = 256 / C8;
+    const T* dout = reinterpret_cast<const T*>(dout_);
+    const T* v = reinterpret_cast<const T*>(d.qkv) + 2 * d.C;
+    const int cb = d.C / d.nbranch;
+    const int branch = (cc * 8) / cb;
+    const int Hs = d.Hs[branch], Ws = d.Ws[branch];
+    const long rows = (long)d.B * d.reso * d.reso;
+    float acc[10][8];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[k][e] = 0.f;
+    if (rib < rpb) {
+        for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
+            const int x = (int)(row % d.reso), y = (int)((row / d.reso) % d.reso);
+            const int ty = y % Hs, tx = x % Ws;
+            float g[8];
+            load8(dout + row * d.ldo + cc * 8, g);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[9][e] += g[e];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if ((unsigned)(ty + dy) < (unsigned)Hs && (unsigned)(tx + dx) < (unsigned)Ws) {
+                        float vv[8];
+                        load8(v + (row + (long)dy * d.reso + dx) * d.ldq + cc * 8, vv);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[(dy + 1) * 3 + dx + 1][e] = fmaf(g[e], vv[e], acc[(dy + 1) * 3 + dx + 1][e]);
+                    }
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[(rib * C8 + cc) * 80 + k * 8 + e] = acc[k][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C8 * 80; i += 256) {
+        float s = 0.f;
+        for (int r = 0; r < rpb; ++r) s += red[r * C8 * 80 + i];
+        const int c8 = i / 80, k = (i % 80) / 8, e = i % 8;
+        const int ch = c8 * 8 + e, br = ch / cb, chb = ch - br * cb;
+        float* dw = br ? dw1 : dw0;
+        float* db = br ? db1 : db0;
+        if (k < 9) atomicAdd(dw + (long)chb * 9 + k, s);
+        else atomicAdd(db + chb, s);
+    }
+}
+
+// =================================================================================================================
+// deep-stem helpers
+// =================================================================================================================
+// fp32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] (channels 3..7 zero) in T: the first stem conv then is an ordinary NHWC gather
+template <typename T>
+__global__ __launch_bounds__(256) void nchw3_to_nhwc8_kernel(const float* __restrict__ x, T* __restrict__ y, long npix, long HW) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const long b = i / HW, p = i - b * HW;
+        const float* s = x + b * 3 * HW + p;
+        float v[8] = {s[0], s[HW], s[2 * HW], 0.f, 0.f, 0.f, 0.f, 0.f};
+        store8(y + i * 8, v);
+    }
+}
+
+// conv weight fp32 [Co][Ci][T taps] -> effective [Co][ldo] in T with k = tap*Cp + ci (ci < Ci, zero padded to Cp)
+template <typename T>
+__global__ __launch_bounds__(256) void convw_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int Tp,
+                                                         int Cp, long ldo) {
+    const long n = (long)Co * ldo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int co = (int)(i / ldo), k = (int)(i - (long)co * ldo);
+        const int tap = k / Cp, ci = k - tap * Cp;
+        float v = 0.f;
+        if (tap < Tp && ci < Ci) v = w[((long)co * Ci + ci) * Tp + tap];
+        elt<T>::st(out + i, v);
+    }
+}
+
+// dW[co][ci][tap] += G[co][tap*Cp + ci]
+__global__ __launch_bounds__(256) void convw_unpack_grad_kernel(const float* __restrict__ G, float* __restrict__ dW, int Co, int Ci,
+                                                                int Tp, int Cp, long ldg) {
+    const long n = (long)Co * Ci * Tp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int tap = (int)(i % Tp);
+        const long t = i / Tp;
+        const int ci = (int)(t % Ci), co = (int)(t / Ci);
+        dW[i] += G[(long)co * ldg + tap * Cp + ci];
+    }
+}
+
+// data-gradient operand of a 3x3 / stride 2 / pad 1 convolution: Bt[(py,px,ci)][(ay,ax,co)] = w[co][ci][ky][kx] with
+// (py,ay) -> ky: (0,0) -> 1, (1,0) -> 2, (1,1) -> 0, (0,1) -> none (same for x); zeros elsewhere.  The product
+// GA_A_NEIGH2(dy) . Bt^T scattered with GA_C_UNPATCH2 is the transposed convolution.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3s2_dgrad_prep_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci,
+                                                                 long ldo) {
+    const long n = (long)4 * Ci * ldo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int row = (int)(i / ldo), k = (int)(i - (long)row * ldo);
+        const int pq = row / Ci, ci = row - pq * Ci;
+        const int py = pq >> 1, px = pq & 1;
+        float v = 0.f;
+        if (k < 4 * Co) {
+            const int a = k / Co, co = k - a * Co;
+            const int ay = a >> 1, ax = a & 1;
+            const int ky = py == 0 ? (ay == 0 ? 1 : -1) : (ay == 0 ? 2 : 0);
+            const int kx = px == 0 ? (ax == 0 ? 1 : -1) : (ax == 0 ? 2 : 0);
+            if (ky >= 0 && kx >= 0) v = w[(((long)co * Ci + ci) * 3 + ky) * 3 + kx];
+        }
+        elt<T>::st(out + i, v);
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_desc(const ga_cswin_attn_desc* d, const char* what) {
+    GA_REQUIRE(d && d->qkv && d->B > 0 && d->reso > 0 && d->C > 0 && d->heads > 0, "%s: null / empty descriptor", what);
+    GA_REQUIRE(d->nbranch == 1 || d->nbranch == 2, "%s: nbranch must be 1 or 2", what);
+    GA_REQUIRE(d->heads % d->nbranch == 0 && d->C % d->heads == 0, "%s: C=%d heads=%d nbranch=%d do not divide", what, d->C,
+               d->heads, d->nbranch);
+    const int hd = d->C / d->heads;
+    GA_REQUIRE(hd == 8 || hd == 16 || hd == 32, "%s: head_dim %d not in {8, 16, 32}", what, hd);
+    for (int i = 0; i < d->nbranch; ++i) {
+        GA_REQUIRE(d->Hs[i] > 0 && d->Ws[i] > 0 && d->reso % d->Hs[i] == 0 && d->reso % d->Ws[i] == 0 &&
+                       d->Hs[i] * d->Ws[i] <= 128,
+                   "%s: stripe %dx%d does not tile %d or exceeds 128 tokens", what, d->Hs[i], d->Ws[i], d->reso);
+        GA_REQUIRE(d->lepe_w[i] && d->lepe_b[i], "%s: LePE weights missing", what);
+    }
+    if (d->nbranch == 2)
+        GA_REQUIRE(d->reso / d->Hs[0] * (d->reso / d->Ws[0]) == d->reso / d->Hs[1] * (d->reso / d->Ws[1]),
+                   "%s: both branches must have the same number of windows", what);
+    GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "%s: bad dtype", what);
+    const int epc = d->dtype == GA_BF16 ? 8 : 4;
+    GA_REQUIRE(aligned16(d->qkv) && d->ldq % epc == 0 && d->ldq >= 3 * d->C && d->C % 8 == 0, "%s: qkv alignment / ldq", what);
+    return GA_OK;
+}
+
+bool use_mfma(const ga_cswin_attn_desc* d) {
+    const char* e = getenv("GAEXT_CSWIN_MFMA");           // 0: generic form everywhere (read per call: tests switch it)
+    const int force = e ? atoi(e) : 1;
+    if (!force || d->dtype != GA_BF16 || d->C / d->heads != 32) return false;
+    for (int i = 0; i < d->nbranch; ++i)
+        if (d->Hs[i] * d->Ws[i] > 112) return false;
+    return true;
+}
+
+template <typename K> bool set_lds(K kern, size_t bytes) {
+    return bytes <= 65536 ||
+           hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_cswin_attn_fwd")) return rc;
+    GA_REQUIRE(d->out && aligned16(d->out) && d->ldo >= d->C && d->ldo % (d->dtype == GA_BF16 ? 8 : 4) == 0,
+               "ga_cswin_attn_fwd: out alignment / ldo");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nwin = (d->reso / d->Hs[0]) * (d->reso / d->Ws[0]);
+    const int items = d->B * nwin * d->heads;
+    const int hd = d->C / d->heads;
+    int nmax = 0;
+    for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
+    if (use_mfma(d)) {
+        if (nmax <= 64) {
+            const size_t lds = 3 * AT<4>::TILE + 4096;
+            hipLaunchKernelGGL(cswin_attn_fwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, items);
+        } else {
+            const size_t lds = 3 * AT<7>::TILE + 4096;
+            hipLaunchKernelGGL(cswin_attn_fwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, items);
+        }
+        return ga_check_launch("ga_cswin_attn_fwd");
+    }
+    const size_t lds = ((size_t)3 * 128 * (hd + 1) + (size_t)nmax * (nmax + 1)) * sizeof(float);
+#define GA_FWD(T, HD)                                                                                              \
+    do {                                                                                                           \
+        GA_REQUIRE(set_lds(cswin_attn_fwd_simple<T, HD>, lds), "ga_cswin_attn_fwd: cannot reserve %zu B of LDS", lds); \
+        hipLaunchKernelGGL((cswin_attn_fwd_simple<T, HD>), dim3(items), dim3(128), lds, s, *d);                    \
+    } while (0)
+    if (d->dtype == GA_BF16) {
+        if (hd == 8) GA_FWD(bf16_t, 8); else if (hd == 16) GA_FWD(bf16_t, 16); else GA_FWD(bf16_t, 32);
+    } else {
+        if (hd == 8) GA_FWD(float, 8); else if (hd == 16) GA_FWD(float, 16); else GA_FWD(float, 32);
+    }
+#undef GA_FWD
+    return ga_check_launch("ga_cswin_attn_fwd");
+}
+
+extern "C" int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_cswin_attn_bwd")) return rc;
+    GA_REQUIRE(dout && dqkv && aligned16(dout) && aligned16(dqkv) && d->ldo >= d->C && d->ldo % (d->dtype == GA_BF16 ? 8 : 4) == 0,
+               "ga_cswin_attn_bwd: dout / dqkv alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nwin = (d->reso / d->Hs[0]) * (d->reso / d->Ws[0]);
+    const int items = d->B * nwin * d->heads;
+    const int hd = d->C / d->heads;
+    int nmax = 0;
+    for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
+    if (use_mfma(d)) {
+        if (nmax <= 64) {
+            const size_t lds = 4 * AT<4>::TILE + 4096 + 2 * AT<4>::KP * sizeof(float);
+            hipLaunchKernelGGL(cswin_attn_bwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, items);
+        } else {
+            const size_t lds = 4 * AT<7>::TILE + 4096 + 2 * AT<7>::KP * sizeof(float);
+            hipLaunchKernelGGL(cswin_attn_bwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, items);
+        }
+        return ga_check_launch("ga_cswin_attn_bwd");
+    }
+    const size_t lds = ((size_t)4 * 128 * (hd + 1) + (size_t)2 * nmax * (nmax + 1)) * sizeof(float);
+#define GA_BWD(T, HD)                                                                                              \
+    do {                                                                                                           \
+        GA_REQUIRE(set_lds(cswin_attn_bwd_simple<T, HD>, lds), "ga_cswin_attn_bwd: cannot reserve %zu B of LDS", lds); \
+        hipLaunchKernelGGL((cswin_attn_bwd_simple<T, HD>), dim3(items), dim3(128), lds, s, *d, dout, dqkv);        \
+    } while (0)
+    if (d->dtype == GA_BF16) {
+        if (hd == 8) GA_BWD(bf16_t, 8); else if (hd == 16) GA_BWD(bf16_t, 16); else GA_BWD(bf16_t, 32);
+    } else {
+        if (hd == 8) GA_BWD(float, 8); else if (hd == 16) GA_BWD(float, 16); else GA_BWD(float, 32);
+    }
+#undef GA_BWD
+    return ga_check_launch("ga_cswin_attn_bwd");
+}
+
+extern "C" int ga_cswin_lepe_wgrad(const ga_cswin_attn_desc* d, const void* dout, float* dw0, float* db0, float* dw1,
+                                   float* db1, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_cswin_lepe_wgrad")) return rc;
+    GA_REQUIRE(dout && dw0 && db0 && (d->nbranch == 1 || (dw1 && db1)), "ga_cswin_lepe_wgrad: null gradient");
+    GA_REQUIRE(d->C / 8 <= 256 && (d->C / d->nbranch) % 8 == 0, "ga_cswin_lepe_wgrad: C=%d unsupported", d->C);
+    const int C8 = d->C / 8, rpb = 256 / C8;
+    const long rows = (long)d->B * d->reso * d->reso;
+    const int grid = (int)std::max<long>(1, std::min<long>(1024, (rows + 4L * rpb - 1) / (4L * rpb)));
+    const size_t lds = (size_t)rpb * C8 * 80 * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == GA_BF16) {
+        GA_REQUIRE(set_lds(lepe_wgrad_kernel<bf16_t>, lds), "ga_cswin_lepe_wgrad: LDS");
+        hipLaunchKernelGGL(lepe_wgrad_kernel<bf16_t>, dim3(grid), dim3(256), lds, s, *d, dout, dw0, db0, dw1, db1);
+    } else {
+        GA_REQUIRE(set_lds(lepe_wgrad_kernel<float>, lds), "ga_cswin_lepe_wgrad: LDS");
+        hipLaunchKernelGGL(lepe_wgrad_kernel<float>, dim3(grid), dim3(256), lds, s, *d, dout, dw0, db0, dw1, db1);
+    }
+    return ga_check_launch("ga_cswin_lepe_wgrad");
+}
+
+extern "C" int ga_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && aligned16(y), "ga_nchw3_to_nhwc8: bad args");
+    const long npix = (long)B * H * W;
+    const int grid = (int)std::min<long>(4096, (npix + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(nchw3_to_nhwc8_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, (bf16_t*)y, npix, (long)H * W);
+    else hipLaunchKernelGGL(nchw3_to_nhwc8_kernel<float>, dim3(grid), dim3(256), 0, s, x, (float*)y, npix, (long)H * W);
+    return ga_check_launch("ga_nchw3_to_nhwc8");
+}
+
+extern "C" int ga_convw_pack(const float* w, void* out, int Co, int Ci, int taps, int Cp, int64_t ldo, int dtype,
+                             ga_stream_t stream) {
+    GA_REQUIRE(w && out && Co > 0 && Ci > 0 && taps > 0 && Cp >= Ci && ldo >= (int64_t)taps * Cp, "ga_convw_pack: bad args");
+    const long n = (long)Co * ldo;
+    const int grid = (int)std::min<long>(2048, (n + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(convw_pack_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, taps, Cp, (long)ldo);
+    else hipLaunchKernelGGL(convw_pack_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, Co, Ci, taps, Cp, (long)ldo);
+    return ga_check_launch("ga_convw_pack");
+}
+
+extern "C" int ga_convw_unpack_grad(const float* G, float* dW, int Co, int Ci, int taps, int Cp, int64_t ldg,
+                                    ga_stream_t stream) {
+    GA_REQUIRE(G && dW && Co > 0 && Ci > 0 && taps > 0 && Cp >= Ci && ldg >= (int64_t)taps * Cp, "ga_convw_unpack_grad: bad args");
+    const long n = (long)Co * Ci * taps;
+    const int grid = (int)std::min<long>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(convw_unpack_grad_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), G, dW, Co, Ci,
+                       taps, Cp, (long)ldg);
+    return ga_check_launch("ga_convw_unpack_grad");
+}
+
+extern "C" int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, int64_t ldo, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(w && out && Co > 0 && Ci > 0 && ldo >= 4L * Co, "ga_conv3s2_dgrad_prep: bad args");
+    const long n = 4L * Ci * ldo;
+    const int grid = (int)std::min<long>(2048, (n + 255) / 256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(conv3s2_dgrad_prep_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, (long)ldo);
+    else hipLaunchKernelGGL(conv3s2_dgrad_prep_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, Co, Ci, (long)ldo);
+    return ga_check_launch("ga_conv3s2_dgrad_prep");
+}

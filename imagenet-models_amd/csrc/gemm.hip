@@ -64,7 +64,7 @@ __device__ __forceinline__ RowCtx make_row(int kind, long m, long M, long ld, in
         const int oy = (int)(t % OH);
         const long b = t / OH;
         r.base = ((b * H + 2 * oy) * W + 2 * ox) * (long)C;
-    } else if (kind == GA_A_CONV3) {
+    } else if (kind == GA_A_CONV3 || kind == GA_A_NEIGH2) {
         const int x = (int)(m % W);
         const long t = m / W;
         const int y = (int)(t % H);
@@ -72,6 +72,15 @@ __device__ __forceinline__ RowCtx make_row(int kind, long m, long M, long ld, in
         r.base = b * H * W;  // pixel index of the image start
         r.y = y;
         r.x = x;
+    } else if (kind == GA_A_CONV3S2) {   // rows = output pixels of the stride-2 conv; (y, x) = centre tap in the input
+        const int OW = (W + 1) >> 1, OH = (H + 1) >> 1;
+        const int ox = (int)(m % OW);
+        const long t = m / OW;
+        const int oy = (int)(t % OH);
+        const long b = t / OH;
+        r.base = b * H * W;
+        r.y = 2 * oy;
+        r.x = 2 * ox;
     } else {  // GA_A_STEM4_NCHW: fp32 NCHW input, C == 3 planes
         const int OW = W >> 2, OH = H >> 2;
         const int ox = (int)(m % OW);
@@ -101,10 +110,15 @@ __device__ __forceinline__ KCtx make_k(int kind, int k, int K, int H, int W, int
     } else if (kind == GA_A_PATCH2) {
         const int tap = k / C, ch = k - tap * C;
         c.off = ((long)(tap >> 1) * W + (tap & 1)) * C + ch;
-    } else if (kind == GA_A_CONV3) {
+    } else if (kind == GA_A_CONV3 || kind == GA_A_CONV3S2) {
         const int tap = k / C, ch = k - tap * C;
         c.dy = tap / 3 - 1;
         c.dx = tap % 3 - 1;
+        c.off = ((long)c.dy * W + c.dx) * C + ch;
+    } else if (kind == GA_A_NEIGH2) {    // taps (0,0) (0,1) (1,0) (1,1)
+        const int tap = k / C, ch = k - tap * C;
+        c.dy = tap >> 1;
+        c.dx = tap & 1;
         c.off = ((long)c.dy * W + c.dx) * C + ch;
     } else {  // stem: k = (c, ky, kx)
         const int ch = k >> 4, ky = (k >> 2) & 3;
@@ -118,7 +132,7 @@ __device__ __forceinline__ uint4 load_chunk(int kind, const void* base, const Ro
                                             int C) {
     uint4 z = make_uint4(0, 0, 0, 0);
     if (!(r.valid && k.valid)) return z;
-    if (kind == GA_A_CONV3) {
+    if (kind == GA_A_CONV3 || kind == GA_A_CONV3S2 || kind == GA_A_NEIGH2) {
         const int yy = r.y + k.dy, xx = r.x + k.dx;
         if ((unsigned)yy >= (unsigned)H || (unsigned)xx >= (unsigned)W) return z;
         const long pix = r.base + (long)r.y * W + r.x;
@@ -1213,6 +1227,12 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
     } else if (d->a_kind == GA_A_CONV3) {
         GA_REQUIRE(d->a_C % epc == 0 && d->K == 9 * d->a_C && (long)d->M % (d->a_H * d->a_W) == 0,
                    "ga_gemm: CONV3 needs C%%%d==0, K==9C", epc);
+    } else if (d->a_kind == GA_A_CONV3S2) {
+        GA_REQUIRE(d->a_C % epc == 0 && d->K == 9 * d->a_C && (long)d->M % (((d->a_H + 1) / 2) * ((d->a_W + 1) / 2)) == 0,
+                   "ga_gemm: CONV3S2 needs C%%%d==0, K==9C", epc);
+    } else if (d->a_kind == GA_A_NEIGH2) {
+        GA_REQUIRE(d->a_C % epc == 0 && d->K == 4 * d->a_C && (long)d->M % (d->a_H * d->a_W) == 0,
+                   "ga_gemm: NEIGH2 needs C%%%d==0, K==4C", epc);
     } else if (d->a_kind == GA_A_STEM4_NCHW) {
         GA_REQUIRE(d->a_C == 3 && d->K == 48 && d->a_H % 4 == 0 && d->a_W % 4 == 0, "ga_gemm: STEM4 needs C=3,K=48");
     } else {
@@ -1310,6 +1330,10 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
         GA_REQUIRE(d->x_C % epc == 0 && d->K == 4 * d->x_C, "ga_wgrad: PATCH2 needs K==4C");
     } else if (d->x_kind == GA_A_CONV3) {
         GA_REQUIRE(d->x_C % epc == 0 && d->K == 9 * d->x_C, "ga_wgrad: CONV3 needs K==9C");
+    } else if (d->x_kind == GA_A_CONV3S2) {
+        GA_REQUIRE(d->x_C % epc == 0 && d->K == 9 * d->x_C, "ga_wgrad: CONV3S2 needs K==9C");
+    } else if (d->x_kind == GA_A_NEIGH2) {
+        GA_REQUIRE(d->x_C % epc == 0 && d->K == 4 * d->x_C, "ga_wgrad: NEIGH2 needs K==4C");
     } else if (d->x_kind == GA_A_STEM4_NCHW) {
         GA_REQUIRE(d->x_C == 3 && d->K == 48, "ga_wgrad: STEM4 needs C=3,K=48");
     } else {

@@ -13,7 +13,7 @@ import os
 import torch
 
 from . import _lib as L
-from ._lib import (A_CONV3, A_PATCH2, A_PLAIN, A_STEM4_NCHW, ACT_GELU, ACT_NONE, ACT_RELU, C_PLAIN, C_UNPATCH2,  # noqa: F401
+from ._lib import (A_CONV3, A_CONV3S2, A_NEIGH2, A_PATCH2, A_PLAIN, A_STEM4_NCHW, ACT_GELU, ACT_NONE, ACT_RELU, C_PLAIN, C_UNPATCH2,  # noqa: F401
                    GA_BF16, GA_F32)
 
 
@@ -461,6 +461,44 @@ class Plan:
         self._add('ga_class_attn_bwd2', (_ptr(dout), _ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(P), _ptr(dq), _ptr(dkv_cls),
                                          _ptr(dkv_tok), B, N, heads, hd, scale, dtype), label,
                   keep=(dout, q, kv_cls, kv_tok, P, dq, dkv_cls, dkv_tok))
+
+    # -- GA-CSWin ----------------------------------------------------------------------------------
+    def cswin_desc(self, qkv, out, B, reso, Cdim, heads, stripes, lepe, scale, dtype, ldq=None, ldo=None):
+        """descriptor of one CSWinBlock's stripe attention: stripes = [(Hs, Ws)] per branch, lepe = [(w [Cb,1,3,3], b [Cb])]"""
+        d = L.CswinAttnDesc()
+        d.B, d.reso, d.C, d.heads, d.nbranch = B, reso, Cdim, heads, len(stripes)
+        for i, ((hs, ws), (w, b)) in enumerate(zip(stripes, lepe)):
+            d.Hs[i], d.Ws[i] = hs, ws
+            d.lepe_w[i], d.lepe_b[i] = _ptr(w), _ptr(b)
+        d.scale, d.dtype = scale, dtype
+        d.qkv, d.ldq = _ptr(qkv), (3 * Cdim if ldq is None else ldq)
+        d.out, d.ldo = _ptr(out), (Cdim if ldo is None else ldo)
+        self.keep.extend([d, qkv, out] + [t for pair in lepe for t in pair])
+        return d
+
+    def cswin_attn_fwd(self, d, label=None):
+        self._add('ga_cswin_attn_fwd', (C.byref(d),), label, keep=(d,))
+
+    def cswin_attn_bwd(self, d, dout, dqkv, label=None):
+        self._add('ga_cswin_attn_bwd', (C.byref(d), _ptr(dout), _ptr(dqkv)), label, keep=(d, dout, dqkv))
+
+    def cswin_lepe_wgrad(self, d, dout, grads, label=None):
+        """grads = [(dw, db)] per branch (fp32, accumulated into)"""
+        g = list(grads) + [(None, None)] * (2 - len(grads))
+        self._add('ga_cswin_lepe_wgrad', (C.byref(d), _ptr(dout), _ptr(g[0][0]), _ptr(g[0][1]), _ptr(g[1][0]), _ptr(g[1][1])),
+                  label, keep=(d, dout) + tuple(t for pair in grads for t in pair))
+
+    def nchw3_to_nhwc8(self, x, y, B, H, W, dtype, label=None):
+        self._add('ga_nchw3_to_nhwc8', (_ptr(x), _ptr(y), B, H, W, dtype), label, keep=(x, y))
+
+    def convw_pack(self, w, out, Co, Ci, taps, Cp, ldo, dtype, label=None):
+        self._add('ga_convw_pack', (_ptr(w), _ptr(out), Co, Ci, taps, Cp, ldo, dtype), label, keep=(w, out))
+
+    def convw_unpack_grad(self, G, dW, Co, Ci, taps, Cp, ldg, label=None):
+        self._add('ga_convw_unpack_grad', (_ptr(G), _ptr(dW), Co, Ci, taps, Cp, ldg), label, keep=(G, dW))
+
+    def conv3s2_dgrad_prep(self, w, out, Co, Ci, ldo, dtype, label=None):
+        self._add('ga_conv3s2_dgrad_prep', (_ptr(w), _ptr(out), Co, Ci, ldo, dtype), label, keep=(w, out))
 
     # -- loss / metric / optimizer ------------------------------------------------------------------
     def loss_fwd_bwd(self, logits, target, loss, dlogits, K, B, NC, lam, kind, smoothing, grad_scale, dtype, label=None):

@@ -35,7 +35,12 @@ enum {
     GA_A_PLAIN = 0,      /* A[m*lda + k]                                                              */
     GA_A_PATCH2 = 1,     /* NHWC [B,H,W,C] -> rows (b,oy,ox) of the 2x2/s2 patches, k = (ky,kx,c)    (ga_convnext.py:127) */
     GA_A_STEM4_NCHW = 2, /* fp32 NCHW [B,3,H,W] -> rows (b,oy,ox) of the 4x4/s4 patches, k=(c,ky,kx) (ga_convnext.py:357) */
-    GA_A_CONV3 = 3       /* NHWC [B,H,W,C], 3x3 pad 1 stride 1, k = (ky,kx,c)                         (ga_convnext.py:273) */
+    GA_A_CONV3 = 3,      /* NHWC [B,H,W,C], 3x3 pad 1 stride 1, k = (ky,kx,c)                         (ga_convnext.py:273) */
+    GA_A_CONV3S2 = 4,    /* NHWC [B,H,W,C], 3x3 pad 1 stride 2 -> rows (b,oy,ox) of the [(H+1)/2, (W+1)/2] output,
+                            k = (ky,kx,c): the deep stem and Merge_Block convs        (ga_cswin.py:464,474,256) */
+    GA_A_NEIGH2 = 5      /* NHWC [B,H,W,C], rows (b,y,x), k = (ay,ax,c) reads pixel (y+ay, x+ax), ay,ax in {0,1}, zero
+                            beyond the map: with ga_conv3s2_dgrad_prep's operand and GA_C_UNPATCH2 it is the
+                            data-gradient (transposed convolution) of GA_A_CONV3S2 */
 };
 /* C-output kinds */
 enum {
@@ -330,6 +335,41 @@ int ga_lamb_stage2(float* p, const float* u, const float* hp, const int* chunks,
  *   ga_clip_grad_f32 mode 0 ('norm'): g *= min(1, limit / (sqrt(*sumsq) + 1e-6));  mode 1 ('value'): clamp to [-limit, limit] */
 int ga_sumsq_f32(const float* x, int64_t n, float* out, ga_stream_t stream);
 int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float limit, int mode, ga_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GA-CSWin: cross-shaped stripe-window attention with LePE (LePEAttention.forward, ga_cswin.py:110-136; get_lepe
+ * :95-108; img2windows / windows2img :215-233) for the 1 or 2 branches of a CSWinBlock (:202-207) in ONE launch.
+ *   qkv [B*L][ldq]: q | k | v column blocks of width C (tokens in image raster order, L = reso*reso);
+ *   branch i owns channels [i*C/nbranch, (i+1)*C/nbranch) of each block, heads/nbranch heads, stripes Hs[i] x Ws[i];
+ *   out[b, t, ch] = softmax_j((q_t * scale) . k_j) v_j + conv3x3_depthwise(v)(t)   over the tokens j of t's stripe,
+ *   the 3x3 (lepe_w[i]: fp32 [C/nbranch][9] = get_v.weight, lepe_b[i]) zero padded at the STRIPE border.
+ *   head_dim in {8, 16, 32}; Hs*Ws <= 128.  bf16 with head_dim 32 runs on MFMA, everything else on a generic fp32 form.
+ * bwd: dqkv [B*L][ldq] = d(q | k | v) from dout [B*L][ldo]  (dv includes the LePE transpose);
+ * lepe_wgrad: dw_i[ch][tap] += sum dout * shifted v, db_i[ch] += sum dout  (fp32 atomics). */
+typedef struct {
+    int B, reso, C, heads, nbranch;
+    int Hs[2], Ws[2];
+    const float* lepe_w[2];
+    const float* lepe_b[2];
+    float scale;
+    int dtype;
+    const void* qkv; int64_t ldq;
+    void* out; int64_t ldo;
+} ga_cswin_attn_desc;
+int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream);
+int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, ga_stream_t stream);
+int ga_cswin_lepe_wgrad(const ga_cswin_attn_desc* d, const void* dout, float* dw0, float* db0, float* dw1, float* db1,
+                        ga_stream_t stream);
+/* deep-stem helpers (ga_cswin.py:463-477):
+ *   ga_nchw3_to_nhwc8: fp32 NCHW [B,3,H,W] -> NHWC [B,H,W,8] in `dtype`, channels 3..7 zero (the first 3x3/s2 conv then is
+ *                      a GA_A_CONV3S2 gather with C = 8);
+ *   ga_convw_pack:     fp32 [Co][Ci][taps] -> out[co][tap*Cp + ci] in `dtype` (zero for ci >= Ci and up to ldo);
+ *   ga_convw_unpack_grad: dW[co][ci][tap] += G[co][tap*Cp + ci];
+ *   ga_conv3s2_dgrad_prep: fp32 [Co][Ci][3][3] -> out[(py,px,ci)][(ay,ax,co)] (4*Ci rows, ldo >= 4*Co), see GA_A_NEIGH2 */
+int ga_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, ga_stream_t stream);
+int ga_convw_pack(const float* w, void* out, int Co, int Ci, int taps, int Cp, int64_t ldo, int dtype, ga_stream_t stream);
+int ga_convw_unpack_grad(const float* G, float* dW, int Co, int Ci, int taps, int Cp, int64_t ldg, ga_stream_t stream);
+int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, int64_t ldo, int dtype, ga_stream_t stream);
 
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
