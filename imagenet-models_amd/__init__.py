@@ -12,6 +12,8 @@ __version__ = '0.1.0'
 from .registry import create_model, is_model, list_models, register_model  # noqa: E402,F401
 from . import ga_convnext  # noqa: E402,F401  (registers the ga_convnext_* entry points)
 from .ga_convnext import GA_ConvNeXt  # noqa: E402,F401
+from . import ga_cswin  # noqa: E402,F401  (registers the ga_CSWin_* entry points)
+from .ga_cswin import GA_CSWinTransformer  # noqa: E402,F401
 from .loss import ga_loss, heads_topk, accuracy_from_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401
 from .trainer import TrainStep  # noqa: E402,F401

@@ -115,6 +115,8 @@ _SIGS = {
     'ga_cswin_attn_fwd': ([C.POINTER(CswinAttnDesc), vp], i32),
     'ga_cswin_attn_bwd': ([C.POINTER(CswinAttnDesc), vp, vp, vp], i32),
     'ga_cswin_lepe_wgrad': ([C.POINTER(CswinAttnDesc), vp, vp, vp, vp, vp, vp], i32),
+    'ga_layernorm_gelu_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
+    'ga_layernorm_gelu_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),
     'ga_nchw3_to_nhwc8': ([vp, vp, i32, i32, i32, i32, vp], i32),
     'ga_convw_pack': ([vp, vp, i32, i32, i32, i32, i64, i32, vp], i32),
     'ga_convw_unpack_grad': ([vp, vp, i32, i32, i32, i32, i64, vp], i32),

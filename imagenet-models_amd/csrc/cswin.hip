@@ -703,6 +703,99 @@ __global__ __launch_bounds__(256) void conv3s2_dgrad_prep_kernel(const float* __
     }
 }
 
+// =================================================================================================================
+// LayerNorm (affine, over C) followed by GELU, as the deep stem applies it between its convs (ga_cswin.py:466-473):
+// a row of C = 8 * G channels on G lanes (G a power of two <= 64), one 8-channel chunk per lane.
+//   fwd: y = gelu(xhat * w + b), mean / rstd saved;   bwd: gz = g * gelu'(xhat * w + b), then the LayerNorm backward
+// =================================================================================================================
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, T* __restrict__ y, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, long rows, float eps) {
+    constexpr int C = 8 * G, RPB = 256 / G;
+    const int lg = threadIdx.x % G, rib = threadIdx.x / G;
+    float wv[8], bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        wv[e] = w[lg * 8 + e];
+        bv[e] = b[lg * 8 + e];
+    }
+    for (long row = (long)blockIdx.x * RPB + rib; row < rows; row += (long)gridDim.x * RPB) {
+        float v[8];
+        load8(x + row * C + lg * 8, v);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[e];
+        const float mu = group_sum<G>(s) * (1.f / C);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += (v[e] - mu) * (v[e] - mu);
+        const float rs = rsqrtf(group_sum<G>(q) * (1.f / C) + eps);
+        if (lg == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(fmaf((v[e] - mu) * rs, wv[e], bv[e]));
+        store8(y + row * C + lg * 8, v);
+    }
+}
+
+template <typename T, int G>
+__global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          T* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                                          long rows) {
+    constexpr int C = 8 * G, RPB = 256 / G;
+    __shared__ float red[2 * 256 * 8];
+    const int lg = threadIdx.x % G, rib = threadIdx.x / G;
+    float wv[8], bv[8], aw[8], ab[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        wv[e] = w[lg * 8 + e];
+        bv[e] = b[lg * 8 + e];
+        aw[e] = ab[e] = 0.f;
+    }
+    for (long row = (long)blockIdx.x * RPB + rib; row < rows; row += (long)gridDim.x * RPB) {
+        float gv[8], xh[8];
+        load8(g + row * C + lg * 8, gv);
+        load8(x + row * C + lg * 8, xh);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            xh[e] = (xh[e] - mu) * rs;
+            const float gz = gv[e] * gelu_grad_f(fmaf(xh[e], wv[e], bv[e]));
+            aw[e] = fmaf(gz, xh[e], aw[e]);
+            ab[e] += gz;
+            gv[e] = gz * wv[e];
+            s1 += gv[e];
+            s2 = fmaf(gv[e], xh[e], s2);
+        }
+        s1 = group_sum<G>(s1) * (1.f / C);
+        s2 = group_sum<G>(s2) * (1.f / C);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gv[e] = rs * (gv[e] - s1 - xh[e] * s2);
+        store8(dx + row * C + lg * 8, gv);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[threadIdx.x * 8 + e] = aw[e];
+        red[2048 + threadIdx.x * 8 + e] = ab[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, bb = 0.f;
+        for (int r = 0; r < RPB; ++r) {
+            a += red[(r * G + c / 8) * 8 + (c & 7)];
+            bb += red[2048 + (r * G + c / 8) * 8 + (c & 7)];
+        }
+        atomicAdd(dw + c, a);
+        atomicAdd(db + c, bb);
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int check_desc(const ga_cswin_attn_desc* d, const char* what) {
@@ -872,4 +965,53 @@ extern "C" int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, 
     if (dtype == GA_BF16) hipLaunchKernelGGL(conv3s2_dgrad_prep_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, (long)ldo);
     else hipLaunchKernelGGL(conv3s2_dgrad_prep_kernel<float>, dim3(grid), dim3(256), 0, s, w, (float*)out, Co, Ci, (long)ldo);
     return ga_check_launch("ga_conv3s2_dgrad_prep");
+}
+
+#define GA_LNG_DISPATCH(KERN, ...)                                                                     \
+    switch (G) {                                                                                       \
+        case 1: hipLaunchKernelGGL((KERN<T, 1>), __VA_ARGS__); break;                                  \
+        case 2: hipLaunchKernelGGL((KERN<T, 2>), __VA_ARGS__); break;                                  \
+        case 4: hipLaunchKernelGGL((KERN<T, 4>), __VA_ARGS__); break;                                  \
+        case 8: hipLaunchKernelGGL((KERN<T, 8>), __VA_ARGS__); break;                                  \
+        case 16: hipLaunchKernelGGL((KERN<T, 16>), __VA_ARGS__); break;                                \
+        case 32: hipLaunchKernelGGL((KERN<T, 32>), __VA_ARGS__); break;                                \
+        default: hipLaunchKernelGGL((KERN<T, 64>), __VA_ARGS__); break;                                \
+    }
+
+template <typename T>
+static void ln_gelu_fwd_t(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows, int C,
+                          float eps, hipStream_t s) {
+    const int G = C / 8;
+    const int grid = (int)std::max<long>(1, std::min<long>(4096, (rows + 256 / G - 1) / (256 / G)));
+    GA_LNG_DISPATCH(ln_gelu_fwd_kernel, dim3(grid), dim3(256), 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, eps);
+}
+
+template <typename T>
+static void ln_gelu_bwd_t(const void* g, const void* x, const float* mean, const float* rstd, const float* w, const float* b,
+                          void* dx, float* dw, float* db, int64_t rows, int C, hipStream_t s) {
+    const int G = C / 8;
+    const int grid = (int)std::max<long>(1, std::min<long>(1024, (rows + 256 / G - 1) / (256 / G)));
+    GA_LNG_DISPATCH(ln_gelu_bwd_kernel, dim3(grid), dim3(256), 0, s, (const T*)g, (const T*)x, mean, rstd, w, b, (T*)dx, dw, db,
+                    (long)rows);
+}
+
+extern "C" int ga_layernorm_gelu_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd,
+                                     int64_t rows, int C, float eps, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && w && b && y && mean && rstd && rows > 0, "ga_layernorm_gelu_fwd: null operand");
+    GA_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "ga_layernorm_gelu_fwd: C=%d must be a power of two in [8, 512]", C);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) ln_gelu_fwd_t<bf16_t>(x, w, b, y, mean, rstd, rows, C, eps, s);
+    else ln_gelu_fwd_t<float>(x, w, b, y, mean, rstd, rows, C, eps, s);
+    return ga_check_launch("ga_layernorm_gelu_fwd");
+}
+
+extern "C" int ga_layernorm_gelu_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
+                                     const float* b, void* dx, float* dw, float* db, int64_t rows, int C, int dtype,
+                                     ga_stream_t stream) {
+    GA_REQUIRE(g && x && mean && rstd && w && b && dx && dw && db && rows > 0, "ga_layernorm_gelu_bwd: null operand");
+    GA_REQUIRE(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "ga_layernorm_gelu_bwd: C=%d must be a power of two in [8, 512]", C);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) ln_gelu_bwd_t<bf16_t>(g, x, mean, rstd, w, b, dx, dw, db, rows, C, s);
+    else ln_gelu_bwd_t<float>(g, x, mean, rstd, w, b, dx, dw, db, rows, C, s);
+    return ga_check_launch("ga_layernorm_gelu_bwd");
 }

@@ -106,6 +106,7 @@ class GAEngine:
         # BatchNorm column-sum accumulators live in one pool that the forward plan zeroes with a single memset
         self.bn_pool = torch.zeros(1 << 16, device=self.dev)
         self.bn_pool_off = 0
+        self.bott_prefix = 'stages.4.'   # the SE-Bottleneck's parameter prefix (GA-CSWin with stage5='bottleneck': 'stage5.')
         self._build()
 
     # ------------------------------------------------------------------------------------------
@@ -290,7 +291,20 @@ class GAEngine:
         assert off == ctot
         # ---------------- Bottleneck "stage 4" ----------------
         x4 = self._bottleneck_fwd(cat, M4, ctot, d[4])
-        # ---------------- heads ----------------
+        self.cout = d[4]
+        self._build_heads(x4, M4, Hc)
+        # ---------------- backward ----------------
+        if T:
+            self._build_backward(feats, taps, stage_in, x4, M4, ctot)
+            if self.async_wgrad:
+                self.bwd.join_async()
+            self.bwd.flush('end.')
+        self.prep.flush('prep.')
+
+    def _build_heads(self, x4, M4, Hc):
+        """the five GA heads on the stage-4 / stage-5 map x4 [M4, cout] (ga_convnext.py:491-504, ga_cswin.py:677-692)"""
+        cfg, B, T, F, dt = self.cfg, self.B, self.training, self.fwd, self.dt
+        cout = self.cout
         NC, K = cfg['num_classes'], cfg['branches']
         assert NC % 8 == 0, 'num_classes must be a multiple of 8 (pad the classifier)'
         self.logits = self.buf('logits', (K, B, NC), torch.float32)
@@ -302,11 +316,11 @@ class GAEngine:
         E_, nh_ = cfg['dim_embed'], cfg['num_heads']
         self.shared_tok = E_ % nh_ == 0 and (E_ // nh_) % 8 == 0 and E_ <= 512   # what ga_class_attn_*2 supports
         if self.shared_tok:
-            self.tok = dict(xn=self.act('ga.tok.xn', (M4, d[4])), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
-            F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, d[4], 1e-5, dt, label='ga.tok.ln')
+            self.tok = dict(xn=self.act('ga.tok.xn', (M4, cout)), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
+            F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, cout, 1e-5, dt, label='ga.tok.ln')
             # the k | v rows of the image tokens of ALL heads from one GEMM over the shared tokens: the heads' effective
             # (norm1-folded) k|v weights are stacked along N; head k reads / writes the column slice [k*2E, (k+1)*2E)
-            E2, cout = 2 * E_, d[4]
+            E2 = 2 * E_
             tk = self.tok
             tk['E2'], tk['ld'] = E2, K * E2
             tk['W'] = self.buf('w.ga.kv_all', (K * E2, cout))
@@ -323,50 +337,48 @@ class GAEngine:
                 self.prep.bias_fold(pk, None, None, P[pre + 'norm1.bias'], tk['b'][k * E2:], E2, cout)
             tk['kv'] = self.act('ga.kv_all', (M4, K * E2))
             F.gemm(tk['xn'], tk['W'], tk['kv'], M4, K * E2, cout, dt, bias=tk['b'], label='ga.kv_all')
-        # gram_contraction (conv1x1 768 -> 192 + BN) of the five heads reads the same x4: ONE GEMM with the five weight
-        # matrices stacked along N; head k owns the column slice [k*g, (k+1)*g) of its output / statistics
-        g_ = cfg['gram_dim']
-        gc = self.gcon = dict(ld=K * g_)
-        gc['W'] = self.buf('w.gram_contraction.all', (K * g_, d[4]))
-        gc['WT'] = self.buf('wT.gram_contraction.all', (d[4], K * g_)) if T else None
-        gc['b'] = self.buf('w.gram_contraction.ball', (K * g_,), torch.float32)
-        gc['s'], gc['q'] = self._bn_pool(K * g_), self._bn_pool(K * g_)
-        for k in range(K):
-            pre = f'gram_contraction.{k}.'
-            self.prep.weight_prep(self.P[pre + '0.weight'], 1, g_, d[4], 1, 1, dt, out=gc['W'][k * g_:], ldo=d[4],
-                                  outT=gc['WT'][:, k * g_:] if T else None, ldt=K * g_ if T else 0, t_cols=g_,
-                                  label='prep.' + pre + 'w')
-            self.prep.bias_fold(None, self.P[pre + '0.bias'], None, None, gc['b'][k * g_:], g_, d[4])
-        gc['out'] = self.act('gram_contraction.all.out', (M4, K * g_))
-        F.gemm(x4, gc['W'], gc['out'], M4, K * g_, d[4], dt, bias=gc['b'], colsum=gc['s'] if T else None,
-               colsumsq=gc['q'] if T else None, label='gram_contraction.all')
+        self._contract_all_fwd(x4, M4)
         # classifiers: inputs of the five heads in one [K][B][cout] buffer, weights stacked -> one batched GEMM
-        fa = self.fc_all = dict(x=self.act('fc.all.x', (K, B, d[4])))
+        fa = self.fc_all = dict(x=self.act('fc.all.x', (K, B, cout)))
         ldn = pad8(NC)
-        fa['W'] = self.buf('w.fc.all', (K, NC, d[4]))
-        fa['WT'] = self.buf('wT.fc.all', (K, d[4], ldn)) if T else None
+        fa['W'] = self.buf('w.fc.all', (K, NC, cout))
+        fa['WT'] = self.buf('wT.fc.all', (K, cout, ldn)) if T else None
         fa['b'] = self.buf('w.fc.ball', (K, NC), torch.float32)
         for k in range(K):
-            self.prep.weight_prep(self.P[f'fc.{k}.weight'], 1, NC, d[4], 1, 1, dt, out=fa['W'][k], ldo=d[4],
+            self.prep.weight_prep(self.P[f'fc.{k}.weight'], 1, NC, cout, 1, 1, dt, out=fa['W'][k], ldo=cout,
                                   outT=fa['WT'][k] if T else None, ldt=ldn if T else 0, label=f'prep.fc.{k}')
-            self.prep.bias_fold(None, self.P[f'fc.{k}.bias'], None, None, fa['b'][k], NC, d[4])
+            self.prep.bias_fold(None, self.P[f'fc.{k}.bias'], None, None, fa['b'][k], NC, cout)
         # the heads are independent chains of mostly small launches: with GAEXT_HEAD_STREAMS=n > 1 head k runs on side
         # stream k % n (between a fork / join of the plan) with its own transient buffers
         self.head_lanes = int(os.environ.get('GAEXT_HEAD_STREAMS', '5')) if self.shared_tok else 1
         for k in range(K):
             if self.head_lanes > 1:
                 F.lane, self.tmp_prefix = 1 + k % self.head_lanes, f'h{k}.'
-            self.heads.append(self._head_fwd(k, x4, M4, d[4], Hc))
+            self.heads.append(self._head_fwd(k, x4, M4, cout, Hc))
         F.lane, self.tmp_prefix = 0, ''
-        F.gemm(fa['x'], fa['W'], self.logits, B, NC, d[4], dt, batch=K, strideA=B * d[4], strideB=NC * d[4], strideC=B * NC,
+        F.gemm(fa['x'], fa['W'], self.logits, B, NC, cout, dt, batch=K, strideA=B * cout, strideB=NC * cout, strideC=B * NC,
                bias=fa['b'], strideBias=NC, c_f32=True, label='fc.all')
-        # ---------------- backward ----------------
-        if T:
-            self._build_backward(feats, taps, stage_in, x4, M4, ctot)
-            if self.async_wgrad:
-                self.bwd.join_async()
-            self.bwd.flush('end.')
-        self.prep.flush('prep.')
+
+    def _contract_all_fwd(self, x4, M4):
+        cfg, T, F, dt, cout = self.cfg, self.training, self.fwd, self.dt, self.cout
+        K = cfg['branches']
+        # gram_contraction (conv1x1 768 -> 192 + BN) of the five heads reads the same x4: ONE GEMM with the five weight
+        # matrices stacked along N; head k owns the column slice [k*g, (k+1)*g) of its output / statistics
+        g_ = cfg['gram_dim']
+        gc = self.gcon = dict(ld=K * g_)
+        gc['W'] = self.buf('w.gram_contraction.all', (K * g_, cout))
+        gc['WT'] = self.buf('wT.gram_contraction.all', (cout, K * g_)) if T else None
+        gc['b'] = self.buf('w.gram_contraction.ball', (K * g_,), torch.float32)
+        gc['s'], gc['q'] = self._bn_pool(K * g_), self._bn_pool(K * g_)
+        for k in range(K):
+            pre = f'gram_contraction.{k}.'
+            self.prep.weight_prep(self.P[pre + '0.weight'], 1, g_, cout, 1, 1, dt, out=gc['W'][k * g_:], ldo=cout,
+                                  outT=gc['WT'][:, k * g_:] if T else None, ldt=K * g_ if T else 0, t_cols=g_,
+                                  label='prep.' + pre + 'w')
+            self.prep.bias_fold(None, self.P[pre + '0.bias'], None, None, gc['b'][k * g_:], g_, cout)
+        gc['out'] = self.act('gram_contraction.all.out', (M4, K * g_))
+        F.gemm(x4, gc['W'], gc['out'], M4, K * g_, cout, dt, bias=gc['b'], colsum=gc['s'] if T else None,
+               colsumsq=gc['q'] if T else None, label='gram_contraction.all')
 
     @staticmethod
     def _last_desc(plan):
@@ -555,7 +567,7 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     def _bottleneck_fwd(self, cat, M4, ctot, cout):
         F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
-        pre = 'stages.4.'
+        pre = self.bott_prefix
         w = cout // 4
         HW = M4 // B
         st = self.bott = dict(cat=cat, w=w, cout=cout, ctot=ctot)
@@ -608,7 +620,7 @@ class GAEngine:
 
     def _bottleneck_bwd(self, dx4, dcat):
         Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
-        pre = 'stages.4.'
+        pre = self.bott_prefix
         st = self.bott
         w, cout, ctot = st['w'], st['cout'], st['ctot']
         M4 = dx4.shape[0]
@@ -659,23 +671,97 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     # one GA head (ga_convnext.py:491-504)
     # ------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------
+    # GroupConvMlp (ga_convnext.py:190-222, ga_cswin.py:321-349): grouped fc1 -> GELU -> channel_shuffle -> grouped fc2
+    # on `rows` tokens.  The shuffle is folded into the ROW ORDER of fc1's effective weights: hidden index
+    # n = gi*gc + ci  <-  fc1 output channel ci*mg + gi; with Nv = gc / mg rows per "virtual group" the fc1 input group is
+    # constant inside one (= v % mg), so fc1 is a batched GEMM over mg*mg virtual groups and fc2 one over mg groups.
+    # ------------------------------------------------------------------------------------------
+    def _gmlp_fwd(self, pre, t, rows, C, mg, out, R, rowscale, rps, gamma_name=None):
+        """out = R + rowscale * gamma * fc2(shuffle(gelu(fc1(t))));  pre = '<block>.mlp.'"""
+        F, dt, P, T = self.fwd, self.dt, self.P, self.training
+        gamma = P[gamma_name] if gamma_name else None
+        Hd = 4 * C
+        gc_ = Hd // mg
+        Nv = gc_ // mg          # rows per virtual group (fc1 input group is constant inside one)
+        cin = C // mg
+        assert gc_ % mg == 0 and Nv % 8 == 0 and cin % 8 == 0, (pre, C, mg)
+        n_idx = torch.arange(Hd)
+        perm = ((n_idx % gc_) * mg + n_idx // gc_).to(torch.int32).to(self.dev)
+        Wm1 = self._w_plain(pre + 'fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
+        bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
+        st = dict(perm=perm, Hd=Hd, gc=gc_, Nv=Nv, cin=cin)
+        st['am'] = self.act(pre + 'am', (rows, Hd))                      # gelu(hidden), shuffled order
+        st['gm'] = self.act(pre + 'gm', (rows, Hd)) if T else None       # gelu'(hidden)
+        F.gemm(t, Wm1, st['am'], rows, Nv, cin, dt, lda=C, batch=mg * mg, strideA=cin, a_batch_mod=mg,
+               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ACT_GELU,
+               C2=st['gm'], c2_mode=2 if T else 0, label=pre + 'fc1')
+        Wm2 = self._w_plain(pre + 'fc2.weight', cin, gc_, 1, 1, groups=mg, rs=gamma)
+        bm2 = self.buf('w.' + pre + 'bm2', (C,), torch.float32)
+        self.prep.bias_fold(None, P[pre + 'fc2.bias'], gamma, None, bm2, C, gc_)
+        F.gemm(st['am'], Wm2, out, rows, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
+               ldb=pad8(gc_), ldc=C, strideC=cin, bias=bm2, strideBias=cin, rowscale=rowscale,
+               rows_per_scale=rps, R=R, ldr=C, strideR=cin, label=pre + 'fc2')
+        return st
+
+    def _gmlp_bwd(self, pre, st, dmz, t, rows, C, mg, dtk, gamma_name=None):
+        """dmz: gradient wrt the MLP branch output (DropPath scale already applied) -> dtk = gradient wrt the input t"""
+        Bk, dt, P, W = self.bwd, self.dt, self.P, self.W
+        gamma = P[gamma_name] if gamma_name else None
+        Hd, gc_, Nv, cin = st['Hd'], st['gc'], st['Nv'], st['cin']
+        # fc2 (mg groups)
+        Gm2, gbm2 = self.gbuf((C, gc_)), self.gbuf((C,))
+        Bk.wgrad(dmz, st['am'], Gm2, rows, cin, gc_, dt, ldy=C, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
+                 strideW=cin * gc_, dbias=gbm2, strideDbias=cin, label=pre + 'fc2.wg')
+        Bk.weight_unfold(Gm2, gc_, C, gc_, gb=gbm2, W=P[pre + 'fc2.weight'], b=P[pre + 'fc2.bias'],
+                         rs=gamma, dW=self.grad(pre + 'fc2.weight'), db=self.grad(pre + 'fc2.bias'),
+                         d_rs=self.grad(gamma_name) if gamma_name else None, label=pre + 'fc2.unf')
+        dhm = self.tmp('dhm', (rows, Hd))
+        gbm1 = self.gbuf((Hd,))
+        Bk.gemm(dmz, W[pre + 'fc2.weight.T'], dhm, rows, gc_, cin, dt, lda=C, batch=mg, strideA=cin,
+                strideB=gc_ * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=gc_, H=st['gm'], ldh=Hd, strideH=gc_, h_is_deriv=True,
+                colsum=gbm1, strideCol=gc_, label=pre + 'fc2.dg')
+        # fc1 (mg*mg virtual groups)
+        Gm1 = self.gbuf((Hd, cin))
+        Bk.wgrad(dhm, t, Gm1, rows, Nv, cin, dt, ldy=Hd, ldx=C, ldw=cin, batch=mg * mg, strideY=Nv, strideX=cin,
+                 x_batch_mod=mg, strideW=Nv * cin, label=pre + 'fc1.wg')
+        Bk.weight_unfold(Gm1, cin, Hd, cin, gb=gbm1, W=P[pre + 'fc1.weight'], b=P[pre + 'fc1.bias'],
+                         row_perm=st['perm'], dW=self.grad(pre + 'fc1.weight'), db=self.grad(pre + 'fc1.bias'),
+                         label=pre + 'fc1.unf')
+        Wm1T = W[pre + 'fc1.weight.T']            # [mg*mg][cin][pad8(Nv)]
+        for gi in range(mg):
+            Bk.gemm(dhm[:, gi * gc_:], Wm1T[gi * mg * cin:], dtk, rows, cin, Nv, dt, lda=Hd, batch=mg, strideA=Nv,
+                    strideB=cin * pad8(Nv), ldb=pad8(Nv), ldc=C, strideC=cin, R=dtk if gi > 0 else None, ldr=C,
+                    strideR=cin, label=pre + f'fc1.dg{gi}')
+
+    def _head_supported(self):
+        cfg, cout = self.cfg, self.cout
+        g, E, nh, mg, groups = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['gram_groups']
+        return E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0
+
     def _head_fwd(self, k, x4, M4, cout, Hc):
-        F, dt, B, P, T, cfg = self.fwd, self.dt, self.B, self.P, self.training, self.cfg
-        g, E, nh, mg, NC = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['num_classes']
-        groups = cfg['gram_groups']
-        HW = Hc * Hc
-        hd = E // nh
-        if not (E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0):
+        cfg = self.cfg
+        if not self._head_supported():
             # ga_convnext_{tiny,small}_688 / base_976: 688 / 8 = 86 and 688 / 4 = 172 channels per group are not multiples
             # of 8, so the grouped operands of gram_embedding / GroupConvMlp are not 16-byte aligned per group -- and the
             # stage-4 Bottleneck is 688 / 4 = 172 channels wide (rows of 344 bytes).  Tried in round 1: padded group
             # layouts around the head GEMMs work, the 172-wide Bottleneck activations need padded leading dimensions in
             # the BatchNorm / 3x3-gather / squeeze-excite kernels as well (not built)
             raise NotImplementedError(
-                f'GA head with dims[4]={cout}, gram groups={groups}, mlp groups={mg}, dim_embed={E}: the HIP engine needs '
-                f'dims[4] divisible by {8 * groups} and {8 * mg} (per-group channel counts that are multiples of 8); '
-                f'the *_768 / *_1024 variants qualify, *_688 / *_976 need padded group layouts (not built)')
+                f"GA head with dims[4]={cout}, gram groups={cfg['gram_groups']}, mlp groups={cfg['mlp_groups']}, "
+                f"dim_embed={cfg['dim_embed']}: the HIP engine needs dims[4] divisible by {8 * cfg['gram_groups']} and "
+                f"{8 * cfg['mlp_groups']} (per-group channel counts that are multiples of 8); the *_768 / *_1024 variants "
+                f"qualify, *_688 / *_976 need padded group layouts (not built)")
         h = dict(k=k)
+        self._head_contract_fwd(h, k, M4)
+        h['g1'] = self._gram_layer_fwd(h, k, Hc)
+        self._head_tail_fwd(h, k, x4, M4, cout, Hc)
+        return h
+
+    def _head_contract_fwd(self, h, k, M4):
+        """gram_contraction[k]'s BatchNorm on this head's column slice of the stacked conv output -> h['g0'] [M4, gram_dim]"""
+        F, dt, g = self.fwd, self.dt, self.cfg['gram_dim']
         # --- gram_contraction: the conv output / batch sums are column slices of the stacked GEMM; BN per head
         pre = f'gram_contraction.{k}.'
         gcn = self.gcon
@@ -687,10 +773,23 @@ class GAEngine:
         self._bn_finalize(pre + '1.', bn, M4, g)
         h['g0'] = self.buf(pre + 'g0', (M4, g))
         F.affine_act(h['gc'], bn['scale'], bn['shift'], None, h['g0'], M4, g, False, dt, ldx=gcn['ld'], label=pre + 'bn')
-        # --- gram_layer: one ConvNeXt block at 14x14
+
+    def _gram_layer_fwd(self, h, k, Hc):
+        """gram_layer[k]: one ConvNeXt block at 14x14 (ga_convnext.py:411-415)"""
         h['blk'] = f'gram_layer.{k}.blocks.0.'
-        g1 = self._block_fwd(h['blk'], h['g0'], Hc, g)
-        h['g1'] = g1
+        return self._block_fwd(h['blk'], h['g0'], Hc, self.cfg['gram_dim'])
+
+    def _gram_layer_bwd(self, h, dg1, dg0):
+        self._block_bwd(h['blk'], dg1, dg0)
+
+    def _head_tail_fwd(self, h, k, x4, M4, cout, Hc):
+        """get_gram -> gram_embedding (+BN) -> LayerScaleBlockClassAttn -> this head's classifier input"""
+        F, dt, B, P, T, cfg = self.fwd, self.dt, self.B, self.P, self.training, self.cfg
+        g, E, nh, mg, NC = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['num_classes']
+        groups = cfg['gram_groups']
+        HW = Hc * Hc
+        hd = E // nh
+        g1 = h['g1']
         # --- Gram vector (fp32 accumulate; the reference's fp64 branch for train & B<128 is covered by the 1e-3 gate)
         alpha = 1.0 / (Hc * Hc * HW)
         h['alpha'] = alpha
@@ -775,45 +874,19 @@ class GAEngine:
         h['r2'] = self.act(pre + 'r2', (B,), torch.float32)
         F.layernorm_fwd(h['cls1'], P[pre + 'norm2.weight'], P[pre + 'norm2.bias'], h['t'], h['m2'], h['r2'], B, cout, 1e-5,
                         dt, label=pre + 'ln2')
-        # GroupConvMlp: grouped fc1 -> GELU -> channel_shuffle -> grouped fc2; the shuffle is folded into the ROW
-        # ORDER of fc1's effective weights: hidden index n = gi*gc + ci  <-  fc1 output channel ci*mg + gi
-        Hd = 4 * cout
-        gc_ = Hd // mg
-        Nv = gc_ // mg          # rows per virtual group (fc1 input group is constant inside one)
-        cin = cout // mg
-        assert gc_ % mg == 0 and Nv % 8 == 0 and cin % 8 == 0
-        n_idx = torch.arange(Hd)
-        perm = ((n_idx % gc_) * mg + n_idx // gc_).to(torch.int32).to(self.dev)
-        h['perm'] = perm
-        Wm1 = self._w_plain(pre + 'mlp.fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
-        bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
-        self.prep.bias_fold(None, P[pre + 'mlp.fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
-        h['am'] = self.act(pre + 'am', (B, Hd))                      # gelu(hidden), shuffled order
-        h['gm'] = self.act(pre + 'gm', (B, Hd)) if T else None       # gelu'(hidden)
-        F.gemm(h['t'], Wm1, h['am'], B, Nv, cin, dt, lda=cout, batch=mg * mg, strideA=cin, a_batch_mod=mg,
-               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ACT_GELU,
-               C2=h['gm'], c2_mode=2 if T else 0, label=pre + 'mlp.fc1')
-        Wm2 = self._w_plain(pre + 'mlp.fc2.weight', cin, gc_, 1, 1, groups=mg, rs=P[pre + 'gamma_2'])
-        bm2 = self.buf('w.' + pre + 'bm2', (cout,), torch.float32)
-        self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma_2'], None, bm2, cout, gc_)
         h['cls2'] = self.fc_all['x'][k]                          # slice of [K][B][cout]: the five classifiers run as one GEMM
-        F.gemm(h['am'], Wm2, h['cls2'], B, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
-               ldb=pad8(gc_), ldc=cout, strideC=cin, bias=bm2, strideBias=cin, rowscale=dp,
-               rows_per_scale=1, R=h['cls1'], ldr=cout, strideR=cin, label=pre + 'mlp.fc2')
-        h.update(Hd=Hd, mlp_gc=gc_, Nv=Nv, cin=cin)
-        return h
+        h['mlp'] = self._gmlp_fwd(pre + 'mlp.', h['t'], B, cout, mg, h['cls2'], h['cls1'], dp, 1, gamma_name=pre + 'gamma_2')
 
     def _head_bwd(self, h, dlog, dx4, first):
         Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
         k = h['k']
         g, E, nh, mg, NC = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['num_classes']
         groups = cfg['gram_groups']
-        cout = cfg['dims'][4]
+        cout = self.cout
         M4 = dx4.shape[0]
         HW = M4 // B
         N = HW
         hd = E // nh
-        Hd, gc_, Nv, cin = h['Hd'], h['mlp_gc'], h['Nv'], h['cin']
         pre = f'ga.{k}.'
         dp = self.dp_scale.get(pre)
         # classifier: done for all heads at once in _build_backward
@@ -822,31 +895,8 @@ class GAEngine:
         if dp is not None:
             dmz = self.tmp('dmz', (B, cout))
             Bk.rowscale(dcls2, dp, dmz, B * cout, cout, dt)
-        # mlp.fc2 (mg groups)
-        Gm2, gbm2 = self.gbuf((cout, gc_)), self.gbuf((cout,))
-        Bk.wgrad(dmz, h['am'], Gm2, B, cin, gc_, dt, ldy=cout, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
-                 strideW=cin * gc_, dbias=gbm2, strideDbias=cin, label=pre + 'mlp.fc2.wg')
-        Bk.weight_unfold(Gm2, gc_, cout, gc_, gb=gbm2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
-                         rs=P[pre + 'gamma_2'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
-                         d_rs=self.grad(pre + 'gamma_2'), label=pre + 'mlp.fc2.unf')
-        dhm = self.tmp('dhm', (B, Hd))
-        gbm1 = self.gbuf((Hd,))
-        Bk.gemm(dmz, W[pre + 'mlp.fc2.weight.T'], dhm, B, gc_, cin, dt, lda=cout, batch=mg, strideA=cin,
-                strideB=gc_ * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=gc_, H=h['gm'], ldh=Hd, strideH=gc_, h_is_deriv=True,
-                colsum=gbm1, strideCol=gc_, label=pre + 'mlp.fc2.dg')
-        # mlp.fc1 (mg*mg virtual groups)
-        Gm1 = self.gbuf((Hd, cin))
-        Bk.wgrad(dhm, h['t'], Gm1, B, Nv, cin, dt, ldy=Hd, ldx=cout, ldw=cin, batch=mg * mg, strideY=Nv, strideX=cin,
-                 x_batch_mod=mg, strideW=Nv * cin, label=pre + 'mlp.fc1.wg')
-        Bk.weight_unfold(Gm1, cin, Hd, cin, gb=gbm1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'],
-                         row_perm=h['perm'], dW=self.grad(pre + 'mlp.fc1.weight'), db=self.grad(pre + 'mlp.fc1.bias'),
-                         label=pre + 'mlp.fc1.unf')
         dtk = self.tmp('dt', (B, cout))
-        Wm1T = W[pre + 'mlp.fc1.weight.T']            # [mg*mg][cin][pad8(Nv)]
-        for gi in range(mg):
-            Bk.gemm(dhm[:, gi * gc_:], Wm1T[gi * mg * cin:], dtk, B, cin, Nv, dt, lda=Hd, batch=mg, strideA=Nv,
-                    strideB=cin * pad8(Nv), ldb=pad8(Nv), ldc=cout, strideC=cin, R=dtk if gi > 0 else None, ldr=cout,
-                    strideR=cin, label=pre + f'mlp.fc1.dg{gi}')
+        self._gmlp_bwd(pre + 'mlp.', h['mlp'], dmz, h['t'], B, cout, mg, dtk, gamma_name=pre + 'gamma_2')
         dcls1 = self.tmp('dcls1', (B, cout))
         Bk.layernorm_bwd(dtk, h['cls1'], h['m2'], h['r2'], P[pre + 'norm2.weight'], dcls2, dcls1,
                          self.grad(pre + 'norm2.weight'), self.grad(pre + 'norm2.bias'), B, cout, False, dt, label=pre + 'ln2b')
@@ -919,8 +969,12 @@ class GAEngine:
         Bk.gemm(h['g1'], S, dg1, HW, g, g, dt, batch=B, strideA=HW * g, strideB=g * g, strideC=HW * g, alpha=h['alpha'],
                 label=f'gram.{k}.dx')
         dg0 = self.tmp('dg0', (M4, g))
-        self._block_bwd(h['blk'], dg1, dg0)
+        self._gram_layer_bwd(h, dg1, dg0)
+        self._head_contract_bwd(h, k, dg0, M4)
+
+    def _head_contract_bwd(self, h, k, dg0, M4):
         # gram_contraction BN backward into this head's column slice; the conv's wgrad / dgrad run once for all heads
+        g = self.cfg['gram_dim']
         pre = f'gram_contraction.{k}.'
         gcn = self.gcon
         self._bn_bwd(pre + '1.', h['bn_gc'], dg0, None, h['gc'], gcn['dout'][:, k * g:], M4, g, ldx=gcn['ld'], lddx=gcn['ld'])
@@ -928,61 +982,74 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     # whole-network backward plan
     # ------------------------------------------------------------------------------------------
-    def _build_backward(self, feats, taps, stage_in, x4, M4, ctot):
+    def _build_heads_backward(self, x4, M4):
+        """backward of _build_heads: classifiers, the heads, the shared parts; returns dx4 [M4, cout]"""
         Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
-        d, dep = cfg['dims'], cfg['depths']
+        cout = self.cout
         K, NC = cfg['branches'], cfg['num_classes']
         self.dlogits = self.buf('dlogits', (K, B, NC))
         Bk.zero(self.arena, label='zero.arena')
-        dx4 = self.tmp('dx4', (M4, d[4]))
+        dx4 = self.tmp('dx4', (M4, cout))
         # classifiers of the five heads: one batched wgrad and one batched dgrad
         fa = self.fc_all
-        Gfc, gbfc = self.gbuf((K, NC, d[4])), self.gbuf((K, NC))
-        Bk.wgrad(self.dlogits, fa['x'], Gfc, B, NC, d[4], dt, batch=K, strideY=B * NC, strideX=B * d[4], strideW=NC * d[4],
+        Gfc, gbfc = self.gbuf((K, NC, cout)), self.gbuf((K, NC))
+        Bk.wgrad(self.dlogits, fa['x'], Gfc, B, NC, cout, dt, batch=K, strideY=B * NC, strideX=B * cout, strideW=NC * cout,
                  dbias=gbfc, strideDbias=NC, label='fc.all.wg')
         for k in range(K):
-            Bk.axpy_f32(self.grad(f'fc.{k}.weight'), Gfc[k], 1.0, NC * d[4])
+            Bk.axpy_f32(self.grad(f'fc.{k}.weight'), Gfc[k], 1.0, NC * cout)
             Bk.axpy_f32(self.grad(f'fc.{k}.bias'), gbfc[k], 1.0, NC)
-        fa['dx'] = self.tmp('dcls2_all', (K, B, d[4]))
-        Bk.gemm(self.dlogits, fa['WT'], fa['dx'], B, d[4], NC, dt, batch=K, strideA=B * NC, strideB=d[4] * pad8(NC),
-                ldb=pad8(NC), strideC=B * d[4], label='fc.all.dg')
+        fa['dx'] = self.tmp('dcls2_all', (K, B, cout))
+        Bk.gemm(self.dlogits, fa['WT'], fa['dx'], B, cout, NC, dt, batch=K, strideA=B * NC, strideB=cout * pad8(NC),
+                ldb=pad8(NC), strideC=B * cout, label='fc.all.dg')
         if self.shared_tok:     # written slice-wise by the heads, consumed after the loop
             tk = self.tok
             tk['dkv'] = self.tmp('dkv_all', (M4, tk['ld']))
-            tk['G'], tk['gb'] = self.gbuf((tk['ld'], d[4])), self.gbuf((tk['ld'],))
+            tk['G'], tk['gb'] = self.gbuf((tk['ld'], cout)), self.gbuf((tk['ld'],))
         self.gcon['dout'] = self.tmp('dgc_all', (M4, self.gcon['ld']))
         for k in range(K):
             if self.head_lanes > 1:
                 Bk.lane, self.tmp_prefix = 1 + k % self.head_lanes, f'h{k}.'
             self._head_bwd(self.heads[k], self.dlogits[k], dx4, first=(k == 0))
         Bk.lane, self.tmp_prefix = 0, ''
-        # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
-        gcn, g_ = self.gcon, cfg['gram_dim']
-        Gc, gbc = self.gbuf((gcn['ld'], d[4])), self.gbuf((gcn['ld'],))
-        with self._wlane():
-            Bk.wgrad(gcn['dout'], x4, Gc, M4, gcn['ld'], d[4], dt, dbias=gbc, label='gram_contraction.all.wg')
-        for k in range(K):
-            pre = f'gram_contraction.{k}.'
-            Bk.axpy_f32(self.grad(pre + '0.weight'), Gc[k * g_:], 1.0, g_ * d[4])
-            Bk.axpy_f32(self.grad(pre + '0.bias'), gbc[k * g_:], 1.0, g_)
-        # the first writer of dx4 on the shared-token path (the per-head token_split of the other path has written it)
-        Bk.gemm(gcn['dout'], gcn['WT'], dx4, M4, d[4], gcn['ld'], dt, R=None if self.shared_tok else dx4, ldr=d[4],
-                label='gram_contraction.all.dg')
+        self._contract_all_bwd(x4, dx4, M4)
         if self.shared_tok:
             tk = self.tok
             E2 = tk['E2']
             # token rows of all heads at once: effective k|v weight gradients, then each head's norm1 fold undone ...
             with self._wlane():
-                Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], d[4], dt, dbias=tk['gb'], label='ga.kv_all.wg')
+                Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], cout, dt, dbias=tk['gb'], label='ga.kv_all.wg')
             for k in range(K):
                 pre = f'ga.{k}.'
-                Bk.weight_unfold(tk['G'][k * E2:], d[4], E2, d[4], gb=tk['gb'][k * E2:], W=P[pre + 'attn.k.weight'],
+                Bk.weight_unfold(tk['G'][k * E2:], cout, E2, cout, gb=tk['gb'][k * E2:], W=P[pre + 'attn.k.weight'],
                                  cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self.grad(pre + 'attn.k.weight'),
                                  d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'kv.unf')
             # ... and dx4 += LayerNorm'(gradient wrt the shared normalised tokens, summed over the heads by the K = 5*2E GEMM)
-            dxt = self.tmp('dxn_tok', (M4, d[4]))
-            Bk.gemm(tk['dkv'], tk['WT'], dxt, M4, d[4], tk['ld'], dt, label='ga.kv_all.dg')
-            Bk.layernorm_bwd(dxt, tk['xn'], None, tk['rstd'], None, dx4, dx4, None, None, M4, d[4], True, dt, label='ga.tok.lnb')
+            dxt = self.tmp('dxn_tok', (M4, cout))
+            Bk.gemm(tk['dkv'], tk['WT'], dxt, M4, cout, tk['ld'], dt, label='ga.kv_all.dg')
+            Bk.layernorm_bwd(dxt, tk['xn'], None, tk['rstd'], None, dx4, dx4, None, None, M4, cout, True, dt, label='ga.tok.lnb')
+        return dx4
+
+    def _contract_all_bwd(self, x4, dx4, M4):
+        """weight / data gradients of the five gram_contraction convs; FIRST writer of dx4 on the shared-token path"""
+        Bk, dt, cfg, cout = self.bwd, self.dt, self.cfg, self.cout
+        K = cfg['branches']
+        # gram_contraction convs of all heads: one wgrad (rows k*g.. -> head k's weight / bias gradient), one dgrad
+        gcn, g_ = self.gcon, cfg['gram_dim']
+        Gc, gbc = self.gbuf((gcn['ld'], cout)), self.gbuf((gcn['ld'],))
+        with self._wlane():
+            Bk.wgrad(gcn['dout'], x4, Gc, M4, gcn['ld'], cout, dt, dbias=gbc, label='gram_contraction.all.wg')
+        for k in range(K):
+            pre = f'gram_contraction.{k}.'
+            Bk.axpy_f32(self.grad(pre + '0.weight'), Gc[k * g_:], 1.0, g_ * cout)
+            Bk.axpy_f32(self.grad(pre + '0.bias'), gbc[k * g_:], 1.0, g_)
+        # the first writer of dx4 on the shared-token path (the per-head token_split of the other path has written it)
+        Bk.gemm(gcn['dout'], gcn['WT'], dx4, M4, cout, gcn['ld'], dt, R=None if self.shared_tok else dx4, ldr=cout,
+                label='gram_contraction.all.dg')
+
+    def _build_backward(self, feats, taps, stage_in, x4, M4, ctot):
+        Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
+        d, dep = cfg['dims'], cfg['depths']
+        dx4 = self._build_heads_backward(x4, M4)
         dcat = self.tmp('dcat', (M4, ctot))
         self._bottleneck_bwd(dx4, dcat)
         if self.async_wgrad:

@@ -6,6 +6,7 @@ buffers under the reference's names; they have no forward of their own.
 import torch
 import torch.nn as nn
 
+from .flat_model import FlatModel, Holder as _Holder
 from .registry import register_model
 
 __all__ = ['GA_ConvNeXt']
@@ -14,11 +15,6 @@ __all__ = ['GA_ConvNeXt']
 def se_rd_channels(c, rd_ratio=0.25, divisor=8):
     # timm make_divisible(c * rd_ratio, 8, round_limit=0.) as used by create_attn('se', width, rd_ratio=1/4)
     return max(divisor, int(c * rd_ratio + divisor / 2) // divisor * divisor)
-
-
-class _Holder(nn.Module):
-    def forward(self, *a, **k):  # pragma: no cover
-        raise RuntimeError('parameter container only: the model runs through engine.GAEngine (libgaext kernels)')
 
 
 class BlockParams(_Holder):
@@ -97,7 +93,7 @@ def _init_weights(module):
             nn.init.constant_(module.bias, 0)
 
 
-class GA_ConvNeXt(nn.Module):
+class GA_ConvNeXt(FlatModel):
     def __init__(self, in_chans=3, num_classes=1000, output_stride=32, patch_size=4,
                  depths=(3, 3, 9, 3, 1), dims=(96, 192, 384, 768, 768), ls_init_value=1e-6, conv_mlp=False,
                  head_init_scale=1., norm_layer=None, drop_rate=0., drop_path_rate=0.,
@@ -140,107 +136,10 @@ class GA_ConvNeXt(nn.Module):
             self.fc.append(nn.Linear(d[4], num_classes))
         self.apply(_init_weights)
         self.math_mode = math_mode  # None -> bf16 (throughput); 'fp32' -> parity math mode
-        self._engines = {}
-        self._flat = None
 
-    # ------------------------------------------------------------------------------------------
-    # flat parameter / gradient storage (one fp32 buffer each: [decay | no-decay], timm's rule)
-    # ------------------------------------------------------------------------------------------
-    @staticmethod
-    def no_weight_decay_param(name, p):
-        return p.ndim <= 1 or name.endswith('.bias')
-
-    def _flatten(self):
-        params = list(self.named_parameters())
-        dev = params[0][1].device
-        decay = [(n, p) for n, p in params if not self.no_weight_decay_param(n, p)]
-        nodecay = [(n, p) for n, p in params if self.no_weight_decay_param(n, p)]
-        order = decay + nodecay
-        total = sum(p.numel() for _, p in order)
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        grads = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
-        slices = {}
-        with torch.no_grad():
-            for n, p in order:
-                k = p.numel()
-                flat[off:off + k].copy_(p.detach().reshape(-1).float())
-                p.data = flat[off:off + k].view(p.shape)
-                p.grad = grads[off:off + k].view(p.shape)
-                slices[n] = (off, k)
-                off += k
-        self._flat = dict(params=flat, grads=grads, n_decay=sum(p.numel() for _, p in decay), total=total,
-                          slices=slices)
-        self._engines = {}
-
-    def _apply(self, fn, recurse=True):
-        out = super()._apply(fn, recurse)
-        first = next(self.parameters())
-        if first.is_cuda:
-            self._flatten()
-        else:
-            self._flat = None
-            self._engines = {}
-        return out
-
-    def flat_state(self):
-        if self._flat is None:
-            raise RuntimeError('GA_ConvNeXt must be moved to the GPU (model.cuda()) before use: the product path has '
-                               'no CPU implementation')
-        return self._flat
-
-    def zero_grad(self, set_to_none=False):
-        """Gradients live in one flat fp32 buffer that the wgrad kernels accumulate into: zero it in place."""
-        if self._flat is not None:
-            self._flat['grads'].zero_()
-        else:
-            super().zero_grad(set_to_none=set_to_none)
-
-    def load_state_dict(self, state_dict, strict=True, assign=False):
-        if self._flat is not None:
-            # keep the flat views: copy values instead of re-assigning tensors
-            own = self.state_dict()
-            missing = [k for k in own if k not in state_dict]
-            unexpected = [k for k in state_dict if k not in own]
-            if strict and (missing or unexpected):
-                raise RuntimeError(f'load_state_dict: missing {missing[:5]} unexpected {unexpected[:5]}')
-            with torch.no_grad():
-                for k, v in state_dict.items():
-                    if k in own:
-                        own[k].copy_(v.to(own[k].device))
-            for e in self._engines.values():
-                e.weights_dirty = True
-            return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
-        return super().load_state_dict(state_dict, strict=strict, assign=assign)
-
-    # ------------------------------------------------------------------------------------------
-    def engine(self, batch, training):
+    def make_engine(self, batch, training, mode):
         from .engine import GAEngine
-        mode = self.math_mode or 'bf16'
-        key = (batch, bool(training), mode)
-        if key not in self._engines:
-            self._engines[key] = GAEngine(self, batch, bool(training), mode)
-        return self._engines[key]
-
-    def forward(self, x):
-        """(B,3,224,224) float -> list of `branches` per-head logits (B,num_classes), fp32 (ga_convnext.py:487-505)."""
-        if not x.is_cuda:
-            raise RuntimeError('GA_ConvNeXt.forward needs a CUDA/HIP tensor: there is no CPU fallback')
-        from .engine import GAFunction
-        eng = self.engine(x.shape[0], self.training)
-        if self.training and torch.is_grad_enabled():
-            logits = GAFunction.apply(eng, x, eng.anchor)
-        else:
-            logits = eng.forward(x)
-        outs = list(logits.unbind(0))
-        for o in outs:
-            o._ga_stack = logits   # lets ga_loss / heads_topk use the stacked (K,B,NC) tensor without a copy
-        return outs
-
-    def set_math_mode(self, mode):
-        assert mode in (None, 'bf16', 'fp32')
-        self.math_mode = mode
-        return self
+        return GAEngine(self, batch, training, mode)
 
 
 def _create(variant, pretrained=False, **kwargs):

@@ -488,6 +488,14 @@ class Plan:
         self._add('ga_cswin_lepe_wgrad', (C.byref(d), _ptr(dout), _ptr(g[0][0]), _ptr(g[0][1]), _ptr(g[1][0]), _ptr(g[1][1])),
                   label, keep=(d, dout) + tuple(t for pair in grads for t in pair))
 
+    def layernorm_gelu_fwd(self, x, w, b, y, mean, rstd, rows, Cdim, eps, dtype, label=None):
+        self._add('ga_layernorm_gelu_fwd', (_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, Cdim, eps, dtype),
+                  label, keep=(x, w, b, y, mean, rstd))
+
+    def layernorm_gelu_bwd(self, g, x, mean, rstd, w, b, dx, dw, db, rows, Cdim, dtype, label=None):
+        self._add('ga_layernorm_gelu_bwd', (_ptr(g), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(dx), _ptr(dw),
+                                            _ptr(db), rows, Cdim, dtype), label, keep=(g, x, mean, rstd, w, b, dx, dw, db))
+
     def nchw3_to_nhwc8(self, x, y, B, H, W, dtype, label=None):
         self._add('ga_nchw3_to_nhwc8', (_ptr(x), _ptr(y), B, H, W, dtype), label, keep=(x, y))
 

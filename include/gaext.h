@@ -366,6 +366,12 @@ int ga_cswin_lepe_wgrad(const ga_cswin_attn_desc* d, const void* dout, float* dw
  *   ga_convw_pack:     fp32 [Co][Ci][taps] -> out[co][tap*Cp + ci] in `dtype` (zero for ci >= Ci and up to ldo);
  *   ga_convw_unpack_grad: dW[co][ci][tap] += G[co][tap*Cp + ci];
  *   ga_conv3s2_dgrad_prep: fp32 [Co][Ci][3][3] -> out[(py,px,ci)][(ay,ax,co)] (4*Ci rows, ldo >= 4*Co), see GA_A_NEIGH2 */
+/* LayerNorm(affine) -> GELU(erf) between the stem convs (ga_cswin.py:466-468,471-473): y = gelu(LN(x)*w + b);
+ * bwd: dx = LN'(g * gelu'(LN(x)*w + b)), dw / db accumulated (fp32 atomics).  C a power of two in [8, 512]. */
+int ga_layernorm_gelu_fwd(const void* x, const float* w, const float* b, void* y, float* mean, float* rstd, int64_t rows,
+                          int C, float eps, int dtype, ga_stream_t stream);
+int ga_layernorm_gelu_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w, const float* b,
+                          void* dx, float* dw, float* db, int64_t rows, int C, int dtype, ga_stream_t stream);
 int ga_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, ga_stream_t stream);
 int ga_convw_pack(const float* w, void* out, int Co, int Ci, int taps, int Cp, int64_t ldo, int dtype, ga_stream_t stream);
 int ga_convw_unpack_grad(const float* G, float* dW, int Co, int Ci, int taps, int Cp, int64_t ldg, ga_stream_t stream);

@@ -288,7 +288,10 @@ def group_conv_mlp(sd, pre, x, groups):
 
 
 def cswin_block(sd, pre, x, reso, split, heads, last_stage=False, mlp_groups=1, dp_mask=None):
-    """CSWinBlock.forward (ga_cswin.py:191-212); LayerNorm eps = nn.LayerNorm default 1e-5"""
+    """CSWinBlock.forward (ga_cswin.py:191-212); LayerNorm eps = nn.LayerNorm default 1e-5.
+    dp_mask: None, one per-sample mask for both DropPath calls, or a pair (attention branch, MLP branch) -- the module
+    draws a fresh mask at each of its two drop_path calls (:209-210)."""
+    dp1, dp2 = dp_mask if isinstance(dp_mask, (tuple, list)) else (dp_mask, dp_mask)
     b, l, c = x.shape
     nbr = branch_num(reso, split, last_stage)
     img = F.layer_norm(x, (c,), sd[pre + 'norm1.weight'], sd[pre + 'norm1.bias'], 1e-5)
@@ -304,14 +307,14 @@ def cswin_block(sd, pre, x, reso, split, heads, last_stage=False, mlp_groups=1, 
         att = lepe_attention(qkv[0], qkv[1], qkv[2], sd[pre + 'attns.0.get_v.weight'], sd[pre + 'attns.0.get_v.bias'],
                              reso, -1, split, heads)
     att = F.linear(att, sd[pre + 'proj.weight'], sd[pre + 'proj.bias'])
-    x = x + _dp(att, dp_mask)
+    x = x + _dp(att, dp1)
     t = F.layer_norm(x, (c,), sd[pre + 'norm2.weight'], sd[pre + 'norm2.bias'], 1e-5)
     if mlp_groups == 1:
         t = F.linear(F.gelu(F.linear(t, sd[pre + 'mlp.fc1.weight'], sd[pre + 'mlp.fc1.bias'])),
                      sd[pre + 'mlp.fc2.weight'], sd[pre + 'mlp.fc2.bias'])
     else:
         t = group_conv_mlp(sd, pre + 'mlp.', t, mlp_groups)
-    return x + _dp(t, dp_mask)
+    return x + _dp(t, dp2)
 
 
 def _tok(x):

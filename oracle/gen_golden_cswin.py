@@ -29,9 +29,10 @@ from oracle.gen_golden import grad_stats, ref_loss, rel  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(HERE), 'tests', 'golden')
 
-# narrow whole-model config: head dims 8 / 8 / 8 / 16 (trunk), 16 (stage5), 8 (gram layer), 8 (class attention)
+# narrow whole-model config: head dims 8 / 8 / 8 / 16 (trunk), 16 (stage5), 32 (gram layer: 8 groups x 24 channels must stay
+# 8-aligned for the grouped contraction GEMM), 8 (class attention)
 V6 = dict(embed_dim=16, depth=(1, 1, 6, 1), split_size=(1, 2, 7, 7, 7), num_heads=(2, 4, 8, 16, 16),
-          dims=(16, 32, 64, 256), naggre=2, gram_dim=48, num_classes=40, stage5_mlp_groups=4)
+          dims=(16, 32, 64, 256), naggre=2, gram_dim=192, num_classes=40, stage5_mlp_groups=4)
 # same with the Bottleneck stage5 (ga_cswin.py:540-542)
 V6B = dict(V6, stage5='bottleneck')
 

@@ -205,3 +205,31 @@ def test_stem_first_conv_from_nchw(dt):
     wr = w.to(dt).float().clone().requires_grad_(True)
     F.conv2d(xr, wr, None, stride=2, padding=1).backward(gy_c.reshape(B, OH, OW, Co).permute(0, 3, 1, 2))
     assert_close(dW, wr.grad, tol(dt, 2), 'stem conv0 wgrad')
+
+
+@pytest.mark.parametrize('dt', DT)
+@pytest.mark.parametrize('C', [16, 64])
+def test_layernorm_gelu(dt, C):
+    """LayerNorm(1e-5, affine) -> GELU between the deep-stem convs (ga_cswin.py:466-468)"""
+    ops = _imp()
+    rows = 3 * 37
+    g = gen(8)
+    x_c, x_g = rnd((rows, C), dt, g, 1.5)
+    gy_c, gy_g = rnd((rows, C), dt, g)
+    w = torch.rand(C, generator=g) * 0.4 + 0.8
+    b = torch.randn(C, generator=g) * 0.1
+    xr, wr, br = x_c.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.gelu(F.layer_norm(xr, (C,), wr, br, 1e-5))
+    y.backward(gy_c)
+    ga = ops.ga_dtype(dt)
+    p = ops.Plan(eager=True)
+    out = torch.empty(rows, C, dtype=dt, device='cuda')
+    mean, rstd = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    p.layernorm_gelu_fwd(x_g, w.cuda(), b.cuda(), out, mean, rstd, rows, C, 1e-5, ga)
+    assert_close(out, y, tol(dt), 'ln+gelu fwd')
+    dx = torch.empty(rows, C, dtype=dt, device='cuda')
+    dw, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    p.layernorm_gelu_bwd(gy_g, x_g, mean, rstd, w.cuda(), b.cuda(), dx, dw, db, rows, C, ga)
+    assert_close(dx, xr.grad, tol(dt, 1.5), 'ln+gelu dx')
+    assert_close(dw, wr.grad, tol(dt, 2), 'ln+gelu dw')
+    assert_close(db, br.grad, tol(dt, 2), 'ln+gelu db')
