@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec of the GA-ConvNeXt-T (ga_convnext_tiny_768) bf16 TRAINING step on synthetic
-3x224x224 at batch 256 per MI355X (BASELINE.json configs[1]); one process per GPU, weak scaling.
+"""Headline benchmark: images/sec of the bf16 TRAINING step on synthetic 3x224x224 at batch 256 per MI355X, one process
+per GPU, weak scaling.  Default workload = BASELINE.json configs[1]: GA-ConvNeXt-T (`ga_convnext_tiny_768`);
+`--model ga_CSWin_64_12211_tiny_224` = configs[2], `--model ga_convnext_base_1024` = configs[3]'s model.
 
-A step = forward + GA loss (CE + lambda*KL, lambda=-0.8) + backward + gradient all-reduce (N>1) + fused AdamW, all
-on the libgaext HIP kernels.  Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel family of the step (by summed device time), timed per launch with HIP
-                  events on the launch stream in a separate instrumented step; achieved = its algorithmic FLOPs
-                  (2*M*N*K per GEMM launch) / its device time; `step_frac` = whole-step img/s * 34.52 GFLOP / peak.
-  cpu_baseline -- the oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores
-                  on a bounded sample (batch 8 train steps), N=1 only.
+A step = forward + GA loss (CE + lambda*KL, lambda=-0.8) + backward + bucketed gradient all-reduce (N>1, RCCL) + fused
+AdamW, all on the libgaext HIP kernels.  Prints ONE JSON line (rank 0).
+
+`python bench.py --gpus N` without a torch.distributed launcher starts the N one-GPU worker processes itself (fresh
+children, before this process touches a GPU) and prints rank 0's line; under `python -m torch.distributed.run` it is one
+of the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+Extra objects:
+  roofline     -- the dominant kernel family of the step (by summed device time), timed per launch with HIP events on the
+                  launch stream in a separate instrumented step; achieved = its algorithmic FLOPs (2*M*N*K per GEMM launch)
+                  / its device time; `step_frac` = whole-step img/s * GFLOP/img / peak.  `measured_peaks` = this box's own
+                  numbers (libgaext bf16 GEMM 8192^3, a streaming copy) beside the vendor figures used for `peak`.
+  cpu_baseline -- the oracle (CPU restatement of the reference path, kind "port") timed on this box's host cores on a
+                  bounded sample (batch 8 train steps), N=1 only.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MODEL = 'ga_convnext_tiny_768'
-GFLOP_PER_IMG = 34.52          # fwd+bwd, SURVEY.md section 8(d) / BASELINE.md section 2
+# fwd+bwd GFLOP per image (2 FLOP/MAC over conv + linear + bmm, backward = 2x forward): SURVEY.md section 8(d) / BASELINE.md 2
+GFLOP_PER_IMG = {'ga_convnext_tiny_768': 34.52, 'ga_convnext_tiny': 34.52, 'ga_convnext_tiny_688': 32.73,
+                 'ga_convnext_small_768': 60.76, 'ga_convnext_small': 60.76, 'ga_convnext_small_688': 58.87,
+                 'ga_convnext_base_1024': 105.54, 'ga_convnext_base': 105.54, 'ga_convnext_base_976': 104.00,
+                 'ga_CSWin_64_12211_tiny_224': 36.5}
+LABEL = {'ga_convnext_tiny_768': 'GA-ConvNeXt-T', 'ga_convnext_small_768': 'GA-ConvNeXt-S', 'ga_convnext_base_1024': 'GA-ConvNeXt-B',
+         'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)'}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -31,14 +46,16 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (the headline config is 256)')
     ap.add_argument('--model', default=MODEL)
     ap.add_argument('--opt', default='adamw')
     ap.add_argument('--math', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-times', action='store_true')
+    ap.add_argument('--no-measured-peaks', action='store_true')
+    ap.add_argument('--no-ddp-bb', action='store_true', help='no per-forward BatchNorm buffer broadcast (GA/train.py:283)')
     ap.add_argument('--kernel-table', default='', help='write the per-kernel-family table (json) here')
     return ap.parse_args()
 
@@ -46,11 +63,12 @@ def parse():
 def kernel_family(label):
     for key, fam in (('.wg', 'gemm_tn(wgrad)'), ('wgrad', 'gemm_tn(wgrad)'), ('gram.', 'gemm/gram'),
                      ('.dww', 'dwconv7_wgrad'), ('.dwd', 'dwconv7'), ('.dw', 'dwconv7'),
-                     ('.lnb', 'layernorm_bwd'), ('ln1b', 'layernorm_bwd'), ('ln2b', 'layernorm_bwd'), ('.ln', 'layernorm_fwd'),
-                     ('prep.', 'weight_prep'), ('unf', 'weight_unfold'), ('bn', 'batchnorm'), ('agg.', 'aggregate'),
-                     ('se.', 'squeeze_excite'), ('attn', 'class_attn'), ('zero', 'memset'), ('.dp', 'rowscale'),
+                     ('attnb', 'stripe_attn_bwd'), ('.attn', 'stripe_attn_fwd' if 'stage' in label or 'gram_layer' in label else 'class_attn'),
+                     ('.lnb', 'layernorm_bwd'), ('ln0b', 'layernorm_bwd'), ('ln1b', 'layernorm_bwd'), ('ln2b', 'layernorm_bwd'),
+                     ('.ln', 'layernorm_fwd'), ('prep.', 'weight_prep'), ('unf', 'weight_unfold'), ('bn', 'batchnorm'),
+                     ('agg.', 'aggregate'), ('se.', 'squeeze_excite'), ('attn', 'class_attn'), ('zero', 'memset'), ('.dp', 'rowscale'),
                      ('ga_rowscale', 'rowscale'), ('loss', 'loss'), ('adamw', 'optimizer'), ('sgd', 'optimizer'),
-                     ('lamb', 'optimizer')):
+                     ('lamb', 'optimizer'), ('pack', 'input_pack')):
         if key in label:
             return fam
     return 'other'
@@ -90,13 +108,50 @@ def time_plan_calls(plan, fams, per_call=None):
         f['launches'] += 1
 
 
-def cpu_baseline(budget_s=10.0):
+def measured_peaks():
+    """this box's own ceilings: libgaext's bf16 GEMM on 8192^3 random operands and a streaming pass of
+    ga_rowscale over 1 GiB (read + write), both timed with HIP events over 10 launches after 3 warm-ups"""
+    from imagenet_models_amd import ops
+    n = 8192
+    g = torch.Generator(device='cuda').manual_seed(1)
+    a = torch.randn(n, n, device='cuda', generator=g).bfloat16()
+    b = torch.randn(n, n, device='cuda', generator=g).bfloat16()
+    c = torch.empty(n, n, device='cuda', dtype=torch.bfloat16)
+    p = ops.Plan(name='peak.gemm')
+    p.gemm(a, b, c, n, n, n, ops.GA_BF16)
+    x = torch.randn(1 << 29, device='cuda', generator=g).bfloat16()
+    y = torch.empty_like(x)
+    s = torch.ones(1, device='cuda')
+    q = ops.Plan(name='peak.copy')
+    q.rowscale(x, s, y, x.numel(), x.numel(), ops.GA_BF16)
+    out = {}
+    for name, plan, work in (('mfma_bf16_tflops_gemm_8192', p, 2.0 * n ** 3 / 1e12), ('hbm_gbs_stream_1gib', q, 2.0 * x.numel() * 2 / 1e9)):
+        for _ in range(3):
+            plan.run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            plan.run()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(work * 10 / (e0.elapsed_time(e1) * 1e-3), 1)
+    return out
+
+
+def cpu_baseline(model_name, budget_s=10.0):
     """oracle (CPU restatement of the reference path) train step, fp32, batch 8, AdamW -- a reported baseline only"""
-    from oracle import ga_convnext_oracle as O
+    if 'CSWin' in model_name:
+        from oracle import ga_cswin_oracle as O
+        from oracle.ga_convnext_oracle import adamw_step
+        mod = 'oracle/ga_cswin_oracle.py'
+    else:
+        from oracle import ga_convnext_oracle as O
+        adamw_step = O.adamw_step
+        mod = 'oracle/ga_convnext_oracle.py'
     # the GPU box gives one GPU's share of the host (16 CPUs); more threads than that only oversubscribes
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(16, ncpu)))
-    cfg = O.make_cfg(MODEL)
+    cfg = O.make_cfg(model_name)
     sd = O.fill_state(cfg)
     B = 8
     g = torch.Generator().manual_seed(42)
@@ -110,7 +165,7 @@ def cpu_baseline(budget_s=10.0):
         t0 = time.time()
         loss, outs, grads, stats = O.train_step_grads(sd, x, y, cfg, lam=-0.8)
         params = {n: sd[n] for n in grads}
-        newp, m, v = O.adamw_step(params, grads, m, v, step + 1, 1e-3, (0.9, 0.999), 1e-8, 0.05)
+        newp, m, v = adamw_step(params, grads, m, v, step + 1, 1e-3, (0.9, 0.999), 1e-8, 0.05)
         sd.update(newp)
         sd.update({k: t for k, t in stats.items()})
         dt = time.time() - t0
@@ -121,15 +176,36 @@ def cpu_baseline(budget_s=10.0):
             break
     best = min(times)
     return dict(value=round(B / best, 2), unit='images/sec', cores=torch.get_num_threads(), kind='port',
-                sample=f'{len(times)} timed train steps (fwd + GA loss + bwd + AdamW) of {MODEL} at batch {B}, fp32, best step '
-                       f'{best:.3f}s, oracle/ga_convnext_oracle.py on the host CPU')
+                sample=f'{len(times)} timed train steps (fwd + GA loss + bwd + AdamW) of {model_name} at batch {B}, fp32, best '
+                       f'step {best:.3f}s, {mod} on the host CPU')
+
+
+def spawn_workers(a):
+    """`bench.py --gpus N` outside a launcher: N fresh one-GPU children (this process makes no GPU call); rank 0's JSON line
+    is passed through.  GA_DIST_BACKEND=gloo + fewer devices than ranks = rehearsal (ranks share a device)."""
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    sys.exit(max(abs(rc) for rc in rcs))
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_workers(a)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    backend = 'none'
     if world > 1:
         # one process per GPU over RCCL; GA_DIST_BACKEND=gloo + fewer GPUs than ranks is a rehearsal mode only
         # (ranks share a device, the all-reduce goes through the host): it exercises the N > 1 code, not its speed
@@ -142,7 +218,6 @@ def main():
             dist.init_process_group(backend, init_method='env://')
     else:
         torch.cuda.set_device(0)
-    assert a.gpus == world, f'--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1'
 
     import imagenet_models_amd as A
     torch.manual_seed(42 + rank)
@@ -150,10 +225,9 @@ def main():
     model.train()
     if world > 1:  # DDP-style start: rank 0's parameters and buffers everywhere (GA/train.py:514)
         dist.broadcast(model.flat_state()['params'], 0)
-        for b in model.buffers():
-            dist.broadcast(b, 0)
+        dist.broadcast(model.flat_state()['buffers'], 0)
     opt = A.create_optimizer_v2(model, opt=a.opt, lr=1e-3, weight_decay=0.05, momentum=0.9)
-    step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce')
+    step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce', broadcast_buffers=not a.no_ddp_bb)
     g = torch.Generator().manual_seed(42 + rank)
     x = torch.randn(a.batch, 3, 224, 224, generator=g).cuda()
     y = torch.randint(0, model.num_classes, (a.batch,), generator=g).cuda()
@@ -178,13 +252,16 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     value = a.batch * world * a.steps / elapsed
     loss_val = float(loss)
+    gflop = GFLOP_PER_IMG.get(a.model)
+    label = LABEL.get(a.model, a.model)
 
-    out = dict(metric='images/sec (whole node) GA-ConvNeXt-T 3x224x224 bf16 training step', value=round(value, 1),
+    out = dict(metric=f'images/sec (whole node) {label} 3x224x224 {a.math} training step', value=round(value, 1),
                unit='images/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.math, data='synthetic',
                config=dict(workload=f'{a.model} train step (fwd + GA loss lam=-0.8 + bwd + all-reduce + {a.opt}), '
                                     f'batch {a.batch}/GPU, drop_path 0.2, synthetic 3x224x224',
-                           global_batch=a.batch * world, parallelism=f'dp{world}'),
+                           global_batch=a.batch * world, parallelism=f'dp{world}', dist_backend=backend,
+                           allreduce_buckets=len(step.buckets), gflop_per_img=gflop),
                loss=round(loss_val, 4))
 
     if rank == 0 and not a.no_kernel_times:
@@ -206,20 +283,29 @@ def main():
         # HBM bytes per launch of the family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE over one step of THIS
         # workload, tools/pmc_step_traffic.py): a PMC run cannot be nested inside the timed bench
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r01_pmc_step_traffic.json')
-        if name == 'gemm_nt' and a.model == MODEL and a.batch == 256 and a.math == 'bf16' and os.path.exists(tj):
-            with open(tj) as fh:
-                g_ = json.load(fh)['gemm_nt']
-            traffic = round((g_['fetch_mb'] + g_['write_mb']) * 1e6 / max(g_['launches'], 1))
-            traffic_src = f"profiles/r01_pmc_step_traffic.json: {g_['launches']} gemm_nt dispatches per step, bytes per dispatch"
+        for tj in ('r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json'):
+            tp = os.path.join(ROOT, 'profiles', tj)
+            if name == 'gemm_nt' and a.model == MODEL and a.batch == 256 and a.math == 'bf16' and os.path.exists(tp):
+                with open(tp) as fh:
+                    g_ = json.load(fh)['gemm_nt']
+                traffic = round((g_['fetch_mb'] + g_['write_mb']) * 1e6 / max(g_['launches'], 1))
+                traffic_src = f"profiles/{tj}: {g_['launches']} gemm_nt dispatches per step, bytes per dispatch"
+                break
         out['roofline'] = dict(bound='mfma', kernel=name, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
                                unit='TFLOP/s', frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                                traffic_source=traffic_src,
                                launches_per_step=f['launches'], avg_launch_us=round(f['ms'] * 1e3 / launches, 2),
                                algorithmic_gflop_per_launch=round(f['flops'] / launches / 1e9, 3),
-                               share_of_step_device_time=round(f['ms'] / total_ms, 3),
-                               step_achieved=round(per_gpu * GFLOP_PER_IMG / 1e3, 1),
-                               step_frac=round(per_gpu * GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS, 4))
+                               share_of_step_device_time=round(f['ms'] / total_ms, 3))
+        if gflop:
+            out['roofline'].update(step_achieved=round(per_gpu * gflop / 1e3, 1),
+                                   step_frac=round(per_gpu * gflop / 1e3 / PEAK_BF16_TFLOPS, 4))
+        if world == 1 and not a.no_measured_peaks:
+            mp_ = measured_peaks()
+            out['roofline']['measured_peaks'] = mp_
+            out['roofline']['frac_of_measured_gemm'] = round(achieved / mp_['mfma_bf16_tflops_gemm_8192'], 4)
+            if gflop:
+                out['roofline']['step_frac_of_measured_gemm'] = round(per_gpu * gflop / 1e3 / mp_['mfma_bf16_tflops_gemm_8192'], 4)
         table = {k: dict(ms=round(v['ms'], 3), launches=v['launches'],
                          tflops=round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1) if v['ms'] > 0 and v['flops'] else None)
                  for k, v in sorted(fams.items(), key=lambda kv: -kv[1]['ms'])}
@@ -229,7 +315,7 @@ def main():
                 json.dump(dict(total_ms=total_ms, families=table,
                                top_calls=sorted(calls, key=lambda c: -c["ms"])), fh, indent=1)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline()
+        out['cpu_baseline'] = cpu_baseline(a.model)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

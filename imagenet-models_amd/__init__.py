@@ -16,5 +16,5 @@ from . import ga_cswin  # noqa: E402,F401  (registers the ga_CSWin_* entry point
 from .ga_cswin import GA_CSWinTransformer  # noqa: E402,F401
 from .loss import ga_loss, heads_topk, accuracy_from_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401
-from .trainer import TrainStep  # noqa: E402,F401
+from .trainer import TrainStep, distribute_bn, make_buckets  # noqa: E402,F401
 from .checkpoint import save_checkpoint, load_checkpoint, ModelEma  # noqa: E402,F401

@@ -121,6 +121,7 @@ _SIGS = {
     'ga_convw_pack': ([vp, vp, i32, i32, i32, i32, i64, i32, vp], i32),
     'ga_convw_unpack_grad': ([vp, vp, i32, i32, i32, i32, i64, vp], i32),
     'ga_conv3s2_dgrad_prep': ([vp, vp, i32, i32, i64, i32, vp], i32),
+    'ga_drop_path_sample': ([vp, vp, i32, i32, C.c_uint64, vp, vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),

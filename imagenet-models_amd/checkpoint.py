@@ -12,6 +12,7 @@ class ModelEma:
         from .ops import Plan
         self.model, self.decay = model, decay
         st = model.flat_state()
+        self.gen = st['gen']
         self.flat = st['params'].clone()
         self.slices = st['slices']
         self.buffers = {n: b.detach().clone() for n, b in model.named_buffers()}
@@ -22,6 +23,7 @@ class ModelEma:
                 self.plan.lerp_f32(self.buffers[n], b, 1.0 - decay, b.numel())
 
     def update(self, model=None):
+        self.model.check_flat_generation(self.gen, 'ModelEma')
         self.plan.run()
         for n, b in self.model.named_buffers():
             if b.dtype != torch.float32:
@@ -49,7 +51,11 @@ def save_checkpoint(model, optimizer, epoch, path, metric=None, arch='', model_e
 
 
 def load_checkpoint(model, path, strict=True, use_ema=False):
-    ck = torch.load(path, map_location='cpu', weights_only=True)
+    """timm-layout checkpoints (`CheckpointSaver` passes args=args, GA/train.py:649-651) carry an argparse.Namespace under
+    'args': allow-listed as plain data, everything else stays under weights_only=True (nothing from the file executes)"""
+    import argparse
+    with torch.serialization.safe_globals([argparse.Namespace]):
+        ck = torch.load(path, map_location='cpu', weights_only=True)
     if use_ema and isinstance(ck, dict) and 'state_dict_ema' in ck:
         ck = {'state_dict': ck['state_dict_ema']}
     sd = ck.get('state_dict', ck.get('model', ck)) if isinstance(ck, dict) else ck

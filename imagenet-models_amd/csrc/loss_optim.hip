@@ -327,3 +327,39 @@ extern "C" int ga_lamb_stage2(float* p, const float* u, const float* hp, const i
     return ga_check_launch("ga_lamb_stage2");
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// DropPath masks (timm DropPath behind GA/ga_convnext.py:111, ga_cswin.py:209-210): out[s][b] = Bernoulli(keep[s]) / keep[s]
+// for every stochastic-depth site s and sample b, from a counter-based generator (splitmix64 of seed, call counter and
+// element index): one workgroup, so the call counter in device memory can be advanced by the kernel itself.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(1024) void drop_path_sample_kernel(float* __restrict__ out, const float* __restrict__ keep, int sites,
+                                                                int B, unsigned long long seed, unsigned long long* counter) {
+    const unsigned long long call = *counter;
+    const int n = sites * B;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const unsigned long long h = splitmix64(splitmix64(seed ^ (call * 0xD1342543DE82EF95ull)) + (unsigned long long)i);
+        const float u = (float)(h >> 40) * (1.0f / 16777216.0f);     // 24 random bits -> [0, 1)
+        const float k = keep[i / B];
+        out[i] = u < k ? 1.0f / k : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = call + 1;
+}
+}  // namespace
+
+extern "C" int ga_drop_path_sample(float* out, const float* keep, int sites, int B, uint64_t seed, uint64_t* counter,
+                                   ga_stream_t stream) {
+    GA_REQUIRE(out && keep && counter && sites > 0 && B > 0, "ga_drop_path_sample: bad args");
+    hipLaunchKernelGGL(drop_path_sample_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), out, keep, sites,
+                       B, (unsigned long long)seed, reinterpret_cast<unsigned long long*>(counter));
+    return ga_check_launch("ga_drop_path_sample");
+}

@@ -91,7 +91,10 @@ class GAEngine:
             sites = [pre for pre, r in self.dp_rates.items() if r > 0]
             if sites:
                 self.dp_all = torch.ones(len(sites), batch, device=self.dev)
-                self.dp_keep = torch.tensor([1.0 - self.dp_rates[p] for p in sites], device=self.dev).unsqueeze(1)
+                self.dp_keep = torch.tensor([1.0 - self.dp_rates[p] for p in sites], device=self.dev)
+                self.dp_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+                self.dp_plan = Plan(name='droppath')
+                self.dp_plan.drop_path_sample(self.dp_all, self.dp_keep, len(sites), batch, torch.initial_seed(), self.dp_counter)
                 for i, pre in enumerate(sites):
                     self.dp_scale[pre] = self.dp_all[i]
         # scratch arena for effective-weight gradients (zeroed once per backward)
@@ -194,11 +197,11 @@ class GAEngine:
             out[f'ga.{k}.'] = 0.0                                    # LayerScaleBlockClassAttn default drop_path=0
         return out
 
-    def sample_drop_path(self, generator=None):
-        """fresh per-sample Bernoulli(keep)/keep factors for every stochastic-depth site (timm DropPath)"""
+    def sample_drop_path(self):
+        """fresh per-sample Bernoulli(keep)/keep factors for every stochastic-depth site (timm DropPath): one launch of
+        ga_drop_path_sample, keyed by torch.initial_seed() at build time and a device-side call counter"""
         if self.dp_scale:
-            r = torch.rand(self.dp_all.shape, device=self.dev, generator=generator)
-            torch.div((r < self.dp_keep).float(), self.dp_keep, out=self.dp_all)
+            self.dp_plan.run()
 
     def set_drop_path_masks(self, masks):
         for pre, t in self.dp_scale.items():
@@ -1142,7 +1145,7 @@ class GAEngine:
             self.sample_drop_path()
         self.fwd.run()
         if self.training:
-            torch._foreach_add_(self._nbt, 1)
+            self.m.count_training_forward()     # num_batches_tracked: host-side count, written on state_dict()
         return self.logits.view_as(self.logits)
 
     def build_loss(self, lam, kind=0, smoothing=0.0, grad_scale=1.0):

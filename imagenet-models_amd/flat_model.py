@@ -55,9 +55,24 @@ class FlatModel(nn.Module):
                 p.grad = grads[off:off + k].view(p.shape)
                 slices[n] = (off, k)
                 off += k
+        # BatchNorm running statistics in ONE flat fp32 buffer too (DDP's per-forward buffer broadcast and timm's
+        # distribute_bn, GA/train.py:514,665-674, then are one collective each); num_batches_tracked in one int64 buffer
+        fbufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.float32]
+        ibufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.int64]
+        fb = torch.empty(sum(b.numel() for _, b in fbufs), dtype=torch.float32, device=dev)
+        ib = torch.empty(sum(b.numel() for _, b in ibufs), dtype=torch.int64, device=dev)
+        with torch.no_grad():
+            for flatbuf, lst in ((fb, fbufs), (ib, ibufs)):
+                off = 0
+                for n, b in lst:
+                    k = b.numel()
+                    flatbuf[off:off + k].copy_(b.detach().reshape(-1))
+                    b.data = flatbuf[off:off + k].view(b.shape)
+                    off += k
         self._flat_gen += 1
         self._flat = dict(params=flat, grads=grads, n_decay=sum(p.numel() for _, p in decay), total=total,
-                          slices=slices, gen=self._flat_gen)
+                          slices=slices, gen=self._flat_gen, buffers=fb, ibuffers=ib)
+        self._nbt_pending = 0
         self._engines = {}
 
     def _is_flat_on(self, first):
@@ -96,11 +111,34 @@ class FlatModel(nn.Module):
                                'parameters after this object was built); rebuild it')
 
     def zero_grad(self, set_to_none=False):
-        """Gradients live in one flat fp32 buffer that the wgrad kernels accumulate into: zero it in place."""
+        """Gradients live in one flat fp32 buffer that the wgrad kernels accumulate into: zero it in place (hipMemsetAsync
+        on the current stream through the C ABI)."""
         if self._flat is not None:
-            self._flat['grads'].zero_()
+            from .ops import zero_
+            zero_(self._flat['grads'])
         else:
             super().zero_grad(set_to_none=set_to_none)
+
+    # nn.BatchNorm2d.num_batches_tracked: counted on the host per training forward and written into the int64 buffers
+    # when somebody looks (state_dict / checkpoint), so the step itself issues no launch for it
+    def count_training_forward(self):
+        self._nbt_pending = getattr(self, '_nbt_pending', 0) + 1
+
+    def flush_counters(self):
+        n = getattr(self, '_nbt_pending', 0)
+        if n and self._flat is not None and self._flat['ibuffers'].numel():
+            self._flat['ibuffers'] += n
+        self._nbt_pending = 0
+
+    def state_dict(self, *args, **kwargs):
+        self.flush_counters()
+        return super().state_dict(*args, **kwargs)
+
+    def grad_groups(self):
+        """[(backward-plan mark, parameter-name prefixes whose gradients are final at that mark)] in backward-completion
+        order; parameters matched by no group are final at the end of backward.  Used to cut the flat gradient buffer into
+        all-reduce buckets that start while the rest of backward still runs (trainer.make_buckets)."""
+        return []
 
     def load_state_dict(self, state_dict, strict=True, assign=False):
         if self._flat is not None:

@@ -141,6 +141,10 @@ class GA_ConvNeXt(FlatModel):
         from .engine import GAEngine
         return GAEngine(self, batch, training, mode)
 
+    def grad_groups(self):
+        return [('heads', ('stages.4.', 'gram_contraction.', 'gram_layer.', 'gram_embedding.', 'ga.', 'fc.')),
+                ('stage3', ('stages.3.',)), ('stage2', ('stages.2.',)), ('stage1', ('stages.1.',))]
+
 
 def _create(variant, pretrained=False, **kwargs):
     # timm build_model_with_cfg: pops cfg kwargs; GA configs carry no weight URL (ga_convnext.py:37-41)

@@ -150,6 +150,10 @@ class GA_CSWinTransformer(FlatModel):
         from .engine_cswin import CSWinEngine
         return CSWinEngine(self, batch, training, mode)
 
+    def grad_groups(self):
+        return [('heads', ('stage5.', 'gram_contraction.', 'gram_layer.', 'gram_embedding.', 'ga.', 'fc.')),
+                ('stage3', ('stage4.', 'merge3.')), ('stage2', ('stage3.', 'merge2.')), ('stage1', ('stage2.', 'merge1.'))]
+
 
 def _create(variant, pretrained=False, **kwargs):
     for k in ('pretrained_cfg', 'pretrained_cfg_overlay', 'features_only', 'default_cfg'):

@@ -525,6 +525,10 @@ class Plan:
         self._add('ga_adamw_step', (_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(hp), n, wd_mult), label,
                   keep=(p, g, m, v, hp))
 
+    def drop_path_sample(self, out, keep, sites, B, seed, counter, label=None):
+        self._add('ga_drop_path_sample', (_ptr(out), _ptr(keep), sites, B, int(seed) & ((1 << 64) - 1), _ptr(counter)), label,
+                  keep=(out, keep, counter))
+
     # -- utilities ----------------------------------------------------------------------------------
     def transpose_f32(self, src, dst, R, Cdim, accumulate=False, label=None):
         if self.defer:
@@ -569,6 +573,12 @@ class Plan:
     def zero(self, t, label=None):
         """memset a persistent buffer (hipMemsetAsync on the plan's stream)."""
         self._add('ga_memset', (_ptr(t), 0, t.numel() * t.element_size()), label or 'zero', keep=(t,))
+
+
+def zero_(t):
+    """t.zero_() as a hipMemsetAsync on the current stream through the C ABI"""
+    L.check(L.load().ga_memset(_ptr(t), 0, t.numel() * t.element_size(), current_stream_ptr()), 'ga_memset')
+    return t
 
 
 _NUM_CU = None

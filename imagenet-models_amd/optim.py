@@ -5,7 +5,7 @@ import math
 
 import torch
 
-from .ops import Plan
+from .ops import Plan, zero_
 
 
 class _FlatOptimizer:
@@ -16,6 +16,7 @@ class _FlatOptimizer:
         self.n_decay, self.total = st['n_decay'], st['total']
         self.param_groups = [dict(lr=lr, weight_decay=weight_decay, initial_lr=lr)]
         self.hp = torch.zeros(8, device=self.p.device)
+        self.gen = st['gen']
         self.steps = 0
         self._hp_host = None
 
@@ -24,7 +25,7 @@ class _FlatOptimizer:
         return self.param_groups[0]['lr']
 
     def zero_grad(self, set_to_none=False):
-        self.g.zero_()
+        zero_(self.g)
 
     def _segments(self):
         segs = []
@@ -54,6 +55,7 @@ class FusedSGD(_FlatOptimizer):
             self.plan.sgd_step(self.p[off:], self.g[off:], self.buf[off:], self.hp, n, nesterov, mult)
 
     def step(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
         g = self.param_groups[0]
         self._push_hp([g['lr'], g['weight_decay'], self.momentum, 0.0, 0.0, 0.0, 0.0, 1.0 if self.steps == 0 else 0.0])
         self.plan.run()
@@ -80,6 +82,7 @@ class FusedAdamW(_FlatOptimizer):
             self.plan.adamw_step(self.p[off:], self.g[off:], self.m[off:], self.v[off:], self.hp, n, mult)
 
     def step(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
         g = self.param_groups[0]
         t = self.steps + 1
         b1, b2 = self.betas
@@ -130,6 +133,7 @@ class FusedLamb(_FlatOptimizer):
         pl.lamb_stage2(self.p, self.u, self.hp, self.chunks, len(rows), self.norms)
 
     def step(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
         g = self.param_groups[0]
         t = self.steps + 1
         b1, b2 = self.betas

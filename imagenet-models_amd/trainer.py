@@ -1,17 +1,70 @@
 """One optimizer step of the GA training loop (GA/train.py:732-769) on the HIP engine, without autograd:
-forward plan -> fused GA loss (writes dlogits) -> backward plan in segments, each finished segment's slice of the
-flat gradient buffer all-reduced over RCCL (one process per GPU) while the remaining backward runs -> fused flat
-optimizer.  Replaces NativeDDP's 25 MB bucket reducer (GA/train.py:514): the flat gradient layout follows the
-parameter registration order, so "stages.4 + heads", "stages.3", ... are contiguous slices."""
+forward plan -> fused GA loss (writes dlogits) -> backward plan in segments, each finished segment's slices of the
+flat gradient buffer all-reduced over RCCL (one process per GPU, torch.distributed backend "nccl") in <= 32 MB
+buckets while the remaining backward runs -> fused flat optimizer.
+
+Replaces NativeDDP (GA/train.py:514): its 25 MB reverse-registration-order bucket reducer, its per-forward broadcast of
+the BatchNorm buffers from rank 0 (`broadcast_buffers`, off with --no-ddp-bb :283) and, with `distribute_bn`, timm's
+epoch-end running-statistics reduction (:665-674).  The flat gradient layout follows the parameter registration order,
+so the parameters of one trunk stage / of the heads are a few contiguous slices; `FlatModel.grad_groups()` says which
+name prefixes are final at which mark of the backward plan."""
 import torch
 import torch.distributed as dist
 
 _KINDS = {'ce': 0, 'bce': 1}
 
+BUCKET_ELEMS = 8 << 20     # 32 MB of fp32 per all-reduce: enough to run at link rate over xGMI, small enough to pipeline
+
+
+def make_buckets(st, groups, bucket_elems=BUCKET_ELEMS):
+    """[(mark, start, end)] -- an exact partition of the flat gradient buffer [0, total) into contiguous slices of at most
+    `bucket_elems` elements, listed in backward-completion order: the slices of groups[0] (final at its mark) first, ...,
+    everything no group claims under mark 'end'."""
+    sl = st['slices']
+    owner = {}
+    order = [m for m, _ in groups] + ['end']
+    for n in sl:
+        owner[n] = 'end'
+        for mark, prefixes in groups:
+            if n.startswith(tuple(prefixes)):
+                owner[n] = mark
+                break
+    # contiguous runs of parameters with the same owner, in flat-buffer order
+    runs = []
+    for n, (off, k) in sorted(sl.items(), key=lambda kv: kv[1][0]):
+        if runs and runs[-1][0] == owner[n] and runs[-1][2] == off:
+            runs[-1][2] = off + k
+        else:
+            runs.append([owner[n], off, off + k])
+    buckets = []
+    for mark in order:
+        for own, a, b in sorted((r for r in runs if r[0] == mark), key=lambda r: -r[1]):   # highest offsets first
+            nchunk = max(1, -(-(b - a) // bucket_elems))
+            step = -(-(b - a) // nchunk)
+            cuts = list(range(a, b, step)) + [b]
+            for lo, hi in reversed(list(zip(cuts, cuts[1:]))):
+                buckets.append((mark, lo, hi))
+    return buckets
+
+
+def distribute_bn(model, world, reduce=False, group=None):
+    """timm.utils.distribute_bn (GA/train.py:665-674): average (reduce=True) or broadcast from rank 0 the BatchNorm
+    running statistics of every rank -- ONE collective over the model's flat buffer of float buffers"""
+    if world <= 1:
+        return
+    fb = model.flat_state()['buffers']
+    if fb.numel() == 0:
+        return
+    if reduce:
+        dist.all_reduce(fb, group=group)
+        fb /= float(world)
+    else:
+        dist.broadcast(fb, 0, group=group)
+
 
 class TrainStep:
     def __init__(self, model, optimizer, batch, lam=0.0, loss='ce', smoothing=0.0, grad_accumulation=1,
-                 process_group=None, clip_grad=None, clip_mode='norm'):
+                 process_group=None, clip_grad=None, clip_mode='norm', broadcast_buffers=True, bucket_elems=BUCKET_ELEMS):
         self.model, self.opt = model, optimizer
         self.eng = model.engine(batch, True)
         self.lam, self.kind, self.smoothing = lam, _KINDS[loss], smoothing
@@ -20,8 +73,11 @@ class TrainStep:
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.micro = 0
         st = model.flat_state()
+        self.gen = st['gen']
         self.flat_g = st['grads']
-        self.buckets = self._make_buckets(st) if self.world > 1 else []
+        self.flat_buffers = st['buffers']
+        self.broadcast_buffers = broadcast_buffers and self.flat_buffers.numel() > 0     # NativeDDP default (GA/train.py:514)
+        self.buckets = make_buckets(st, model.grad_groups(), bucket_elems) if self.world > 1 else []
         # gradient clipping (timm dispatch_clip_grad through NativeScaler, GA/train.py:312-333): global L2 norm or
         # value clamp over the flat gradient buffer, after the all-reduce, before the optimizer
         if clip_mode not in ('norm', 'value'):
@@ -40,32 +96,12 @@ class TrainStep:
                 p.clip_grad_f32(self.flat_g, n, self.gnorm_sq, clip_grad, 1)
             self.clip_plan = p
 
-    def _make_buckets(self, st):
-        """[(plan mark, start, end)] -- contiguous slices of the flat gradient buffer in backward-completion order"""
-        sl = st['slices']
-        names_decay = [n for n in sl if sl[n][0] < st['n_decay']]
-
-        def first_off(prefixes):
-            offs = [sl[n][0] for n in names_decay if n.startswith(prefixes)]
-            return min(offs) if offs else None
-
-        cuts = []  # (mark, start offset of the slice that becomes final at this mark)
-        head_start = first_off(('stages.4.',))
-        cuts.append(('heads', head_start))
-        for i in (3, 2, 1):
-            cuts.append((f'stage{i}', first_off((f'stages.{i}.',))))
-        buckets, end = [], st['n_decay']
-        for mark, start in cuts:
-            buckets.append((mark, start, end))
-            end = start
-        # stem + stages.0 (decay) and every no-decay parameter (biases, norms, gammas) go last
-        buckets.append(('end', 0, end))
-        buckets.append(('end', st['n_decay'], st['total']))
-        return buckets
-
     def __call__(self, x, target):
         eng = self.eng
+        self.model.check_flat_generation(self.gen, 'TrainStep')
         last_micro = (self.micro + 1) % self.accum == 0
+        if self.world > 1 and self.broadcast_buffers:
+            dist.broadcast(self.flat_buffers, 0, group=self.pg)      # rank 0's BatchNorm statistics before every forward
         # the reference divides the loss by grad_accumulation (train.py:750); DDP averages over ranks
         scale = 1.0 / (self.accum * self.world)
         loss = eng.forward_loss(x, target, self.lam, self.kind, self.smoothing, scale)

@@ -377,6 +377,11 @@ int ga_convw_pack(const float* w, void* out, int Co, int Ci, int taps, int Cp, i
 int ga_convw_unpack_grad(const float* G, float* dW, int Co, int Ci, int taps, int Cp, int64_t ldg, ga_stream_t stream);
 int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, int64_t ldo, int dtype, ga_stream_t stream);
 
+/* DropPath masks of a training step (timm DropPath: ga_convnext.py:96,111; ga_cswin.py:181,209-210):
+ *   out[s][b] = Bernoulli(keep[s]) / keep[s]  for `sites` stochastic-depth sites x B samples, from a counter-based
+ *   generator keyed by (seed, *counter, element); *counter (device memory) is advanced by one per call. */
+int ga_drop_path_sample(float* out, const float* keep, int sites, int B, uint64_t seed, uint64_t* counter, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */

@@ -98,14 +98,22 @@ def test_flat_layout_and_buckets_partition_the_gradient_buffer():
         off, k = st['slices'][n]
         assert p.data_ptr() == st['params'].data_ptr() + 4 * off and p.grad.data_ptr() == st['grads'].data_ptr() + 4 * off
         assert (off < n_decay) == (not m.no_weight_decay_param(n, p))
-    ts = TrainStep.__new__(TrainStep)
-    buckets = TrainStep._make_buckets(ts, st)
-    cover = sorted((a, b) for _, a, b in buckets)
-    assert cover[0][0] == 0 and cover[-1][1] == total
-    for (a0, b0), (a1, b1) in zip(cover, cover[1:]):
-        assert b0 == a1
-    # backward-completion order: the head slice is final first
-    assert buckets[0][0] == 'heads' and buckets[0][2] == n_decay
+    from imagenet_models_amd.trainer import make_buckets
+    for cap in (8 << 20, 50000):     # one bucket per run / runs cut into <= 50k-element all-reduces
+        buckets = make_buckets(st, m.grad_groups(), cap)
+        cover = sorted((a, b) for _, a, b in buckets)
+        assert cover[0][0] == 0 and cover[-1][1] == total
+        for (a0, b0), (a1, b1) in zip(cover, cover[1:]):
+            assert b0 == a1                                   # exact partition
+        assert all(b - a <= cap for a, b in cover)
+        # backward-completion order: the heads' slices first (the end of the decay segment), marks never go backwards
+        assert buckets[0][0] == 'heads' and any(mk == 'heads' and b == n_decay for mk, a, b in buckets)
+        marks = [mk for mk, _, _ in buckets]
+        order = [g for g, _ in m.grad_groups()] + ['end']
+        assert [order.index(mk) for mk in marks] == sorted(order.index(mk) for mk in marks)
+        owner = {n: next((g for g, pre in m.grad_groups() if n.startswith(tuple(pre))), 'end') for n in st['slices']}
+        for n, (off, k) in st['slices'].items():
+            assert all(mk == owner[n] for mk, a, b in buckets if a < off + k and off < b), n
     k_off = st['slices']['ga.0.attn.k.weight'][0]
     v_off = st['slices']['ga.0.attn.v.weight'][0]
     assert v_off == k_off + m.ga[0].attn.k.weight.numel()   # engine relies on k/v adjacency
@@ -115,13 +123,12 @@ def _gloo_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from imagenet_models_amd.trainer import TrainStep
+    from imagenet_models_amd.trainer import make_buckets
     torch.manual_seed(0)
     m = _small()
     m._flatten()
     st = m.flat_state()
-    ts = TrainStep.__new__(TrainStep)
-    buckets = TrainStep._make_buckets(ts, st)
+    buckets = make_buckets(st, m.grad_groups(), 60000)
     g = torch.Generator().manual_seed(100 + rank)
     local = torch.randn(st['total'], generator=g)
     st['grads'].copy_(local / world)          # TrainStep folds 1/world into the loss gradient scale
@@ -180,3 +187,40 @@ def test_drop_path_schedule_matches_reference():
     ref = O.drop_path_rates(O.make_cfg('ga_convnext_tiny_768', drop_path_rate=0.2))
     assert abs(rates['stages.2.blocks.4.'] - ref[2][4]) < 1e-7 and abs(rates['stages.3.blocks.2.'] - ref[3][2]) < 1e-7
     assert abs(rates['gram_layer.3.blocks.0.'] - ref[4][0]) < 1e-7 and rates['stages.4.'] == pytest.approx(0.2)
+
+
+def test_load_timm_layout_checkpoint_with_args_namespace(tmp_path):
+    """timm CheckpointSaver files (GA/train.py:649-651: args=args) hold an argparse.Namespace, 'module.'-prefixed keys when
+    saved from DDP, and state_dict_ema: load_checkpoint must read them under weights_only=True"""
+    import argparse
+    from imagenet_models_amd.checkpoint import load_checkpoint
+    m = _small()
+    sd = {k: torch.full_like(v, 0.25) if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    ema = {k: torch.full_like(v, 0.5) if v.is_floating_point() else v.clone() for k, v in m.state_dict().items()}
+    path = os.path.join(tmp_path, 'checkpoint-3.pth.tar')
+    torch.save({'epoch': 3, 'arch': 'ga_convnext_tiny_768', 'state_dict': {'module.' + k: v for k, v in sd.items()},
+                'optimizer': {'state': {}, 'param_groups': [{'lr': 0.1}]}, 'version': 2,
+                'args': argparse.Namespace(model='ga_convnext_tiny_768', lr=5e-3, opt='lamb'), 'amp_scaler': {'scale': 65536.0},
+                'state_dict_ema': ema, 'metric': 81.2}, path)
+    load_checkpoint(m, path)
+    assert float(m.fc[0].weight.mean()) == 0.25
+    load_checkpoint(m, path, use_ema=True)
+    assert float(m.fc[0].weight.mean()) == 0.5
+    with pytest.raises(RuntimeError, match='size mismatch'):      # a wrong-shaped tensor is rejected, not broadcast
+        bad = dict(sd)
+        bad['fc.0.bias'] = torch.zeros(1)
+        m2 = _small()
+        m2._flatten()
+        m2.load_state_dict(bad)
+
+
+def test_second_cuda_call_keeps_flat_buffers_and_stale_holders_raise():
+    """model.cuda()/.to() after the optimizer exists must not silently re-create the flat buffers"""
+    m = _small()
+    m._flatten()
+    st = m.flat_state()
+    gen = st['gen']
+    m.check_flat_generation(gen, 'test')
+    m._flatten()                                  # what a parameter move does
+    with pytest.raises(RuntimeError, match='re-created'):
+        m.check_flat_generation(gen, 'test')

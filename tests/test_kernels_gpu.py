@@ -791,3 +791,27 @@ def test_weight_prep_stacked_transposed_operand(dt):
         ref = torch.cat([w * c[None, :] for w, c in zip(ws, css)], 0)      # [heads*Co, Ci]
         assert_close(outT, ref.t(), tol(dt, 0.5), 'stacked outT')
         assert_close(out[:, :Ci], ref, tol(dt, 0.5), 'stacked out')
+
+
+def test_drop_path_sampler_statistics():
+    """ga_drop_path_sample: values in {0, 1/keep}, keep-rate within 4 sigma, a new mask every call (device-side counter)"""
+    ops = _imp()
+    sites, B = 7, 4096
+    keep = torch.linspace(0.5, 1.0, sites)
+    out = torch.zeros(sites, B, device='cuda')
+    ctr = torch.zeros(1, dtype=torch.int64, device='cuda')
+    p = ops.Plan(name='dp')
+    p.drop_path_sample(out, keep.cuda(), sites, B, 1234, ctr)
+    p.run()
+    a = out.cpu().clone()
+    p.run()
+    b = out.cpu()
+    assert int(ctr) == 2
+    for s in range(sites):
+        k = float(keep[s])
+        vals = set(a[s].unique().tolist())
+        assert vals <= {0.0, pytest.approx(1.0 / k)} or all(v == 0.0 or abs(v - 1 / k) < 1e-6 for v in vals)
+        rate = float((a[s] > 0).float().mean())
+        assert abs(rate - k) <= 4 * math.sqrt(k * (1 - k) / B) + 1e-9, (s, rate, k)
+    assert not torch.equal(a[0], b[0])          # keep 0.5: two calls give different masks
+    assert torch.equal(a[-1], torch.ones(B))    # keep 1.0: never dropped
