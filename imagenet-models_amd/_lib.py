@@ -121,6 +121,18 @@ _SIGS = {
     'ga_convw_pack': ([vp, vp, i32, i32, i32, i32, i64, i32, vp], i32),
     'ga_convw_unpack_grad': ([vp, vp, i32, i32, i32, i32, i64, vp], i32),
     'ga_conv3s2_dgrad_prep': ([vp, vp, i32, i32, i64, i32, vp], i32),
+    'ga_gram_pack_fwd2': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_gram_pack_bwd2': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_map_tokens_fwd': ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_map_tokens_bwd': ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_class_attn_mt_fwd': ([vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_mt_bwd': ([vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_map_loss_fwd_bwd': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, i32, vp], i32),
+    'ga_gelu_fwd': ([vp, vp, i64, i32, vp], i32),
+    'ga_gelu_bwd': ([vp, vp, vp, i64, i32, vp], i32),
+    'ga_relu_drop': ([vp, vp, vp, vp, i64, i32, vp], i32),
+    'ga_mask_mul': ([vp, vp, vp, vp, i64, i32, vp], i32),
+    'ga_copy2d': ([vp, i64, vp, i64, i64, i32, i32, i32, vp], i32),
     'ga_drop_path_sample': ([vp, vp, i32, i32, C.c_uint64, vp, vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),

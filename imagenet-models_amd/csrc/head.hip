@@ -57,6 +57,17 @@ __global__ __launch_bounds__(256) void pool_concat_kernel(const T* __restrict__ 
             const float inv = 1.f / (float)(f * f);
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] *= inv;
+        } else if (mode == 2) {          // bilinear reduction by an even factor f: the mean of the central 2 x 2 of each f x f block
+            const int f = Hin / Hout, o = f / 2 - 1;
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v[E];
+                    ldE<E>(sb + ((long)(oy * f + o + dy) * Win + ox * f + o + dx) * C, v);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] += 0.25f * v[e];
+                }
+        } else if (mode == 3) {          // adaptive_avg_pool2d to twice the size: every input pixel replicated 2 x 2
+            ldE<E>(sb + ((long)(oy >> 1) * Win + (ox >> 1)) * C, acc);
         } else {
             int y0, y1, x0, x1;
             float ly, lx;
@@ -99,6 +110,23 @@ __global__ __launch_bounds__(256) void pool_concat_bwd_kernel(const T* __restric
             const float inv = 1.f / (float)(f * f);
 #pragma unroll
             for (int e = 0; e < E; ++e) acc[e] = v[e] * inv;
+        } else if (mode == 2) {
+            const int f = Hin / Hout, o = f / 2 - 1;
+            const int ry = iy % f - o, rx = ix % f - o;
+            if ((unsigned)ry < 2u && (unsigned)rx < 2u) {
+                float v[E];
+                ldE<E>(db + ((long)(iy / f) * Wout + ix / f) * ldd, v);
+#pragma unroll
+                for (int e = 0; e < E; ++e) acc[e] = 0.25f * v[e];
+            }
+        } else if (mode == 3) {
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v[E];
+                    ldE<E>(db + ((long)(2 * iy + dy) * Wout + 2 * ix + dx) * ldd, v);
+#pragma unroll
+                    for (int e = 0; e < E; ++e) acc[e] += v[e];
+                }
         } else {
             for (int oy = max(0, 2 * iy - 2); oy <= min(Hout - 1, 2 * iy + 3); ++oy) {
                 int y0, y1;
@@ -285,7 +313,7 @@ __device__ __forceinline__ void tri_ij(int t, int C, int& i, int& j) {
 template <typename T>
 __global__ __launch_bounds__(1024) void gram_pack_kernel(const float* __restrict__ G, T* __restrict__ out,
                                                          float* __restrict__ inv_norm, int C, int groups, int Kg,
-                                                         int Kp) {
+                                                         int Kp, int ntok, int per_tok) {
     __shared__ float red[16];
     const long b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -309,6 +337,14 @@ __global__ __launch_bounds__(1024) void gram_pack_kernel(const float* __restrict
         const unsigned t0 = (unsigned)(i * C - i * (i - 1) / 2);        // packed index of (i, i)
         unsigned t = t0 + lane;
         unsigned g = t / (unsigned)Kg, k = t - g * (unsigned)Kg;
+        if (ntok > 1) {     // GramToken's token interleave (map.py:225-227): packed entry t goes to (t % T) * (ntri / T) + t / T
+            for (int j = i + lane; j < C; j += 64, t += 64) {
+                const unsigned d = (t % (unsigned)ntok) * (unsigned)per_tok + t / (unsigned)ntok;
+                const unsigned gd = d / (unsigned)Kg;
+                elt<T>::st(ob + gd * Kp + (d - gd * (unsigned)Kg), Gb[i * C + j] * inv);
+            }
+            continue;
+        }
         for (int j = i + lane; j < C; j += 64) {
             if (g < (unsigned)groups) elt<T>::st(ob + g * Kp + k, Gb[i * C + j] * inv);
             k += 64;
@@ -327,7 +363,7 @@ __global__ __launch_bounds__(1024) void gram_pack_kernel(const float* __restrict
 template <typename T>
 __global__ __launch_bounds__(1024) void gram_pack_bwd_kernel(const T* __restrict__ dvec, const T* __restrict__ vhat,
                                                              const float* __restrict__ inv_norm, T* __restrict__ S,
-                                                             int C, int groups, int Kg, int Kp) {
+                                                             int C, int groups, int Kg, int Kp, int ntok, int per_tok) {
     __shared__ float red[16];
     const long b = blockIdx.x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -347,7 +383,8 @@ __global__ __launch_bounds__(1024) void gram_pack_bwd_kernel(const T* __restrict
     for (int i = wave; i < C; i += 16) {                 // output row i: entries (i, j) read packed (min, max)
         for (int j = lane; j < C; j += 64) {
             const int lo = min(i, j), hi = max(i, j);
-            const unsigned t = (unsigned)(lo * C - lo * (lo - 1) / 2 + (hi - lo));
+            unsigned t = (unsigned)(lo * C - lo * (lo - 1) / 2 + (hi - lo));
+            if (ntok > 1) t = (t % (unsigned)ntok) * (unsigned)per_tok + t / (unsigned)ntok;
             const unsigned g = t / (unsigned)Kg, k = t - g * (unsigned)Kg;
             const float draw = g < (unsigned)groups ? inv * (elt<T>::ld(db + g * Kp + k) - elt<T>::ld(vb + g * Kp + k) * dot) : 0.f;
             elt<T>::st(Sb + i * C + j, i == j ? 2.f * draw : draw);
@@ -691,8 +728,10 @@ static size_t class_attn_rows_lds(int N, int heads, int hd, bool bwd) {
 extern "C" int ga_pool_concat_fwd(const void* src, void* dst, int B, int Hin, int Win, int C, int Hout, int Wout,
                                   int ldd, int c_off, int mode, int dtype, ga_stream_t stream) {
     GA_REQUIRE(src && dst && C % 4 == 0 && c_off % 4 == 0 && ldd % 4 == 0, "ga_pool_concat_fwd: alignment");
-    GA_REQUIRE(mode == 0 ? (Hin % Hout == 0 && Win % Wout == 0 && Hin / Hout == Win / Wout)
-                         : (Hout == 2 * Hin && Wout == 2 * Win),
+    GA_REQUIRE(mode >= 0 && mode <= 3 &&
+                   ((mode == 0 || mode == 2) ? (Hin % Hout == 0 && Win % Wout == 0 && Hin / Hout == Win / Wout &&
+                                                (mode == 0 || (Hin / Hout) % 2 == 0))
+                                             : (Hout == 2 * Hin && Wout == 2 * Win)),
                "ga_pool_concat_fwd: unsupported geometry %dx%d -> %dx%d mode %d", Hin, Win, Hout, Wout, mode);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool w8 = C % 8 == 0 && c_off % 8 == 0 && ldd % 8 == 0;
@@ -773,23 +812,35 @@ extern "C" int ga_chan_scale(const void* x, const float* g, const float* add, vo
     return ga_check_launch("ga_chan_scale");
 }
 
+extern "C" int ga_gram_pack_fwd2(const float* G, void* out, float* inv_norm, int B, int C, int groups, int Kp, int ntok,
+                                 int dtype, ga_stream_t stream) {
+    const int ntri = C * (C + 1) / 2;
+    GA_REQUIRE(G && out && inv_norm && ntri % groups == 0 && Kp >= ntri / groups && ntok >= 1 && ntri % ntok == 0,
+               "ga_gram_pack_fwd: bad args (C=%d groups=%d Kp=%d ntok=%d)", C, groups, Kp, ntok);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(1024), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp, ntok,
+               ntri / ntok);
+    return ga_check_launch("ga_gram_pack_fwd");
+}
+
+extern "C" int ga_gram_pack_bwd2(const void* dvec, const void* vhat, const float* inv_norm, void* S, int B, int C,
+                                 int groups, int Kp, int ntok, int dtype, ga_stream_t stream) {
+    const int ntri = C * (C + 1) / 2;
+    GA_REQUIRE(dvec && vhat && inv_norm && S && ntri % groups == 0 && ntok >= 1 && ntri % ntok == 0, "ga_gram_pack_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(1024), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
+               groups, ntri / groups, Kp, ntok, ntri / ntok);
+    return ga_check_launch("ga_gram_pack_bwd");
+}
+
 extern "C" int ga_gram_pack_fwd(const float* G, void* out, float* inv_norm, int B, int C, int groups, int Kp, int dtype,
                                 ga_stream_t stream) {
-    const int ntri = C * (C + 1) / 2;
-    GA_REQUIRE(G && out && inv_norm && ntri % groups == 0 && Kp >= ntri / groups, "ga_gram_pack_fwd: bad args");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(1024), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp);
-    return ga_check_launch("ga_gram_pack_fwd");
+    return ga_gram_pack_fwd2(G, out, inv_norm, B, C, groups, Kp, 1, dtype, stream);
 }
 
 extern "C" int ga_gram_pack_bwd(const void* dvec, const void* vhat, const float* inv_norm, void* S, int B, int C,
                                 int groups, int Kp, int dtype, ga_stream_t stream) {
-    const int ntri = C * (C + 1) / 2;
-    GA_REQUIRE(dvec && vhat && inv_norm && S && ntri % groups == 0, "ga_gram_pack_bwd: bad args");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(1024), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
-               groups, ntri / groups, Kp);
-    return ga_check_launch("ga_gram_pack_bwd");
+    return ga_gram_pack_bwd2(dvec, vhat, inv_norm, S, B, C, groups, Kp, 1, dtype, stream);
 }
 
 extern "C" int ga_token_cat(const void* cls, const void* tok, void* u, int B, int N, int C, int dtype,

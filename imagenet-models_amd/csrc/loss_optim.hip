@@ -31,7 +31,8 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 template <typename T>
 __global__ __launch_bounds__(256) void ga_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                       float* __restrict__ loss, T* __restrict__ dlogits, int K, int B,
-                                                      int NC, float lam, int kind, float smooth, float gscale) {
+                                                      int NC, float lam, int kind, float smooth, float gscale,
+                                                      const float* __restrict__ avg, T* __restrict__ davg) {
     extern __shared__ float sm[];  // mean logits -> r[NC]; red[8]
     float* r = sm;
     float* red = sm + NC;
@@ -83,6 +84,21 @@ __global__ __launch_bounds__(256) void ga_loss_kernel(const float* __restrict__ 
             }
             if (dlogits) elt<T>::st(dlogits + ((long)k * B + b) * NC + c, g * gscale);
         }
+        if (avg) {   // MAP self-distillation term (MAP/train.py:815-816): KL_sum(log_softmax(avg_k) || log_softmax(out_k).detach()) / (B*NC)
+            const float* a = avg + ((long)k * B + b) * NC;
+            float m3 = -3.0e38f;
+            for (int c = threadIdx.x; c < NC; c += 256) m3 = fmaxf(m3, a[c]);
+            m3 = block_max(m3, red);
+            float s3 = 0.f;
+            for (int c = threadIdx.x; c < NC; c += 256) s3 += __expf(a[c] - m3);
+            s3 = block_sum(s3, red);
+            const float lse_a = m3 + __logf(s3);
+            for (int c = threadIdx.x; c < NC; c += 256) {
+                const float logp = o[c] - lse, p = __expf(logp), loga = a[c] - lse_a;
+                total += p * (logp - loga) * invBN;
+                if (davg) elt<T>::st(davg + ((long)k * B + b) * NC + c, (__expf(loga) - p) * invBN * gscale);
+            }
+        }
     }
     total = block_sum(total, red);
     if (threadIdx.x == 0) atomicAdd(loss, total);
@@ -97,8 +113,8 @@ __global__ __launch_bounds__(64) void heads_topk_kernel(const float* __restrict_
     for (int c = lane; c < NC; c += 64) {
         float s = 0.f;
         for (int k = 0; k < K; ++k) s += logits[((long)k * B + b) * NC + c];
-        sv[c] = s;
         if (out_sum) out_sum[b * NC + c] = s;
+        sv[c] = s != s ? INFINITY : s;   // torch.topk ranks NaN largest (a diverged run must still give valid indices)
     }
     __syncthreads();
     for (int t = 0; t < topk; ++t) {
@@ -106,6 +122,7 @@ __global__ __launch_bounds__(64) void heads_topk_kernel(const float* __restrict_
         int bi = 0x7fffffff;
         for (int c = lane; c < NC; c += 64) {
             const float v = sv[c];
+            if (v != v) continue;        // already taken
             if (v > best || (v == best && c < bi)) {
                 best = v;
                 bi = c;
@@ -122,7 +139,7 @@ __global__ __launch_bounds__(64) void heads_topk_kernel(const float* __restrict_
         }
         if (lane == 0) {
             out_idx[b * topk + t] = bi;
-            sv[bi] = -INFINITY;
+            if (bi < NC) sv[bi] = __builtin_nanf("");
         }
         __syncthreads();
     }
@@ -163,21 +180,42 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 extern "C" int ga_loss_fwd_bwd(const float* logits, const int64_t* target, float* loss, void* dlogits, int K, int B,
                                int NC, float lam, int kind, float smoothing, float grad_scale, int dtype,
                                ga_stream_t stream) {
-    GA_REQUIRE(logits && target && loss && K >= 1 && B >= 1 && NC >= 1 && (kind == 0 || kind == 1), "ga_loss_fwd_bwd: bad args");
+    return ga_map_loss_fwd_bwd(logits, nullptr, target, loss, dlogits, nullptr, K, B, NC, lam, kind, smoothing, grad_scale, dtype,
+                               stream);
+}
+
+extern "C" int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int64_t* target, float* loss, void* dorg, void* davg,
+                                   int K, int B, int NC, float lam, int kind, float smoothing, float grad_scale, int dtype,
+                                   ga_stream_t stream) {
+    GA_REQUIRE(org && target && loss && K >= 1 && B >= 1 && NC >= 1 && (kind == 0 || kind == 1), "ga_loss_fwd_bwd: bad args");
+    GA_REQUIRE(NC <= 36000, "ga_loss_fwd_bwd: num_classes=%d exceeds the LDS row buffer (36000)", NC);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t lds = (NC + 8) * sizeof(float);
+    if (lds > 65536) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(ga_loss_kernel<bf16_t>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                               hipFuncSetAttribute(reinterpret_cast<const void*>(ga_loss_kernel<float>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        GA_REQUIRE(ok, "ga_loss_fwd_bwd: cannot reserve %zu B of LDS", lds);
+    }
     if (dtype == GA_BF16)
-        hipLaunchKernelGGL(ga_loss_kernel<bf16_t>, dim3(B), dim3(256), lds, s, logits, target, loss, (bf16_t*)dlogits, K,
-                           B, NC, lam, kind, smoothing, grad_scale);
+        hipLaunchKernelGGL(ga_loss_kernel<bf16_t>, dim3(B), dim3(256), lds, s, org, target, loss, (bf16_t*)dorg, K,
+                           B, NC, lam, kind, smoothing, grad_scale, avg, (bf16_t*)davg);
     else
-        hipLaunchKernelGGL(ga_loss_kernel<float>, dim3(B), dim3(256), lds, s, logits, target, loss, (float*)dlogits, K, B,
-                           NC, lam, kind, smoothing, grad_scale);
+        hipLaunchKernelGGL(ga_loss_kernel<float>, dim3(B), dim3(256), lds, s, org, target, loss, (float*)dorg, K, B,
+                           NC, lam, kind, smoothing, grad_scale, avg, (float*)davg);
     return ga_check_launch("ga_loss_fwd_bwd");
 }
 
 extern "C" int ga_heads_topk(const float* logits, int K, int B, int NC, int topk, float* out_sum, int64_t* out_idx,
                              ga_stream_t stream) {
     GA_REQUIRE(logits && out_idx && K >= 1 && topk >= 1 && topk <= NC, "ga_heads_topk: bad args");
+    GA_REQUIRE(NC <= 36000, "ga_heads_topk: num_classes=%d exceeds the LDS row buffer (36000)", NC);
+    if ((size_t)NC * sizeof(float) > 65536) {
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(heads_topk_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+        GA_REQUIRE(ok, "ga_heads_topk: cannot reserve LDS");
+    }
     hipLaunchKernelGGL(heads_topk_kernel, dim3(B), dim3(64), NC * sizeof(float), reinterpret_cast<hipStream_t>(stream),
                        logits, K, B, NC, topk, out_sum, out_idx);
     return ga_check_launch("ga_heads_topk");

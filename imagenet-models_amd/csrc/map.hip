@@ -1,0 +1,467 @@
+// MAP head kernels for gfx950 (/root/reference/MAP/models/map.py): all small / latency- or HBM-bound, no MFMA here
+// (the GEMM-shaped parts -- ch_reduction, bp_reduction, q / k / v / proj, the grouped MLP, the classifiers -- go through
+// ga_gemm / ga_wgrad):
+//   * Gram tokens -> class tokens: de-interleave of GramToken's (out_dim, T) channel layout + the self-distillation
+//     mean token (map.py:231-232, 273-275) and its backward;
+//   * ClassAttention with T query tokens against T class rows + N image rows of k | v (map.py:118-144), with the optional
+//     attention-dropout mask, forward and backward;
+//   * elementwise helpers: GELU fwd / bwd (MultiScale's ConvNormAct with non_linearity = GELU), ReLU derivative x dropout
+//     mask (GroupConvMlp with act = ReLU), mask multiply, strided 2-D copy.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+int nblk(long n, int per = 256, int cap = 4096) { return (int)std::max<long>(1, std::min<long>(cap, (n + per - 1) / per)); }
+
+// e [B][C*T] with channel c*T + t  ->  tok [B][T (+1)][C]; the extra row = mean over t (self-distillation token)
+template <typename T>
+__global__ __launch_bounds__(256) void map_tokens_fwd_kernel(const T* __restrict__ e, T* __restrict__ tok, long B, int C, int Tn,
+                                                             int add_mean) {
+    const int rows = Tn + (add_mean ? 1 : 0);
+    const long n = B * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / C;
+        const int c = (int)(i - b * C);
+        float s = 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            const float v = elt<T>::ld(e + b * C * Tn + (long)c * Tn + t);
+            s += elt<T>::round(v);
+            elt<T>::st(tok + (b * rows + t) * C + c, v);
+        }
+        if (add_mean) elt<T>::st(tok + (b * rows + Tn) * C + c, s / (float)Tn);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void map_tokens_bwd_kernel(const T* __restrict__ dtok, T* __restrict__ de, long B, int C, int Tn,
+                                                             int add_mean) {
+    const int rows = Tn + (add_mean ? 1 : 0);
+    const long n = B * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / C;
+        const int c = (int)(i - b * C);
+        const float dm = add_mean ? elt<T>::ld(dtok + (b * rows + Tn) * C + c) / (float)Tn : 0.f;
+        for (int t = 0; t < Tn; ++t) elt<T>::st(de + b * C * Tn + (long)c * Tn + t, elt<T>::ld(dtok + (b * rows + t) * C + c) + dm);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// multi-token class attention.  q [B][T][E]; kv_cls [B][T][2E] (k | v of the class rows); kv_tok rows of k | v of the
+// N - T image tokens (row stride tok_ld, sample stride (N - T) * tok_ld); E = heads * hd, hd % 8 == 0, E <= 512.
+//   a_t = softmax_n(scale * q_t . k_n);  out_t = sum_n (a_t[n] * m_t[n]) v_n     (m = attention dropout mask or NULL)
+//   P [B][T][heads][N] fp32 = a (saved for backward)
+// One workgroup of 16 waves per sample; a WAVE per k | v row, lane c = the row's 8-channel chunk c (whole 16-byte lines).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kW = 16, kThr = 64 * kW, kMaxT = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv_cls,
+                                                           const T* __restrict__ kv_tok, long tok_ld, T* __restrict__ out,
+                                                           float* __restrict__ P, const float* __restrict__ mask, int Tn, int N,
+                                                           int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, NCH = E >> 3, cph = hd >> 3;
+    float* part = sm;                       // [N][NCH]
+    float* pl = part + N * NCH;             // [T][heads][N]  (a * m)
+    float* red = pl + Tn * heads * N;       // [kW][E]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live = lane < NCH;
+    const T* kvc = kv_cls + b * Tn * 2 * E;
+    const T* kvt = kv_tok + b * (N - Tn) * tok_ld - (long)Tn * tok_ld;    // row n >= T is kvt + n * tok_ld
+    auto row = [&](int n) { return n < Tn ? kvc + (long)n * 2 * E : kvt + (long)n * tok_ld; };
+    for (int t = 0; t < Tn; ++t) {
+        float qv[8];
+        if (live) {
+            load8(q + (b * Tn + t) * E + lane * 8, qv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[e] *= scale;
+        }
+        __syncthreads();                     // `part` of the previous query is consumed
+        for (int n = wave; n < N; n += kW) {
+            if (live) {
+                float k[8];
+                load8(row(n) + lane * 8, k);
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(qv[e], k[e], s);
+                part[n * NCH + lane] = s;
+            }
+        }
+        __syncthreads();
+        for (int h = wave; h < heads; h += kW) {
+            float* pr = pl + (t * heads + h) * N;
+            float mx = -3.0e38f;
+            for (int n = lane; n < N; n += 64) {
+                float s = 0.f;
+                for (int i = 0; i < cph; ++i) s += part[n * NCH + h * cph + i];
+                pr[n] = s;
+                mx = fmaxf(mx, s);
+            }
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                const float e = __expf(pr[n] - mx);
+                pr[n] = e;
+                sum += e;
+            }
+            sum = wave_sum(sum);
+            const float inv = 1.f / sum;
+            const long pofs = ((b * Tn + t) * heads + h) * N;
+            for (int n = lane; n < N; n += 64) {
+                const float p = pr[n] * inv;
+                P[pofs + n] = p;
+                pr[n] = mask ? p * mask[pofs + n] : p;
+            }
+        }
+    }
+    __syncthreads();
+    float acc[kMaxT][8];
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const int hl = live ? lane / cph : 0;
+    for (int n = wave; n < N; n += kW) {
+        if (live) {
+            float v[8];
+            load8(row(n) + E + lane * 8, v);
+#pragma unroll
+            for (int t = 0; t < kMaxT; ++t) {
+                if (t < Tn) {
+                    const float p = pl[(t * heads + hl) * N + n];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[t][e] = fmaf(p, v[e], acc[t][e]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+        if (t < Tn) {
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[wave * E + lane * 8 + e] = acc[t][e];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < E; c += kThr) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) a += red[w * E + c];
+                elt<T>::st(out + (b * Tn + t) * E + c, a);
+            }
+        }
+    }
+}
+
+// backward: dout [B][T][E] -> dq [B][T][E], dkv_cls [B][T][2E], dkv_tok rows (overwritten)
+template <typename T>
+__global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+                                                           const T* __restrict__ kv_cls, const T* __restrict__ kv_tok, long tok_ld,
+                                                           const float* __restrict__ P, const float* __restrict__ mask,
+                                                           T* __restrict__ dq, T* __restrict__ dkv_cls, T* __restrict__ dkv_tok,
+                                                           long dtok_ld, int Tn, int N, int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, NCH = E >> 3, cph = hd >> 3;
+    float* part = sm;                       // [N][NCH]
+    float* pl = part + N * NCH;             // [T][heads][N]  a * m   (weights of dv)
+    float* dsl = pl + Tn * heads * N;       // [T][heads][N]  gradient wrt the scaled scores
+    float* red = dsl + Tn * heads * N;      // [kW][E]
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live = lane < NCH;
+    const T* kvc = kv_cls + b * Tn * 2 * E;
+    const T* kvt = kv_tok + b * (N - Tn) * tok_ld - (long)Tn * tok_ld;
+    T* dkc = dkv_cls + b * Tn * 2 * E;
+    T* dkt = dkv_tok + b * (N - Tn) * dtok_ld - (long)Tn * dtok_ld;
+    auto row = [&](int n) { return n < Tn ? kvc + (long)n * 2 * E : kvt + (long)n * tok_ld; };
+    float dov[kMaxT][8], qv[kMaxT][8];
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+        if (t < Tn && live) {
+            load8(dout + (b * Tn + t) * E + lane * 8, dov[t]);
+            load8(q + (b * Tn + t) * E + lane * 8, qv[t]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[t][e] *= scale;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dov[t][e] = qv[t][e] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+        if (t >= Tn) break;
+        __syncthreads();
+        for (int n = wave; n < N; n += kW) {
+            if (live) {
+                float v[8];
+                load8(row(n) + E + lane * 8, v);
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s = fmaf(dov[t][e], v[e], s);
+                part[n * NCH + lane] = s;
+            }
+        }
+        __syncthreads();
+        for (int h = wave; h < heads; h += kW) {
+            const long pofs = ((b * Tn + t) * heads + h) * N;
+            float* pr = pl + (t * heads + h) * N;
+            float* dr = dsl + (t * heads + h) * N;
+            float dot = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                float dp = 0.f;
+                for (int i = 0; i < cph; ++i) dp += part[n * NCH + h * cph + i];
+                const float a = P[pofs + n], m = mask ? mask[pofs + n] : 1.f;
+                dp *= m;                                   // d(a) = d(a*m) * m
+                pr[n] = a * m;
+                dr[n] = dp;
+                dot = fmaf(dp, a, dot);
+            }
+            dot = wave_sum(dot);
+            for (int n = lane; n < N; n += 64) dr[n] = P[pofs + n] * (dr[n] - dot);
+        }
+    }
+    __syncthreads();
+    float acc[kMaxT][8];
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
+    const int hl = live ? lane / cph : 0;
+    for (int n = wave; n < N; n += kW) {
+        if (live) {
+            float k[8], dk[8], dv[8];
+            load8(row(n) + lane * 8, k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dk[e] = dv[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < kMaxT; ++t) {
+                if (t < Tn) {
+                    const float ds = dsl[(t * heads + hl) * N + n], p = pl[(t * heads + hl) * N + n];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        acc[t][e] = fmaf(ds, k[e], acc[t][e]);
+                        dk[e] = fmaf(ds, qv[t][e], dk[e]);
+                        dv[e] = fmaf(p, dov[t][e], dv[e]);
+                    }
+                }
+            }
+            T* drow = n < Tn ? dkc + (long)n * 2 * E : dkt + (long)n * dtok_ld;
+            store8(drow + lane * 8, dk);
+            store8(drow + E + lane * 8, dv);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxT; ++t) {
+        if (t < Tn) {
+            __syncthreads();
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[wave * E + lane * 8 + e] = acc[t][e];
+            }
+            __syncthreads();
+            for (int c = threadIdx.x; c < E; c += kThr) {
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < kW; ++w) a += red[w * E + c];
+                elt<T>::st(dq + (b * Tn + t) * E + c, a * scale);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// elementwise helpers (8 elements per thread)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8];
+        load8(x + i * 8, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        store8(y + i * 8, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8], g[8];
+        load8(x + i * 8, v);
+        load8(dy + i * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] *= gelu_grad_f(v[e]);
+        store8(dx + i * 8, g);
+    }
+}
+
+// a (ReLU output) -> a * m, deriv = (a > 0) * m   (m fp32 mask or NULL = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void relu_drop_kernel(const T* __restrict__ a, const float* __restrict__ m, T* __restrict__ out,
+                                                        T* __restrict__ deriv, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8], mm[8], d[8];
+        load8(a + i * 8, v);
+        if (m) load8(m + i * 8, mm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float k = m ? mm[e] : 1.f;
+            d[e] = v[e] > 0.f ? k : 0.f;
+            v[e] *= k;
+        }
+        store8(out + i * 8, v);
+        if (deriv) store8(deriv + i * 8, d);
+    }
+}
+
+// y = x * m (+ res)
+template <typename T>
+__global__ __launch_bounds__(256) void mask_mul_kernel(const T* __restrict__ x, const float* __restrict__ m, const T* __restrict__ res,
+                                                       T* __restrict__ y, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float v[8], mm[8];
+        load8(x + i * 8, v);
+        load8(m + i * 8, mm);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= mm[e];
+        if (res) {
+            float r[8];
+            load8(res + i * 8, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        store8(y + i * 8, v);
+    }
+}
+
+// dst[r][0..cols) (row stride ldd) (+)= src[r][0..cols) (row stride lds); cols % 8 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void copy2d_kernel(const T* __restrict__ src, long lds, T* __restrict__ dst, long ldd, long rows,
+                                                     int cols, int accumulate) {
+    const int c8 = cols / 8;
+    const long n = rows * c8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        float v[8];
+        load8(src + r * lds + c, v);
+        if (accumulate) {
+            float o[8];
+            load8(dst + r * ldd + c, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += o[e];
+        }
+        store8(dst + r * ldd + c, v);
+    }
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+size_t mt_lds(int Tn, int N, int heads, int hd, bool bwd) {
+    const int E = heads * hd;
+    return ((size_t)N * (E / 8) + (size_t)(bwd ? 2 : 1) * Tn * heads * N + (size_t)kW * E) * sizeof(float);
+}
+
+}  // namespace
+
+#define MAP_DISPATCH(dtype, KERNEL, grid, block, lds, s, ...)                                                       \
+    do {                                                                                                            \
+        if ((dtype) == GA_BF16) { using T = bf16_t; hipLaunchKernelGGL(KERNEL<T>, grid, block, lds, s, __VA_ARGS__); } \
+        else { using T = float; hipLaunchKernelGGL(KERNEL<T>, grid, block, lds, s, __VA_ARGS__); }                  \
+    } while (0)
+
+extern "C" int ga_map_tokens_fwd(const void* e, void* tok, int B, int C, int T_, int add_mean, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(e && tok && B > 0 && C > 0 && T_ >= 1, "ga_map_tokens_fwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, map_tokens_fwd_kernel, dim3(nblk((long)B * C)), dim3(256), 0, s, (const T*)e, (T*)tok, (long)B, C, T_, add_mean);
+    return ga_check_launch("ga_map_tokens_fwd");
+}
+
+extern "C" int ga_map_tokens_bwd(const void* dtok, void* de, int B, int C, int T_, int add_mean, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dtok && de && B > 0 && C > 0 && T_ >= 1, "ga_map_tokens_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, map_tokens_bwd_kernel, dim3(nblk((long)B * C)), dim3(256), 0, s, (const T*)dtok, (T*)de, (long)B, C, T_, add_mean);
+    return ga_check_launch("ga_map_tokens_bwd");
+}
+
+extern "C" int ga_class_attn_mt_fwd(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P,
+                                    const float* mask, int B, int T_, int N, int heads, int hd, float scale, int dtype,
+                                    ga_stream_t stream) {
+    GA_REQUIRE(q && kv_cls && kv_tok && out && P && B > 0 && T_ >= 1 && T_ <= kMaxT && N > T_, "ga_class_attn_mt_fwd: bad args (T <= %d)", kMaxT);
+    const int E = heads * hd;
+    GA_REQUIRE(hd % 8 == 0 && E <= 512 && tok_ld >= 2 * E && tok_ld % 8 == 0 && al16(q) && al16(kv_cls) && al16(kv_tok),
+               "ga_class_attn_mt_fwd: needs head_dim %% 8 == 0, heads*head_dim <= 512, 16-byte aligned rows");
+    const size_t lds = mt_lds(T_, N, heads, hd, false);
+    GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_fwd: %zu B of LDS needed", lds);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_fwd_kernel<bf16_t>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_fwd_kernel<float>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    GA_REQUIRE(ok, "ga_class_attn_mt_fwd: cannot reserve LDS");
+    MAP_DISPATCH(dtype, mt_attn_fwd_kernel, dim3(B), dim3(kThr), lds, s, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld,
+                 (T*)out, P, mask, T_, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_mt_fwd");
+}
+
+extern "C" int ga_class_attn_mt_bwd(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld,
+                                    const float* P, const float* mask, void* dq, void* dkv_cls, void* dkv_tok, int64_t dtok_ld,
+                                    int B, int T_, int N, int heads, int hd, float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dout && q && kv_cls && kv_tok && P && dq && dkv_cls && dkv_tok && B > 0 && T_ >= 1 && T_ <= kMaxT && N > T_,
+               "ga_class_attn_mt_bwd: bad args (T <= %d)", kMaxT);
+    const int E = heads * hd;
+    GA_REQUIRE(hd % 8 == 0 && E <= 512 && tok_ld >= 2 * E && dtok_ld >= 2 * E && tok_ld % 8 == 0 && dtok_ld % 8 == 0,
+               "ga_class_attn_mt_bwd: needs head_dim %% 8 == 0, heads*head_dim <= 512");
+    const size_t lds = mt_lds(T_, N, heads, hd, true);
+    GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_bwd: %zu B of LDS needed", lds);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                           hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    GA_REQUIRE(ok, "ga_class_attn_mt_bwd: cannot reserve LDS");
+    MAP_DISPATCH(dtype, mt_attn_bwd_kernel, dim3(B), dim3(kThr), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok,
+                 (long)tok_ld, P, mask, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, T_, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_mt_bwd");
+}
+
+extern "C" int ga_gelu_fwd(const void* x, void* y, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && y && n > 0 && n % 8 == 0 && al16(x) && al16(y), "ga_gelu_fwd: n must be a multiple of 8, 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, gelu_fwd_kernel, dim3(nblk(n / 8)), dim3(256), 0, s, (const T*)x, (T*)y, (long)(n / 8));
+    return ga_check_launch("ga_gelu_fwd");
+}
+
+extern "C" int ga_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dy && x && dx && n > 0 && n % 8 == 0, "ga_gelu_bwd: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, gelu_bwd_kernel, dim3(nblk(n / 8)), dim3(256), 0, s, (const T*)dy, (const T*)x, (T*)dx, (long)(n / 8));
+    return ga_check_launch("ga_gelu_bwd");
+}
+
+extern "C" int ga_relu_drop(const void* a, const float* mask, void* out, void* deriv, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(a && out && n > 0 && n % 8 == 0, "ga_relu_drop: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, relu_drop_kernel, dim3(nblk(n / 8)), dim3(256), 0, s, (const T*)a, mask, (T*)out, (T*)deriv, (long)(n / 8));
+    return ga_check_launch("ga_relu_drop");
+}
+
+extern "C" int ga_mask_mul(const void* x, const float* mask, const void* res, void* y, int64_t n, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && mask && y && n > 0 && n % 8 == 0, "ga_mask_mul: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, mask_mul_kernel, dim3(nblk(n / 8)), dim3(256), 0, s, (const T*)x, mask, (const T*)res, (T*)y, (long)(n / 8));
+    return ga_check_launch("ga_mask_mul");
+}
+
+extern "C" int ga_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int cols, int accumulate, int dtype,
+                         ga_stream_t stream) {
+    GA_REQUIRE(src && dst && rows > 0 && cols > 0 && cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && al16(src) && al16(dst),
+               "ga_copy2d: cols / leading dimensions must be multiples of 8, 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MAP_DISPATCH(dtype, copy2d_kernel, dim3(nblk(rows * (cols / 8))), dim3(256), 0, s, (const T*)src, (long)lds, (T*)dst, (long)ldd,
+                 (long)rows, cols, accumulate);
+    return ga_check_launch("ga_copy2d");
+}

@@ -508,6 +508,50 @@ class Plan:
     def conv3s2_dgrad_prep(self, w, out, Co, Ci, ldo, dtype, label=None):
         self._add('ga_conv3s2_dgrad_prep', (_ptr(w), _ptr(out), Co, Ci, ldo, dtype), label, keep=(w, out))
 
+    # -- MAP head -----------------------------------------------------------------------------------
+    def gram_pack_fwd2(self, G, out, inv_norm, B, Cdim, groups, Kp, ntok, dtype, label=None):
+        self._add('ga_gram_pack_fwd2', (_ptr(G), _ptr(out), _ptr(inv_norm), B, Cdim, groups, Kp, ntok, dtype), label,
+                  keep=(G, out, inv_norm))
+
+    def gram_pack_bwd2(self, dvec, vhat, inv_norm, S, B, Cdim, groups, Kp, ntok, dtype, label=None):
+        self._add('ga_gram_pack_bwd2', (_ptr(dvec), _ptr(vhat), _ptr(inv_norm), _ptr(S), B, Cdim, groups, Kp, ntok, dtype), label,
+                  keep=(dvec, vhat, inv_norm, S))
+
+    def map_tokens_fwd(self, e, tok, B, Cdim, T, add_mean, dtype, label=None):
+        self._add('ga_map_tokens_fwd', (_ptr(e), _ptr(tok), B, Cdim, T, int(add_mean), dtype), label, keep=(e, tok))
+
+    def map_tokens_bwd(self, dtok, de, B, Cdim, T, add_mean, dtype, label=None):
+        self._add('ga_map_tokens_bwd', (_ptr(dtok), _ptr(de), B, Cdim, T, int(add_mean), dtype), label, keep=(dtok, de))
+
+    def class_attn_mt_fwd(self, q, kv_cls, kv_tok, tok_ld, out, P, mask, B, T, N, heads, hd, scale, dtype, label=None):
+        self._add('ga_class_attn_mt_fwd', (_ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(out), _ptr(P), _ptr(mask), B, T, N, heads,
+                                           hd, scale, dtype), label, keep=(q, kv_cls, kv_tok, out, P, mask))
+
+    def class_attn_mt_bwd(self, dout, q, kv_cls, kv_tok, tok_ld, P, mask, dq, dkv_cls, dkv_tok, dtok_ld, B, T, N, heads, hd, scale,
+                          dtype, label=None):
+        self._add('ga_class_attn_mt_bwd', (_ptr(dout), _ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(P), _ptr(mask), _ptr(dq),
+                                           _ptr(dkv_cls), _ptr(dkv_tok), dtok_ld, B, T, N, heads, hd, scale, dtype), label,
+                  keep=(dout, q, kv_cls, kv_tok, P, mask, dq, dkv_cls, dkv_tok))
+
+    def map_loss_fwd_bwd(self, org, avg, target, loss, dorg, davg, K, B, NC, lam, kind, smoothing, grad_scale, dtype, label=None):
+        self._add('ga_map_loss_fwd_bwd', (_ptr(org), _ptr(avg), _ptr(target), _ptr(loss), _ptr(dorg), _ptr(davg), K, B, NC, lam, kind,
+                                          smoothing, grad_scale, dtype), label, keep=(org, avg, target, loss, dorg, davg))
+
+    def gelu_fwd(self, x, y, n, dtype, label=None):
+        self._add('ga_gelu_fwd', (_ptr(x), _ptr(y), n, dtype), label, keep=(x, y))
+
+    def gelu_bwd(self, dy, x, dx, n, dtype, label=None):
+        self._add('ga_gelu_bwd', (_ptr(dy), _ptr(x), _ptr(dx), n, dtype), label, keep=(dy, x, dx))
+
+    def relu_drop(self, a, mask, out, deriv, n, dtype, label=None):
+        self._add('ga_relu_drop', (_ptr(a), _ptr(mask), _ptr(out), _ptr(deriv), n, dtype), label, keep=(a, mask, out, deriv))
+
+    def mask_mul(self, x, mask, res, y, n, dtype, label=None):
+        self._add('ga_mask_mul', (_ptr(x), _ptr(mask), _ptr(res), _ptr(y), n, dtype), label, keep=(x, mask, res, y))
+
+    def copy2d(self, src, lds, dst, ldd, rows, cols, dtype, accumulate=False, label=None):
+        self._add('ga_copy2d', (_ptr(src), lds, _ptr(dst), ldd, rows, cols, int(accumulate), dtype), label, keep=(src, dst))
+
     # -- loss / metric / optimizer ------------------------------------------------------------------
     def loss_fwd_bwd(self, logits, target, loss, dlogits, K, B, NC, lam, kind, smoothing, grad_scale, dtype, label=None):
         self._add('ga_loss_fwd_bwd', (_ptr(logits), _ptr(target), _ptr(loss), _ptr(dlogits), K, B, NC, lam, kind,

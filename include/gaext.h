@@ -377,6 +377,41 @@ int ga_convw_pack(const float* w, void* out, int Co, int Ci, int taps, int Cp, i
 int ga_convw_unpack_grad(const float* G, float* dW, int Co, int Ci, int taps, int Cp, int64_t ldg, ga_stream_t stream);
 int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, int64_t ldo, int dtype, ga_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * MAP head (MAP/models/map.py).  The GEMM-shaped parts go through ga_gemm / ga_wgrad; these are the rest.
+ *   ga_gram_pack_fwd2 / _bwd2: ga_gram_pack_* with GramToken's token interleave (map.py:225-227): packed upper-triangular
+ *       entry t is stored at (t % ntok) * (ntri / ntok) + t / ntok before the grouped layout is applied (ntok = 1: identity).
+ *   ga_map_tokens_fwd: e [B][C*T] (channel c*T + t, the bp_reduction output, map.py:231-232) -> tok [B][T (+1)][C];
+ *       add_mean: the extra row is the mean over the T tokens (CAP's self-distillation token, map.py:273-275).  _bwd: its transpose.
+ *   ga_class_attn_mt_*: ClassAttention with T <= 4 query tokens (map.py:118-144, in_dim == dim branch, no `interactive`):
+ *       q [B][T][E], kv_cls [B][T][2E] (k | v of the class rows), kv_tok = k | v rows of the N - T image tokens (row stride
+ *       tok_ld); P [B][T][heads][N] fp32 = softmax, saved; mask (fp32, same shape, or NULL) = attention dropout mask
+ *       (already divided by keep); out [B][T][E].  bwd overwrites dq, dkv_cls and the dkv_tok rows (stride dtok_ld).
+ *   ga_map_loss_fwd_bwd: MAP/train.py:792-839 (distill_tokens == 0): ga_loss_fwd_bwd on the org logits plus, per group,
+ *       KL_sum(log_softmax(avg_k) || log_softmax(org_k).detach()) / (B*NC); davg = its gradient (avg == NULL: the GA loss).
+ *   ga_gelu_fwd / _bwd: y = gelu(x) (erf), dx = dy * gelu'(x)   (MultiScale ConvNormAct with non_linearity = GELU, map.py:331)
+ *   ga_relu_drop: out = a * m, deriv = (a > 0) * m  for a = relu output, m = fp32 dropout mask or NULL (GroupConvMlp, act ReLU)
+ *   ga_mask_mul: y = x * m (+ res);   ga_copy2d: dst[r][0..cols) (+)= src[r][0..cols) with row strides (elements) */
+int ga_gram_pack_fwd2(const float* G, void* out, float* inv_norm, int B, int C, int groups, int Kp, int ntok, int dtype,
+                      ga_stream_t stream);
+int ga_gram_pack_bwd2(const void* dvec, const void* vhat, const float* inv_norm, void* S, int B, int C, int groups, int Kp,
+                      int ntok, int dtype, ga_stream_t stream);
+int ga_map_tokens_fwd(const void* e, void* tok, int B, int C, int T, int add_mean, int dtype, ga_stream_t stream);
+int ga_map_tokens_bwd(const void* dtok, void* de, int B, int C, int T, int add_mean, int dtype, ga_stream_t stream);
+int ga_class_attn_mt_fwd(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P,
+                         const float* mask, int B, int T, int N, int heads, int hd, float scale, int dtype, ga_stream_t stream);
+int ga_class_attn_mt_bwd(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, const float* P,
+                         const float* mask, void* dq, void* dkv_cls, void* dkv_tok, int64_t dtok_ld, int B, int T, int N,
+                         int heads, int hd, float scale, int dtype, ga_stream_t stream);
+int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int64_t* target, float* loss, void* dorg, void* davg, int K,
+                        int B, int NC, float lam, int kind, float smoothing, float grad_scale, int dtype, ga_stream_t stream);
+int ga_gelu_fwd(const void* x, void* y, int64_t n, int dtype, ga_stream_t stream);
+int ga_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, ga_stream_t stream);
+int ga_relu_drop(const void* a, const float* mask, void* out, void* deriv, int64_t n, int dtype, ga_stream_t stream);
+int ga_mask_mul(const void* x, const float* mask, const void* res, void* y, int64_t n, int dtype, ga_stream_t stream);
+int ga_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int cols, int accumulate, int dtype,
+              ga_stream_t stream);
+
 /* DropPath masks of a training step (timm DropPath: ga_convnext.py:96,111; ga_cswin.py:181,209-210):
  *   out[s][b] = Bernoulli(keep[s]) / keep[s]  for `sites` stochastic-depth sites x B samples, from a counter-based
  *   generator keyed by (seed, *counter, element); *counter (device memory) is advanced by one per call. */
