@@ -36,9 +36,10 @@ MODEL = 'ga_convnext_tiny_768'
 GFLOP_PER_IMG = {'ga_convnext_tiny_768': 34.52, 'ga_convnext_tiny': 34.52, 'ga_convnext_tiny_688': 32.73,
                  'ga_convnext_small_768': 60.76, 'ga_convnext_small': 60.76, 'ga_convnext_small_688': 58.87,
                  'ga_convnext_base_1024': 105.54, 'ga_convnext_base': 105.54, 'ga_convnext_base_976': 104.00,
-                 'ga_CSWin_64_12211_tiny_224': 36.5}
+                 'ga_CSWin_64_12211_tiny_224': 36.5, 'map_convnext_tiny': 30.37, 'map_convnext_small': 55.85}
 LABEL = {'ga_convnext_tiny_768': 'GA-ConvNeXt-T', 'ga_convnext_small_768': 'GA-ConvNeXt-S', 'ga_convnext_base_1024': 'GA-ConvNeXt-B',
-         'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)'}
+         'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)', 'map_convnext_tiny': 'MAP-ConvNeXt-T',
+         'map_convnext_small': 'MAP-ConvNeXt-S'}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -140,10 +141,16 @@ def measured_peaks():
 
 def cpu_baseline(model_name, budget_s=10.0):
     """oracle (CPU restatement of the reference path) train step, fp32, batch 8, AdamW -- a reported baseline only"""
+    step_kw = dict(lam=-0.8)
     if 'CSWin' in model_name:
         from oracle import ga_cswin_oracle as O
         from oracle.ga_convnext_oracle import adamw_step
         mod = 'oracle/ga_cswin_oracle.py'
+    elif model_name.startswith('map_'):
+        from oracle import map_oracle as O
+        from oracle.ga_convnext_oracle import adamw_step
+        mod = 'oracle/map_oracle.py'
+        step_kw = dict(dec_lam=-0.8)
     else:
         from oracle import ga_convnext_oracle as O
         adamw_step = O.adamw_step
@@ -163,7 +170,7 @@ def cpu_baseline(model_name, budget_s=10.0):
     step = 0
     while True:
         t0 = time.time()
-        loss, outs, grads, stats = O.train_step_grads(sd, x, y, cfg, lam=-0.8)
+        loss, outs, grads, stats = O.train_step_grads(sd, x, y, cfg, **step_kw)
         params = {n: sd[n] for n in grads}
         newp, m, v = adamw_step(params, grads, m, v, step + 1, 1e-3, (0.9, 0.999), 1e-8, 0.05)
         sd.update(newp)

@@ -14,7 +14,9 @@ from . import ga_convnext  # noqa: E402,F401  (registers the ga_convnext_* entry
 from .ga_convnext import GA_ConvNeXt  # noqa: E402,F401
 from . import ga_cswin  # noqa: E402,F401  (registers the ga_CSWin_* entry points)
 from .ga_cswin import GA_CSWinTransformer  # noqa: E402,F401
-from .loss import ga_loss, heads_topk, accuracy_from_topk  # noqa: E402,F401
+from . import map_convnext  # noqa: E402,F401  (registers the map_convnext_* entry points)
+from .map_convnext import MAP_ConvNeXt  # noqa: E402,F401
+from .loss import ga_loss, heads_topk, accuracy_from_topk, map_loss, heads_mean_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401
 from .trainer import TrainStep, distribute_bn, make_buckets  # noqa: E402,F401
 from .checkpoint import save_checkpoint, load_checkpoint, ModelEma  # noqa: E402,F401

@@ -133,6 +133,7 @@ _SIGS = {
     'ga_relu_drop': ([vp, vp, vp, vp, i64, i32, vp], i32),
     'ga_mask_mul': ([vp, vp, vp, vp, i64, i32, vp], i32),
     'ga_copy2d': ([vp, i64, vp, i64, i64, i32, i32, i32, vp], i32),
+    'ga_dropout_mask_sample': ([vp, i64, f32, C.c_uint64, vp, vp], i32),
     'ga_drop_path_sample': ([vp, vp, i32, i32, C.c_uint64, vp, vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),

@@ -401,3 +401,31 @@ extern "C" int ga_drop_path_sample(float* out, const float* keep, int sites, int
                        B, (unsigned long long)seed, reinterpret_cast<unsigned long long*>(counter));
     return ga_check_launch("ga_drop_path_sample");
 }
+
+// ------------------------------------------------------------------------------------------------
+// dropout masks (nn.Dropout inside the MAP head, map.py:82-83,54): out[i] = Bernoulli(keep) / keep for n elements, same
+// counter-based generator as the DropPath sampler; any grid size -- the call counter is advanced by a second 1-thread launch
+// that runs after every workgroup of the first has read it (stream order).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, long n, float keep, unsigned long long seed,
+                                                           const unsigned long long* __restrict__ counter) {
+    const unsigned long long base = splitmix64(seed ^ (*counter * 0xD1342543DE82EF95ull));
+    const float inv = 1.0f / keep;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned long long h = splitmix64(base + (unsigned long long)i);
+        out[i] = (float)(h >> 40) * (1.0f / 16777216.0f) < keep ? inv : 0.0f;
+    }
+}
+__global__ void bump_counter_kernel(unsigned long long* counter) { *counter += 1; }
+}  // namespace
+
+extern "C" int ga_dropout_mask_sample(float* out, int64_t n, float keep, uint64_t seed, uint64_t* counter, ga_stream_t stream) {
+    GA_REQUIRE(out && counter && n > 0 && keep > 0.f && keep <= 1.f, "ga_dropout_mask_sample: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int grid = (int)std::max<long>(1, std::min<long>(2048, (n + 255) / 256));
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid), dim3(256), 0, s, out, (long)n, keep, (unsigned long long)seed,
+                       reinterpret_cast<const unsigned long long*>(counter));
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned long long*>(counter));
+    return ga_check_launch("ga_dropout_mask_sample");
+}

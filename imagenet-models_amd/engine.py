@@ -210,73 +210,17 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     # build
     # ------------------------------------------------------------------------------------------
+    # parameter names of the ConvNeXt trunk: GA-ConvNeXt follows timm's ConvNeXt (ga_convnext.py:86-137,356-359), MAP-ConvNeXt
+    # the FB one (map_convnext.py:16-83) -- same arithmetic, different module names
+    NAMES = dict(stem_conv='stem.0.', stem_ln='stem.1.', ds_ln='stages.{i}.downsample.0.', ds_conv='stages.{i}.downsample.1.',
+                 block='stages.{i}.blocks.{j}.', dw='conv_dw.', fc1='mlp.fc1.', fc2='mlp.fc2.')
+
     def _build(self):
         cfg = self.cfg
-        d, dep = cfg['dims'], cfg['depths']
+        d = cfg['dims']
         B, T, F = self.B, self.training, self.fwd
         dt = self.dt
-        S0 = self.img // 4
-        self.x_in = None
-        # ---------------- stem ----------------
-        M0 = B * S0 * S0
-        if T:
-            F.zero(self.bn_pool, label='zero.bn_sums')
-        Wst = self._w_plain('stem.0.weight', d[0], 3, 4, 4, stem=True, need_T=False)
-        stem_pre = self.act('stem.pre', (M0, d[0]))
-        self.x_placeholder = torch.zeros(8, device=self.dev)  # patched by set_input
-        F.gemm(self.x_placeholder, Wst, stem_pre, M0, d[0], 48, dt, a_kind=A_STEM4_NCHW, a_dims=(self.img, self.img, 3),
-               bias=self.P['stem.0.bias'], label='stem.conv')
-        self.input_descs.append(self._last_desc(F))
-        mean = self.act('stem.mean', (M0,), torch.float32)
-        rstd = self.act('stem.rstd', (M0,), torch.float32)
-        x = self.buf('stem.out', (M0, d[0]))
-        F.layernorm_fwd(stem_pre, self.P['stem.1.weight'], self.P['stem.1.bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
-                        label='stem.ln')
-        # ---------------- stages 0..3 ----------------
-        # one pass per chain (batch part): with GAEXT_FWD_SPLIT > 1 the chains run on side streams; every pass names
-        # the same full-batch buffers and records its own rows only
-        x_stem = x
-        chains = self._chains()
-        skew_ev = None
-        for ci, chain in enumerate(chains):
-            self._chain = chain if len(chains) > 1 else None
-            if self._chain is not None and skew_ev is not None:
-                F.lane_wait(chain[0], skew_ev)       # start this chain when the previous one has passed stage fwd_skew
-                skew_ev = None
-            feats, taps = [], []
-            x = x_stem
-            res = S0
-            stage_in = []
-            for i in range(4):
-                if i > 0:
-                    Hp = res
-                    res //= 2
-                    Mi = B * res * res
-                    Mp = B * Hp * Hp
-                    pre = f'stages.{i}.downsample.'
-                    ln = self.act(pre + 'ln', (Mp, d[i - 1]))
-                    mean = self.act(pre + 'mean', (Mp,), torch.float32)
-                    rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
-                    Wd = self._w_plain(pre + '1.weight', d[i], d[i - 1], 2, 2)
-                    xo = self.buf(pre + 'out', (Mi, d[i]))
-                    for lane, r0, r1, b0, b1 in self._fsplits(Hp * Hp):
-                        F.lane = lane
-                        F.layernorm_fwd(x[r0:r1], self.P[pre + '0.weight'], self.P[pre + '0.bias'], ln[r0:r1], mean[r0:r1],
-                                        rstd[r0:r1], r1 - r0, d[i - 1], 1e-6, dt, label=pre + 'ln')
-                        F.gemm(ln[r0:r1], Wd, xo[r0 // 4:r1 // 4], (r1 - r0) // 4, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2,
-                               a_dims=(Hp, Hp, d[i - 1]), bias=self.P[pre + '1.bias'], label=pre + 'conv')
-                    F.lane = 0
-                    stage_in.append((x, Hp))
-                    x = xo
-                tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
-                for j in range(dep[i]):
-                    x = self._block_fwd(f'stages.{i}.blocks.{j}.', x, res, d[i])
-                    if j in tap_at:
-                        taps.append(x)
-                feats.append((x, res))
-                if self._chain is not None and i == self.fwd_skew and ci + 1 < len(chains):
-                    skew_ev = F.lane_signal(chain[0])
-        self._chain = None
+        feats, taps, stage_in, _ = self._build_trunk()
         # ---------------- aggregate (ga_convnext.py:479-483) ----------------
         Hc = 14
         M4 = B * Hc * Hc
@@ -303,6 +247,78 @@ class GAEngine:
                 self.bwd.join_async()
             self.bwd.flush('end.')
         self.prep.flush('prep.')
+
+    def _build_trunk(self):
+        """stem + the four ConvNeXt stages; returns (feats [(x, res)], taps, stage_in [(x, H)], stem output)"""
+        cfg, nm = self.cfg, self.NAMES
+        d, dep = cfg['dims'], cfg['depths']
+        B, T, F = self.B, self.training, self.fwd
+        dt = self.dt
+        S0 = self.img // 4
+        self.x_in = None
+        # ---------------- stem ----------------
+        M0 = B * S0 * S0
+        if T:
+            F.zero(self.bn_pool, label='zero.bn_sums')
+        sc, sl = nm['stem_conv'], nm['stem_ln']
+        Wst = self._w_plain(sc + 'weight', d[0], 3, 4, 4, stem=True, need_T=False)
+        stem_pre = self.act('stem.pre', (M0, d[0]))
+        self.x_placeholder = torch.zeros(8, device=self.dev)  # patched by set_input
+        F.gemm(self.x_placeholder, Wst, stem_pre, M0, d[0], 48, dt, a_kind=A_STEM4_NCHW, a_dims=(self.img, self.img, 3),
+               bias=self.P[sc + 'bias'], label='stem.conv')
+        self.input_descs.append(self._last_desc(F))
+        mean = self.act('stem.mean', (M0,), torch.float32)
+        rstd = self.act('stem.rstd', (M0,), torch.float32)
+        x = self.buf('stem.out', (M0, d[0]))
+        F.layernorm_fwd(stem_pre, self.P[sl + 'weight'], self.P[sl + 'bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
+                        label='stem.ln')
+        # ---------------- stages 0..3 ----------------
+        # one pass per chain (batch part): with GAEXT_FWD_SPLIT > 1 the chains run on side streams; every pass names
+        # the same full-batch buffers and records its own rows only
+        x_stem = x
+        chains = self._chains()
+        skew_ev = None
+        for ci, chain in enumerate(chains):
+            self._chain = chain if len(chains) > 1 else None
+            if self._chain is not None and skew_ev is not None:
+                F.lane_wait(chain[0], skew_ev)       # start this chain when the previous one has passed stage fwd_skew
+                skew_ev = None
+            feats, taps = [], []
+            x = x_stem
+            res = S0
+            stage_in = []
+            for i in range(4):
+                if i > 0:
+                    Hp = res
+                    res //= 2
+                    Mi = B * res * res
+                    Mp = B * Hp * Hp
+                    pre = f'stages.{i}.downsample.'          # buffer names only
+                    pln, pcv = nm['ds_ln'].format(i=i), nm['ds_conv'].format(i=i)
+                    ln = self.act(pre + 'ln', (Mp, d[i - 1]))
+                    mean = self.act(pre + 'mean', (Mp,), torch.float32)
+                    rstd = self.act(pre + 'rstd', (Mp,), torch.float32)
+                    Wd = self._w_plain(pcv + 'weight', d[i], d[i - 1], 2, 2)
+                    xo = self.buf(pre + 'out', (Mi, d[i]))
+                    for lane, r0, r1, b0, b1 in self._fsplits(Hp * Hp):
+                        F.lane = lane
+                        F.layernorm_fwd(x[r0:r1], self.P[pln + 'weight'], self.P[pln + 'bias'], ln[r0:r1], mean[r0:r1],
+                                        rstd[r0:r1], r1 - r0, d[i - 1], 1e-6, dt, label=pre + 'ln')
+                        F.gemm(ln[r0:r1], Wd, xo[r0 // 4:r1 // 4], (r1 - r0) // 4, d[i], 4 * d[i - 1], dt, a_kind=A_PATCH2,
+                               a_dims=(Hp, Hp, d[i - 1]), bias=self.P[pcv + 'bias'], label=pre + 'conv')
+                    F.lane = 0
+                    stage_in.append((x, Hp))
+                    x = xo
+                tap_at = tap_indices(dep[i], cfg['naggre']) if i == 2 else []
+                for j in range(dep[i]):
+                    x = self._block_fwd(nm['block'].format(i=i, j=j), x, res, d[i])
+                    if j in tap_at:
+                        taps.append(x)
+                feats.append((x, res))
+                if self._chain is not None and i == self.fwd_skew and ci + 1 < len(chains):
+                    skew_ev = F.lane_signal(chain[0])
+        self._chain = None
+        return feats, taps, stage_in, x_stem
 
     def _build_heads(self, x4, M4, Hc):
         """the five GA heads on the stage-4 / stage-5 map x4 [M4, cout] (ga_convnext.py:491-504, ga_cswin.py:677-692)"""
@@ -423,15 +439,15 @@ class GAEngine:
             return
         P = self.P
         w49 = self.buf('w.' + pre + 'w49', (49, C), torch.float32)
-        self.prep.transpose_f32(P[pre + 'conv_dw.weight'], w49, C, 49, label='prep.' + pre + 'w49')
+        self.prep.transpose_f32(P[pre + self.NAMES['dw'] + 'weight'], w49, C, 49, label='prep.' + pre + 'w49')
         self.W[pre + 'w49'] = w49
-        self._w_plain(pre + 'mlp.fc1.weight', 4 * C, C, 1, 1, cs=P[pre + 'norm.weight'])
+        self._w_plain(pre + self.NAMES['fc1'] + 'weight', 4 * C, C, 1, 1, cs=P[pre + 'norm.weight'])
         b1e = self.buf('w.' + pre + 'b1e', (4 * C,), torch.float32)
-        self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm.bias'], b1e, 4 * C, C)
+        self.prep.bias_fold(P[pre + self.NAMES['fc1'] + 'weight'], P[pre + self.NAMES['fc1'] + 'bias'], None, P[pre + 'norm.bias'], b1e, 4 * C, C)
         self.W[pre + 'b1e'] = b1e
-        self._w_plain(pre + 'mlp.fc2.weight', C, 4 * C, 1, 1, rs=P[pre + 'gamma'])
+        self._w_plain(pre + self.NAMES['fc2'] + 'weight', C, 4 * C, 1, 1, rs=P[pre + 'gamma'])
         b2e = self.buf('w.' + pre + 'b2e', (C,), torch.float32)
-        self.prep.bias_fold(None, P[pre + 'mlp.fc2.bias'], P[pre + 'gamma'], None, b2e, C, 4 * C)
+        self.prep.bias_fold(None, P[pre + self.NAMES['fc2'] + 'bias'], P[pre + 'gamma'], None, b2e, C, 4 * C)
         self.W[pre + 'b2e'] = b2e
 
     # ------------------------------------------------------------------------------------------
@@ -455,12 +471,12 @@ class GAEngine:
         cur = F.lane      # inside a head's lane: one chain in that lane
         for lane, r0, r1, b0, b1 in (self._fsplits(res * res) if cur == 0 else [(cur, 0, M, 0, B)]):
             F.lane = lane
-            F.dwconv7_fwd(x[r0:r1], W[pre + 'w49'], self.P[pre + 'conv_dw.bias'], u[r0:r1], b1 - b0, res, res, C, dt,
+            F.dwconv7_fwd(x[r0:r1], W[pre + 'w49'], self.P[pre + self.NAMES['dw'] + 'bias'], u[r0:r1], b1 - b0, res, res, C, dt,
                           label=pre + 'dw')
             F.layernorm_fwd(u[r0:r1], None, None, xn[r0:r1], None, rstd[r0:r1], r1 - r0, C, 1e-6, dt, label=pre + 'ln')
-            F.gemm(xn[r0:r1], W[pre + 'mlp.fc1.weight'], a[r0:r1], r1 - r0, 4 * C, C, dt, bias=W[pre + 'b1e'], act=ACT_GELU,
+            F.gemm(xn[r0:r1], W[pre + self.NAMES['fc1'] + 'weight'], a[r0:r1], r1 - r0, 4 * C, C, dt, bias=W[pre + 'b1e'], act=ACT_GELU,
                    C2=g[r0:r1] if g is not None else None, c2_mode=2 if g is not None else 0, label=pre + 'fc1')
-            F.gemm(a[r0:r1], W[pre + 'mlp.fc2.weight'], y[r0:r1], r1 - r0, C, 4 * C, dt, bias=W[pre + 'b2e'],
+            F.gemm(a[r0:r1], W[pre + self.NAMES['fc2'] + 'weight'], y[r0:r1], r1 - r0, C, 4 * C, dt, bias=W[pre + 'b2e'],
                    rowscale=dp[b0:b1] if dp is not None else None, rows_per_scale=res * res, R=x[r0:r1], ldr=C,
                    label=pre + 'fc2')
         F.lane = cur
@@ -504,19 +520,19 @@ class GAEngine:
         Bk.lane = ml
         dh = self.tmp('dh' + par, (M, 4 * C))
         gb1 = self.gbuf((4 * C,))
-        Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, H=b['g'], ldh=4 * C, h_is_deriv=True, colsum=gb1,
+        Bk.gemm(dyz, W[pre + self.NAMES['fc2'] + 'weight.T'], dh, M, 4 * C, C, dt, H=b['g'], ldh=4 * C, h_is_deriv=True, colsum=gb1,
                 label=pre + 'dg2')
         G1 = self.gbuf((4 * C, C))
         Bk.lane = wl
         Bk.wgrad(dh, b['xn'], G1, M, 4 * C, C, dt, label=pre + 'wg1')
         Bk.lane = ml
         g = self.tmp('g', (M, C))
-        Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], g, M, C, 4 * C, dt, label=pre + 'dg1')
+        Bk.gemm(dh, W[pre + self.NAMES['fc1'] + 'weight.T'], g, M, C, 4 * C, dt, label=pre + 'dg1')
         du = self.tmp('du' + par, (M, C))
         Bk.layernorm_bwd(g, b['xn'], None, b['rstd'], None, None, du, None, None, M, C, True, dt, label=pre + 'lnb')
         dw49 = self.gbuf((49, C))
         Bk.lane = wl
-        Bk.dwconv7_bwd_weight(du, b['x'], dw49, self.grad(pre + 'conv_dw.bias'), B, res, res, C, dt, label=pre + 'dww')
+        Bk.dwconv7_bwd_weight(du, b['x'], dw49, self.grad(pre + self.NAMES['dw'] + 'bias'), B, res, res, C, dt, label=pre + 'dww')
         Bk.lane = ml
         if side:
             Bk.async_mark(f'blk{self._bwd_seq}')
@@ -527,14 +543,14 @@ class GAEngine:
                 nxt = f'dyz{(self._bwd_seq + 1) % 3}' if side else 'dyz'
                 dx2 = self._pre_dyz[next_pre] = self.tmp(nxt, (M, C))
         Bk.dwconv7_bwd_data(du, W[pre + 'w49'], dy, dx, B, res, res, C, dt, dx2=dx2, scale2=dp_next, label=pre + 'dwd')
-        Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + 'mlp.fc2.weight'], b=P[pre + 'mlp.fc2.bias'],
-                         rs=P[pre + 'gamma'], dW=self.grad(pre + 'mlp.fc2.weight'), db=self.grad(pre + 'mlp.fc2.bias'),
+        Bk.weight_unfold(G2, 4 * C, C, 4 * C, gb=gb2, W=P[pre + self.NAMES['fc2'] + 'weight'], b=P[pre + self.NAMES['fc2'] + 'bias'],
+                         rs=P[pre + 'gamma'], dW=self.grad(pre + self.NAMES['fc2'] + 'weight'), db=self.grad(pre + self.NAMES['fc2'] + 'bias'),
                          d_rs=self.grad(pre + 'gamma'), label=pre + 'unf2')
-        Bk.weight_unfold(G1, C, 4 * C, C, gb=gb1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'],
-                         cs=P[pre + 'norm.weight'], v=P[pre + 'norm.bias'], dW=self.grad(pre + 'mlp.fc1.weight'),
-                         db=self.grad(pre + 'mlp.fc1.bias'), d_cs=self.grad(pre + 'norm.weight'),
+        Bk.weight_unfold(G1, C, 4 * C, C, gb=gb1, W=P[pre + self.NAMES['fc1'] + 'weight'], b=P[pre + self.NAMES['fc1'] + 'bias'],
+                         cs=P[pre + 'norm.weight'], v=P[pre + 'norm.bias'], dW=self.grad(pre + self.NAMES['fc1'] + 'weight'),
+                         db=self.grad(pre + self.NAMES['fc1'] + 'bias'), d_cs=self.grad(pre + 'norm.weight'),
                          d_v=self.grad(pre + 'norm.bias'), label=pre + 'unf1')
-        Bk.transpose_f32(dw49, self.grad(pre + 'conv_dw.weight'), 49, C, accumulate=True, label=pre + 'unfdw')
+        Bk.transpose_f32(dw49, self.grad(pre + self.NAMES['dw'] + 'weight'), 49, C, accumulate=True, label=pre + 'unfdw')
 
     # ------------------------------------------------------------------------------------------
     # BatchNorm helper (stats come from the producing GEMM's colsum epilogue)
@@ -680,8 +696,9 @@ class GAEngine:
     # n = gi*gc + ci  <-  fc1 output channel ci*mg + gi; with Nv = gc / mg rows per "virtual group" the fc1 input group is
     # constant inside one (= v % mg), so fc1 is a batched GEMM over mg*mg virtual groups and fc2 one over mg groups.
     # ------------------------------------------------------------------------------------------
-    def _gmlp_fwd(self, pre, t, rows, C, mg, out, R, rowscale, rps, gamma_name=None):
-        """out = R + rowscale * gamma * fc2(shuffle(gelu(fc1(t))));  pre = '<block>.mlp.'"""
+    def _gmlp_fwd(self, pre, t, rows, C, mg, out, R, rowscale, rps, gamma_name=None, act='gelu', drop_mask=None):
+        """out = R + rowscale * gamma * fc2(shuffle(drop(act(fc1(t)))));  pre = '<block>.mlp.';  act 'gelu' (GA) or 'relu'
+        (MAP, map.py:467) with an optional dropout mask [rows, 4C] on the hidden layer (in the SHUFFLED channel order)"""
         F, dt, P, T = self.fwd, self.dt, self.P, self.training
         gamma = P[gamma_name] if gamma_name else None
         Hd = 4 * C
@@ -697,9 +714,19 @@ class GAEngine:
         st = dict(perm=perm, Hd=Hd, gc=gc_, Nv=Nv, cin=cin)
         st['am'] = self.act(pre + 'am', (rows, Hd))                      # gelu(hidden), shuffled order
         st['gm'] = self.act(pre + 'gm', (rows, Hd)) if T else None       # gelu'(hidden)
-        F.gemm(t, Wm1, st['am'], rows, Nv, cin, dt, lda=C, batch=mg * mg, strideA=cin, a_batch_mod=mg,
-               strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ACT_GELU,
-               C2=st['gm'], c2_mode=2 if T else 0, label=pre + 'fc1')
+        if act == 'gelu':
+            assert drop_mask is None
+            F.gemm(t, Wm1, st['am'], rows, Nv, cin, dt, lda=C, batch=mg * mg, strideA=cin, a_batch_mod=mg,
+                   strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ACT_GELU,
+                   C2=st['gm'], c2_mode=2 if T else 0, label=pre + 'fc1')
+        else:   # ReLU: its derivative (times the dropout mask) is a small pass of its own; the GEMM epilogue stays generic
+            two = T or drop_mask is not None
+            raw = self.tmp('am_raw', (rows, Hd)) if two else st['am']
+            F.gemm(t, Wm1, raw, rows, Nv, cin, dt, lda=C, batch=mg * mg, strideA=cin, a_batch_mod=mg,
+                   strideB=Nv * pad8(cin), ldb=pad8(cin), ldc=Hd, strideC=Nv, bias=bm1, strideBias=Nv, act=ops.ACT_RELU,
+                   label=pre + 'fc1')
+            if two:
+                F.relu_drop(raw, drop_mask, st['am'], st['gm'], rows * Hd, dt, label=pre + 'relu')
         Wm2 = self._w_plain(pre + 'fc2.weight', cin, gc_, 1, 1, groups=mg, rs=gamma)
         bm2 = self.buf('w.' + pre + 'bm2', (C,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'fc2.bias'], gamma, None, bm2, C, gc_)
@@ -1071,6 +1098,13 @@ class GAEngine:
         d_s2, d_s3 = seeds[2 + ntap], seeds[3 + ntap]
         seed = {0: d_s0, 1: d_s1, 2: d_s2, 3: d_s3}
         tap_at = tap_indices(dep[2], cfg['naggre'])
+        self._build_trunk_backward(seed, d_taps, tap_at, feats, stage_in)
+
+    def _build_trunk_backward(self, seed, d_taps, tap_at, feats, stage_in, stem_seed=None):
+        """backward of _build_trunk: seed[i] = gradient of stage i's output from the aggregation, d_taps those of the stage-2
+        taps (after blocks tap_at), stem_seed that of the stem output (MAP: the stem output is a feature map itself)"""
+        Bk, dt, B, P, W, cfg, nm = self.bwd, self.dt, self.B, self.P, self.W, self.cfg, self.NAMES
+        d, dep = cfg['dims'], cfg['depths']
         dy = seed[3]
         for i in (3, 2, 1, 0):
             res = feats[i][1]
@@ -1083,24 +1117,25 @@ class GAEngine:
                     Bk.affine_act(dy, None, None, dtap, dy, Mi, d[i], False, dt, label=f'tap.add.{j}')
                 dx = pp[turn % 3]          # not this block's dy nor the previous block's (still read by its wgrad)
                 turn += 1
-                nxt = f'stages.{i}.blocks.{j - 1}.' if j > 0 and not (i == 2 and (j - 1) in tap_at) else None
-                self._block_bwd(f'stages.{i}.blocks.{j}.', dy, dx, next_pre=nxt)
+                nxt = nm['block'].format(i=i, j=j - 1) if j > 0 and not (i == 2 and (j - 1) in tap_at) else None
+                self._block_bwd(nm['block'].format(i=i, j=j), dy, dx, next_pre=nxt)
                 dy = dx
             if i > 0:
-                pre = f'stages.{i}.downsample.'
+                pre = f'stages.{i}.downsample.'          # buffer names only
+                pln, pcv = nm['ds_ln'].format(i=i), nm['ds_conv'].format(i=i)
                 x_prev, Hp = stage_in[i - 1]
                 Mp = B * Hp * Hp
                 G = self.gbuf((d[i], 4 * d[i - 1]))
                 with self._wlane():
                     Bk.wgrad(dy, self.bufs[pre + 'ln'], G, Mi, d[i], 4 * d[i - 1], dt, x_kind=A_PATCH2,
-                             x_dims=(Hp, Hp, d[i - 1]), dbias=self.grad(pre + '1.bias'), label=pre + 'wg')
-                Bk.weight_unfold(G, 4 * d[i - 1], d[i], d[i - 1], 2, 2, dW=self.grad(pre + '1.weight'), label=pre + 'unf')
+                             x_dims=(Hp, Hp, d[i - 1]), dbias=self.grad(pcv + 'bias'), label=pre + 'wg')
+                Bk.weight_unfold(G, 4 * d[i - 1], d[i], d[i - 1], 2, 2, dW=self.grad(pcv + 'weight'), label=pre + 'unf')
                 dln = self.tmp('dln', (Mp, d[i - 1]))
-                Bk.gemm(dy, W[pre + '1.weight.T'], dln, Mi, 4 * d[i - 1], d[i], dt, ldb=pad8(d[i]), c_kind=C_UNPATCH2,
+                Bk.gemm(dy, W[pcv + 'weight.T'], dln, Mi, 4 * d[i - 1], d[i], dt, ldb=pad8(d[i]), c_kind=C_UNPATCH2,
                         c_dims=(Hp, Hp, d[i - 1]), label=pre + 'dg')
                 dprev = self.tmp(f'dprev{i}', (Mp, d[i - 1]))
-                Bk.layernorm_bwd(dln, x_prev, self.bufs[pre + 'mean'], self.bufs[pre + 'rstd'], P[pre + '0.weight'],
-                                 seed[i - 1], dprev, self.grad(pre + '0.weight'), self.grad(pre + '0.bias'), Mp, d[i - 1],
+                Bk.layernorm_bwd(dln, x_prev, self.bufs[pre + 'mean'], self.bufs[pre + 'rstd'], P[pln + 'weight'],
+                                 seed[i - 1], dprev, self.grad(pln + 'weight'), self.grad(pln + 'bias'), Mp, d[i - 1],
                                  False, dt, label=pre + 'lnb')
                 dy = dprev
             if self.async_wgrad:
@@ -1109,12 +1144,15 @@ class GAEngine:
             Bk.mark(f'stage{i}')  # gradients of stages.i (incl. its downsample) are final
         # stem
         M0 = dy.shape[0]
+        sc, sl = nm['stem_conv'], nm['stem_ln']
+        if stem_seed is not None:
+            Bk.affine_act(dy, None, None, stem_seed, dy, M0, d[0], False, dt, label='stem.seed')
         dpre = self.tmp('dstem', (M0, d[0]))
-        Bk.layernorm_bwd(dy, self.bufs['stem.pre'], self.bufs['stem.mean'], self.bufs['stem.rstd'], P['stem.1.weight'], None,
-                         dpre, self.grad('stem.1.weight'), self.grad('stem.1.bias'), M0, d[0], False, dt, label='stem.lnb')
+        Bk.layernorm_bwd(dy, self.bufs['stem.pre'], self.bufs['stem.mean'], self.bufs['stem.rstd'], P[sl + 'weight'], None,
+                         dpre, self.grad(sl + 'weight'), self.grad(sl + 'bias'), M0, d[0], False, dt, label='stem.lnb')
         with self._wlane():
-            Bk.wgrad(dpre, self.x_placeholder, self.grad('stem.0.weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
-                     x_dims=(self.img, self.img, 3), dbias=self.grad('stem.0.bias'), label='stem.wg')
+            Bk.wgrad(dpre, self.x_placeholder, self.grad(sc + 'weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
+                     x_dims=(self.img, self.img, 3), dbias=self.grad(sc + 'bias'), label='stem.wg')
         self.input_descs.append(self._last_desc(Bk))
 
     # ------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ class FlatModel(nn.Module):
         # BatchNorm running statistics in ONE flat fp32 buffer too (DDP's per-forward buffer broadcast and timm's
         # distribute_bn, GA/train.py:514,665-674, then are one collective each); num_batches_tracked in one int64 buffer
         fbufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.float32]
-        ibufs = [(n, b) for n, b in self.named_buffers() if b.dtype == torch.int64]
+        ibufs = [(n, b) for n, b in self.named_buffers() if n.endswith('num_batches_tracked')]   # not e.g. GramToken.bp_index
         fb = torch.empty(sum(b.numel() for _, b in fbufs), dtype=torch.float32, device=dev)
         ib = torch.empty(sum(b.numel() for _, b in ibufs), dtype=torch.int64, device=dev)
         with torch.no_grad():

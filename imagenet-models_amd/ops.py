@@ -573,6 +573,10 @@ class Plan:
         self._add('ga_drop_path_sample', (_ptr(out), _ptr(keep), sites, B, int(seed) & ((1 << 64) - 1), _ptr(counter)), label,
                   keep=(out, keep, counter))
 
+    def dropout_mask_sample(self, out, n, keep, seed, counter, label=None):
+        self._add('ga_dropout_mask_sample', (_ptr(out), n, float(keep), int(seed) & ((1 << 64) - 1), _ptr(counter)), label,
+                  keep=(out, counter))
+
     # -- utilities ----------------------------------------------------------------------------------
     def transpose_f32(self, src, dst, R, Cdim, accumulate=False, label=None):
         if self.defer:

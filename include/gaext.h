@@ -417,6 +417,9 @@ int ga_copy2d(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows
  *   generator keyed by (seed, *counter, element); *counter (device memory) is advanced by one per call. */
 int ga_drop_path_sample(float* out, const float* keep, int sites, int B, uint64_t seed, uint64_t* counter, ga_stream_t stream);
 
+/* nn.Dropout masks of the MAP head (map.py:54,82-83): out[i] = Bernoulli(keep) / keep, i < n; *counter advanced by one */
+int ga_dropout_mask_sample(float* out, int64_t n, float keep, uint64_t seed, uint64_t* counter, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
