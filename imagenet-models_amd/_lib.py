@@ -41,7 +41,7 @@ class WgradDesc(C.Structure):
         ('x_H', i32), ('x_W', i32), ('x_C', i32), ('x_act', i32),
         ('dW', vp), ('ldw', i64), ('strideW', i64),
         ('dbias', vp), ('strideDbias', i64),
-        ('alpha', f32), ('split_m', i32), ('accumulate', i32),
+        ('alpha', f32), ('split_m', i32), ('accumulate', i32), ('workspace', vp), ('ws_bytes', i64),
     ]
 
 
@@ -84,7 +84,9 @@ _SIGS = {
     'ga_dwconv7_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_dwconv7_bwd_data': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_dwconv7_bwd_data2': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
-    'ga_dwconv7_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwconv7_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp], i32),
+    'ga_dwconv7_bwd_weight_workspace': ([i32, i32, i32, i32, i32], C.c_size_t),
+    'ga_wgrad_workspace': ([C.POINTER(WgradDesc)], C.c_size_t),
     'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
     'ga_bn_finalize': ([vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),

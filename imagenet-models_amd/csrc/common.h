@@ -17,7 +17,6 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // ----------------------------------------------------------------------------------------------
 void ga_set_error(const char* fmt, ...);
 int ga_check_launch(const char* what);
-float* ga_scratch(hipStream_t stream, size_t bytes);   // per-stream scratch buffer owned by the library (runtime.hip)
 
 #define GA_REQUIRE(cond, ...)                 \
     do {                                      \

@@ -962,20 +962,28 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
     return ga_check_launch("ga_dwconv7");
 }
 
-template <typename T>
-int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
-                        hipStream_t s) {
+void dwconv_wgrad_geometry(int B, int H, int W, int C, bool bf16, int* gx_out, int* nparts_out) {
     const int slices = cdiv(C, kCSW);
-    const int num_cu = num_cus();
     const bool big = H % 14 == 0 && W % 14 == 0;
     const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
-    const bool dot2 = sizeof(T) == 2 && C % 8 == 0;   // dot2 form: 89 KB of LDS at 14x14 -> one workgroup per CU
-    const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? (dot2 ? 1 : 2) : 4) * num_cu / slices));
-    const int nparts = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
-    float* part = ga_scratch(s, (size_t)nparts * 50 * C * sizeof(float));
-    if (!part) {
-        ga_set_error("dwconv7_wgrad: cannot allocate %zu B of scratch", (size_t)nparts * 50 * C * sizeof(float));
-        return GA_ERR_HIP;
+    const bool dot2 = bf16 && C % 8 == 0;   // dot2 form: 89 KB of LDS at 14x14 -> one workgroup per CU
+    const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? (dot2 ? 1 : 2) : 4) * num_cus() / slices));
+    *gx_out = gx;
+    *nparts_out = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
+}
+
+template <typename T>
+int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
+                        float* part, size_t ws_bytes, hipStream_t s) {
+    const int slices = cdiv(C, kCSW);
+    const bool big = H % 14 == 0 && W % 14 == 0;
+    const bool dot2 = sizeof(T) == 2 && C % 8 == 0;
+    int gx, nparts;
+    dwconv_wgrad_geometry(B, H, W, C, sizeof(T) == 2, &gx, &nparts);
+    if (!part || ws_bytes < (size_t)nparts * 50 * C * sizeof(float)) {
+        ga_set_error("ga_dwconv7_bwd_weight: needs %zu B of caller-provided workspace (ga_dwconv7_bwd_weight_workspace), got %zu",
+                     (size_t)nparts * 50 * C * sizeof(float), part ? ws_bytes : (size_t)0);
+        return GA_ERR_BAD_ARG;
     }
     if constexpr (sizeof(T) == 2) {
         if (dot2) {
@@ -1052,10 +1060,17 @@ extern "C" int ga_dwconv7_bwd_data2(const void* dy, const float* w49, const void
                             : launch_dwconv<float>(dy, w49, nullptr, res, dx, B, H, W, C, 1, s, dx2, scale2);
 }
 
+extern "C" size_t ga_dwconv7_bwd_weight_workspace(int B, int H, int W, int C, int dtype) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    int gx, nparts;
+    dwconv_wgrad_geometry(B, H, W, C, dtype == GA_BF16, &gx, &nparts);
+    return (size_t)nparts * 50 * C * sizeof(float);
+}
+
 extern "C" int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W,
-                                     int C, int dtype, ga_stream_t stream) {
+                                     int C, int dtype, void* workspace, size_t ws_bytes, ga_stream_t stream) {
     GA_REQUIRE(dy && x && dw49 && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "ga_dwconv7_bwd_weight: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    return dtype == GA_BF16 ? launch_dwconv_wgrad<bf16_t>(dy, x, dw49, dbias, B, H, W, C, s)
-                            : launch_dwconv_wgrad<float>(dy, x, dw49, dbias, B, H, W, C, s);
+    return dtype == GA_BF16 ? launch_dwconv_wgrad<bf16_t>(dy, x, dw49, dbias, B, H, W, C, (float*)workspace, ws_bytes, s)
+                            : launch_dwconv_wgrad<float>(dy, x, dw49, dbias, B, H, W, C, (float*)workspace, ws_bytes, s);
 }

@@ -1104,6 +1104,21 @@ bool tn2_eligible(const ga_wgrad_desc* d) {
            d->M >= 8192 && (d->accumulate || d->split_m > 1) && d->ldw % 1 == 0;
 }
 
+// row split of the wide form and the bytes of partial-tile workspace it wants (0: combine with atomics)
+size_t tn2_plan(const ga_wgrad_desc* d, int* split_out) {
+    const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
+    const int stages = d->M / 32;
+    static const int wg_budget = [] { const char* e = getenv("GAEXT_TN2_WGS"); return e ? atoi(e) : 0; }();
+    // 3/4 of the CUs: in the train step these launches share the chip with the dgrad chain (asynchronous lane), and
+    // fewer row splits mean fewer partial tiles to write and reduce (same-box A/B: 192 vs 256 workgroups -0.13 ms/step)
+    const int cus = wg_budget > 0 ? wg_budget : num_cus() * 3 / 4;
+    int split = std::max(1, std::min(stages / 8, cus / tiles));               // one workgroup per CU
+    split = cdiv(stages, cdiv(stages, split));                                // no empty row range
+    *split_out = split;
+    const long nk = (long)d->N * d->K;
+    return (split > 1 && nk >= 131072) ? (size_t)d->batch * split * nk * sizeof(float) : 0;   // small outputs: atomics are cheaper
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // persistent grid = exactly the number of workgroups that are resident at once (occupancy query per variant),
@@ -1344,21 +1359,14 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
         static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kTn2Smem) == hipSuccess;
         GA_REQUIRE(attr_ok, "ga_wgrad: cannot reserve %d bytes of LDS", kTn2Smem);
-        const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
-        const int stages = d->M / 32;
-        static const int wg_budget = [] { const char* e = getenv("GAEXT_TN2_WGS"); return e ? atoi(e) : 0; }();
-        // 3/4 of the CUs: in the train step these launches share the chip with the dgrad chain (asynchronous lane), and
-        // fewer row splits mean fewer partial tiles to write and reduce (same-box A/B: 192 vs 256 workgroups -0.13 ms/step)
-        const int cus = wg_budget > 0 ? wg_budget : num_cus() * 3 / 4;
-        int split = std::max(1, std::min(stages / 8, cus / tiles));               // one workgroup per CU
-        split = cdiv(stages, cdiv(stages, split));                                // no empty row range
+        int split;
+        const size_t need = tn2_plan(d, &split);
         dim3 grid2(cdiv(d->N, 256) * cdiv(d->K, 256) * split, 1, d->batch), block2(kTn2Threads);
-        float* part = nullptr;
+        // partial tiles + one reduce launch when the caller provided the workspace ga_wgrad_workspace() asks for; fp32 atomics
+        // into dW otherwise (slower for wide outputs, same result up to summation order)
+        float* part = (need && d->workspace && (size_t)d->ws_bytes >= need) ? reinterpret_cast<float*>(d->workspace) : nullptr;
+        GA_REQUIRE(!part || aligned16(part), "ga_wgrad: workspace must be 16-byte aligned");
         const long nk = (long)d->N * d->K;
-        if (split > 1 && nk >= 131072) {   // small outputs: the atomics are cheaper than a second launch
-            part = ga_scratch(s, (size_t)d->batch * split * nk * sizeof(float));
-            GA_REQUIRE(part, "ga_wgrad: cannot allocate %zu B of scratch", (size_t)d->batch * split * nk * sizeof(float));
-        }
         hipLaunchKernelGGL(gemm_tn2_kernel, grid2, block2, kTn2Smem, s, *d, split, part);
         if (part)
             hipLaunchKernelGGL(tn2_reduce_kernel, dim3((unsigned)std::min<long>(2048, cdiv(nk, 1024)), d->batch), dim3(256),
@@ -1371,4 +1379,10 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
     else
         hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, block, 65536, s, *d);
     return ga_check_launch("ga_wgrad");
+}
+
+extern "C" size_t ga_wgrad_workspace(const ga_wgrad_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1 || !tn2_eligible(d)) return 0;
+    int split;
+    return tn2_plan(d, &split);
 }

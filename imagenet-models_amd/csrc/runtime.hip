@@ -58,27 +58,3 @@ extern "C" int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream) {
     return GA_OK;
 }
 
-// per-stream scratch for kernels that reduce per-workgroup partial results in a second launch (grown on demand, never
-// shrunk).  Launches on one stream are ordered, so consecutive users of a stream's buffer cannot overlap.
-float* ga_scratch(hipStream_t s, size_t bytes) {
-    struct Slot { hipStream_t s; float* p; size_t bytes; };
-    static Slot slots[16];
-    static int nslots = 0;
-    Slot* sl = nullptr;
-    for (int i = 0; i < nslots; ++i)
-        if (slots[i].s == s) sl = &slots[i];
-    if (!sl) {
-        if (nslots == 16) return nullptr;
-        sl = &slots[nslots++];
-        *sl = Slot{s, nullptr, 0};
-    }
-    if (sl->bytes < bytes) {
-        if (sl->p) (void)hipFree(sl->p);        // synchronises with the work still using it
-        sl->p = nullptr;
-        sl->bytes = 0;
-        const size_t want = bytes > ((size_t)64 << 20) ? bytes : ((size_t)64 << 20);
-        if (hipMalloc(&sl->p, want) != hipSuccess) return nullptr;
-        sl->bytes = want;
-    }
-    return sl->p;
-}

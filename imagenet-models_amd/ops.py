@@ -111,6 +111,12 @@ class Plan:
         # Lane -1 (ASYNC_LANE) is different: such a call runs on ONE extra stream after everything recorded before it on
         # lane 0, and lane 0 does not wait for it until join_async() (or the end of the range being run).  The trunk's
         # weight-gradient launches go there: nothing on the dgrad chain reads their results.
+        # workspaces: ga_wgrad / ga_dwconv7_bwd_weight reduce per-workgroup partial results through CALLER-owned scratch
+        # (include/gaext.h): one torch buffer per lane (launches of one lane are stream-ordered and may share it; lanes run
+        # concurrently), sized to the largest request of that lane and allocated before the first run
+        self._ws_req = []    # (lane, bytes, patch callable(ptr, bytes))
+        self._ws = {}        # lane -> uint8 tensor
+        self._ws_dirty = False
         self.lane = 0
         self.lanes = []      # lane of every call
         self._side = None    # number of side lanes (streams come from a process-wide pool)
@@ -142,7 +148,31 @@ class Plan:
         if self.eager:
             L.check(fn(*args, current_stream_ptr()), label or fname)
 
+    def _want_workspace(self, nbytes, patch):
+        if self.eager:
+            t = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+            self.keep.append(t)
+            patch(t.data_ptr(), nbytes)
+            return
+        self._ws_req.append((self.lane, nbytes, patch))
+        self._ws_dirty = True
+
+    def finalize(self):
+        """allocate / grow the per-lane workspaces and hand their addresses to the recorded calls"""
+        if not self._ws_dirty:
+            return
+        need = {}
+        for lane, nbytes, _ in self._ws_req:
+            need[lane] = max(need.get(lane, 0), nbytes)
+        for lane, nbytes in need.items():
+            if lane not in self._ws or self._ws[lane].numel() < nbytes:
+                self._ws[lane] = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+        for lane, nbytes, patch in self._ws_req:
+            patch(self._ws[lane].data_ptr(), self._ws[lane].numel())
+        self._ws_dirty = False
+
     def run(self, stream=None):
+        self.finalize()
         s = current_stream_ptr() if stream is None else stream
         if os.environ.get('GAEXT_SYNC_DEBUG'):   # localise a faulting launch: label printed before, sync after
             for fn, args, label in self.calls:
@@ -271,6 +301,7 @@ class Plan:
         self.marks[name] = len(self.calls)
 
     def run_range(self, start, end, stream=None):
+        self.finalize()
         s = current_stream_ptr() if stream is None else stream
         if any(self.lanes[start:end]):
             return self._run_lanes(start, end)
@@ -320,6 +351,11 @@ class Plan:
         if split_m is None:
             split_m = pick_split_m(M, N, K, batch, dtype)
         d.split_m, d.accumulate = split_m, int(accumulate)
+        need = self.lib.ga_wgrad_workspace(C.byref(d))
+        if need:
+            def patch(ptr, nbytes, d=d):
+                d.workspace, d.ws_bytes = ptr, nbytes
+            self._want_workspace(int(need), patch)
         self._add('ga_wgrad', (C.byref(d),), label, keep=(d, Y, X, dW, dbias))
 
     def weight_prep(self, w, G, Co, Ci, KH, KW, dtype, out=None, ldo=0, outT=None, ldt=0, rs=None, cs=None, flip=False,
@@ -370,8 +406,18 @@ class Plan:
                   keep=(dy, w49, res, dx))
 
     def dwconv7_bwd_weight(self, dy, x, dw49, dbias, B, H, W, Cdim, dtype, label=None):
-        self._add('ga_dwconv7_bwd_weight', (_ptr(dy), _ptr(x), _ptr(dw49), _ptr(dbias), B, H, W, Cdim, dtype), label,
-                  keep=(dy, x, dw49, dbias))
+        need = int(self.lib.ga_dwconv7_bwd_weight_workspace(B, H, W, Cdim, dtype))
+        head = (_ptr(dy), _ptr(x), _ptr(dw49), _ptr(dbias), B, H, W, Cdim, dtype)
+        box = {}
+
+        def patch(ptr, nbytes):
+            box['ws'] = (ptr, nbytes)
+            if 'idx' in box:
+                fn, _, lb = self.calls[box['idx']]
+                self.calls[box['idx']] = (fn, head + (ptr, nbytes), lb)
+        self._want_workspace(need, patch)
+        self._add('ga_dwconv7_bwd_weight', head + box.get('ws', (None, 0)), label, keep=(dy, x, dw49, dbias))
+        box['idx'] = len(self.calls) - 1
 
     def layernorm_fwd(self, x, w, b, y, mean, rstd, rows, Cdim, eps, dtype, label=None):
         self._add('ga_layernorm_fwd', (_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, Cdim, eps, dtype),

@@ -5,7 +5,9 @@
  * op(s) named in its comment (file:line = /root/reference/...).  Conventions:
  *
  *  - plain pointers + sizes only; every pointer is DEVICE memory owned by the caller (the library never
- *    allocates, frees or synchronises); every call only ENQUEUES work on the hipStream_t passed last.
+ *    allocates, frees or synchronises: the two entry points that reduce per-workgroup partial results take a
+ *    caller-owned workspace sized by their ga_*_workspace() query); every call only ENQUEUES work on the
+ *    hipStream_t passed last.
  *  - activations are NHWC ("channels last"), i.e. 2-D row-major [rows = B*H*W, C]; `dtype` selects the
  *    element type of activations and of the prepared ("effective") weight copies: GA_F32 = the parity math
  *    mode, GA_BF16 = the throughput mode (fp32 accumulation, fp32 statistics, fp32 master weights/gradients).
@@ -130,8 +132,13 @@ typedef struct {
     float alpha;
     int split_m;           /* >=1 */
     int accumulate;        /* 1: add into dW (atomics); 0 with split_m==1: overwrite */
+    void* workspace;       /* caller-owned device scratch of ga_wgrad_workspace(d) bytes (16-byte aligned), or NULL: the wide */
+    int64_t ws_bytes;      /* form then combines its row splits with fp32 atomics instead of partial tiles + a reduce launch */
 } ga_wgrad_desc;
 int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream);
+/* bytes of scratch ga_wgrad would like for this descriptor (0: none).  Concurrent calls (different streams) need distinct
+ * workspaces; calls on one stream may share one. */
+size_t ga_wgrad_workspace(const ga_wgrad_desc* d);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Weight preparation: fp32 master conv/linear weight [G*Co][Ci][KH][KW]  ->  "effective" copies in `dtype`
@@ -192,10 +199,11 @@ int ga_dwconv7_bwd_data(const void* dy, const float* w49, const void* res, void*
  * separate pass over it; res is required */
 int ga_dwconv7_bwd_data2(const void* dy, const float* w49, const void* res, void* dx, void* dx2, const float* scale2,
                          int B, int H, int W, int C, int dtype, ga_stream_t stream);
-/* dw49[49][C] += sum dy * shifted x ; dbias[C] += sum dy   (per-workgroup partial sums in a per-stream scratch
- * buffer owned by the library, then one reduction launch; deterministic for a fixed grid) */
+/* dw49[49][C] += sum dy * shifted x ; dbias[C] += sum dy   (per-workgroup partial sums in the CALLER-provided workspace of
+ * ga_dwconv7_bwd_weight_workspace(...) bytes, then one reduction launch; deterministic for a fixed grid) */
+size_t ga_dwconv7_bwd_weight_workspace(int B, int H, int W, int C, int dtype);
 int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
-                          int dtype, ga_stream_t stream);
+                          int dtype, void* workspace, size_t ws_bytes, ga_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dim of [rows][C]  (F.layer_norm / LayerNorm2d, ga_convnext.py:51-67,93,233,237)

@@ -17,12 +17,23 @@ def test_library_exports_every_declared_symbol():
     from imagenet_models_amd import _lib
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, 'include', 'gaext.h')).read()
-    declared = sorted(set(re.findall(r'^\s*int\s+(ga_\w+)\s*\(', hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r'^\s*(?:int|size_t)\s+(ga_\w+)\s*\(', hdr, flags=re.M)))
     assert len(declared) >= 38
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/gaext.h but not exported by libgaext.so'
     assert sorted(_lib.exported_symbols()) == declared, 'ctypes signature table out of sync with the header'
     assert lib.ga_version() >= 100
+
+
+def test_library_never_allocates_device_memory():
+    """include/gaext.h: every pointer is caller-owned; the two reducing entry points take a caller workspace"""
+    import subprocess
+    from imagenet_models_amd import _lib
+    syms = subprocess.run(['nm', '-D', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    for banned in ('hipMalloc', 'hipFree', 'hipMallocAsync', 'hipDeviceSynchronize', 'hipStreamSynchronize'):
+        assert not re.search(r'\bU ' + banned + r'\b', syms), f'libgaext.so references {banned}'
+    lib = _lib.load()
+    assert lib.ga_dwconv7_bwd_weight_workspace(2, 14, 14, 64, _lib.GA_BF16) > 0
 
 
 def test_descriptor_structs_match_header_field_order():
