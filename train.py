@@ -46,6 +46,12 @@ parser.add_argument('--bce-loss', action='store_true')
 parser.add_argument('--drop-path', type=float, default=None)
 parser.add_argument('--grad-accumulation', type=int, default=1)
 parser.add_argument('--GA_lam', type=float, default=0)
+parser.add_argument('--dec-lam', type=float, default=None, help='MAP: weight of the group-decorrelation KL term '
+                    '(MAP/train_with_script.py:39, multi_group_loss); alias of --GA_lam for the map_* models')
+parser.add_argument('--no-ddp-bb', action='store_true', help='no per-forward broadcast of the BatchNorm buffers from rank 0 '
+                    '(GA/train.py:283,514)')
+parser.add_argument('--dist-bn', default='reduce', help='"reduce" | "broadcast" | "": distribute the BatchNorm running '
+                    'statistics between ranks after every epoch (timm distribute_bn, GA/train.py:665-674)')
 parser.add_argument('--model-ema', action='store_true', help='track an EMA of the weights (timm ModelEmaV2)')
 parser.add_argument('--model-ema-decay', type=float, default=0.9998)
 parser.add_argument('--clip-grad', type=float, default=None, help='clip gradients (GA/train.py --clip-grad)')
@@ -144,27 +150,31 @@ def main():
         raise SystemExit('train.py: only --synthetic data is shipped (no dataset / network in this environment)')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', str(args.local_rank)))
+    local = int(os.environ.get('LOCAL_RANK', str(args.local_rank))) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
+        backend = os.environ.get('GA_DIST_BACKEND', 'nccl')      # gloo: rehearsal with ranks sharing a device
+        if backend == 'nccl':
+            dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend, init_method='env://')
     import imagenet_models_amd as A
     torch.manual_seed(args.seed + rank)
     model = A.create_model(args.model, pretrained=False, num_classes=args.num_classes, drop_path_rate=args.drop_path,
                            math_mode='fp32' if args.fp32 else 'bf16').cuda()
     if world > 1:
         dist.broadcast(model.flat_state()['params'], 0)
-        for b in model.buffers():
-            dist.broadcast(b, 0)
+        dist.broadcast(model.flat_state()['buffers'], 0)
     if rank == 0:
         _logger.info('Model %s created, param count: %d', args.model, sum(p.numel() for p in model.parameters()))
     opt = A.create_optimizer_v2(model, opt=args.opt, lr=args.lr, weight_decay=args.weight_decay, momentum=args.momentum,
                                 eps=args.opt_eps, betas=tuple(args.opt_betas) if args.opt_betas else None)
     sched = A.CosineLRScheduler(opt, t_initial=args.epochs, lr_min=args.min_lr, warmup_t=args.warmup_epochs,
                                 warmup_lr_init=args.warmup_lr) if args.sched == 'cosine' else None
-    step_fn = A.TrainStep(model, opt, args.batch_size, lam=args.GA_lam, loss='bce' if args.bce_loss else 'ce',
+    lam = args.dec_lam if args.dec_lam is not None else args.GA_lam
+    step_fn = A.TrainStep(model, opt, args.batch_size, lam=lam, loss='bce' if args.bce_loss else 'ce',
                           smoothing=args.smoothing, grad_accumulation=args.grad_accumulation,
-                          clip_grad=args.clip_grad, clip_mode=args.clip_mode)
+                          clip_grad=args.clip_grad, clip_mode=args.clip_mode, broadcast_buffers=not args.no_ddp_bb)
     model_ema = A.ModelEma(model, args.model_ema_decay) if args.model_ema else None
     loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda')
     eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda')
@@ -173,6 +183,8 @@ def main():
         if sched is not None:
             sched.step(epoch)
         train_metrics = train_one_epoch(epoch, step_fn, loader, args, world, rank, model_ema)
+        if world > 1 and args.dist_bn in ('broadcast', 'reduce'):
+            A.distribute_bn(model, world, args.dist_bn == 'reduce')
         eval_metrics = validate(model, eval_loader, args, world)
         if rank == 0:
             _logger.info('*** epoch %d: train loss %.4f  top1 %.3f  top5 %.3f', epoch, train_metrics['loss'],
