@@ -2,7 +2,10 @@
 `create_model(name, pretrained, num_classes, drop_rate, drop_path_rate, ...)`, GA/train.py:407-420)."""
 import sys
 
+import warnings
+
 _entrypoints = {}
+_unsupported = {}   # name -> reason: registered for state_dict / checkpoint compatibility, refused by the HIP engine
 
 
 def register_model(fn):
@@ -17,8 +20,17 @@ def is_model(name):
     return name in _entrypoints
 
 
-def list_models(filter=''):
-    return sorted(n for n in _entrypoints if filter in n)
+def mark_unsupported(name, reason):
+    _unsupported[name] = reason
+
+
+def is_supported(name):
+    return name in _entrypoints and name not in _unsupported
+
+
+def list_models(filter='', include_unsupported=False):
+    """names the HIP engine can run; include_unsupported adds the ones that only construct (parameter layout, checkpoints)"""
+    return sorted(n for n in _entrypoints if filter in n and (include_unsupported or n not in _unsupported))
 
 
 def model_entrypoint(name):
@@ -30,6 +42,8 @@ def create_model(model_name, pretrained=False, checkpoint_path='', scriptable=No
     if not is_model(model_name):
         raise RuntimeError(f'Unknown model ({model_name}); known: {list_models()}')
     kwargs = {k: v for k, v in kwargs.items() if v is not None}
+    if model_name in _unsupported:   # say so at creation time, not at the first training step
+        warnings.warn(f'{model_name}: {_unsupported[model_name]}', stacklevel=2)
     model = _entrypoints[model_name](pretrained=pretrained, **kwargs)
     if checkpoint_path:
         from .checkpoint import load_checkpoint

@@ -61,15 +61,18 @@ def test_descriptor_structs_match_header_field_order():
 
 def test_registry_and_factories():
     import imagenet_models_amd as A
-    names = A.list_models()
+    names = A.list_models(include_unsupported=True)
+    assert 'ga_convnext_tiny_688' not in A.list_models() and 'ga_convnext_tiny_768' in A.list_models()
     for n in ('ga_convnext_tiny_688', 'ga_convnext_tiny_768', 'ga_convnext_small_688', 'ga_convnext_small_768',
               'ga_convnext_base_976', 'ga_convnext_base_1024'):
         assert n in names and A.is_model(n)
     # timm create_model drops None kwargs (GA/train.py:407-420 passes many that are None)
-    m = A.create_model('ga_convnext_tiny_688', pretrained=False, num_classes=10, drop_rate=None, drop_path_rate=0.1,
-                       drop_block_rate=None, global_pool=None, bn_momentum=None, bn_eps=None, scriptable=None)
+    with pytest.warns(UserWarning, match='refuses'):
+        m = A.create_model('ga_convnext_tiny_688', pretrained=False, num_classes=10, drop_rate=None, drop_path_rate=0.1,
+                           drop_block_rate=None, global_pool=None, bn_momentum=None, bn_eps=None, scriptable=None)
     assert m.num_classes == 10 and m.cfg['dims'][-1] == 688 and m.cfg['dim_embed'] == 168
-    assert sum(p.numel() for p in A.create_model('ga_convnext_tiny_688').parameters()) == 47821324
+    with pytest.warns(UserWarning):
+        assert sum(p.numel() for p in A.create_model('ga_convnext_tiny_688').parameters()) == 47821324
     with pytest.raises(RuntimeError):
         A.create_model('ga_convnext_tiny_768', pretrained=True)
     with pytest.raises(RuntimeError):
