@@ -116,16 +116,25 @@ class CSWinEngine(GAEngine):
         C, reso, mg = mod.dim, mod.reso, mod.mlp_groups
         HW = reso * reso
         dp1, dp2 = self.dp_scale.get(pre + '#1'), self.dp_scale.get(pre + '#2')
+        # trunk blocks: the weight-gradient launches go to the plan's asynchronous lane (nothing on the dgrad chain reads their
+        # results); two sets of the transients they read + three rotating dx buffers (caller), so this block only waits for the
+        # asynchronous launches of the block before the previous one (same scheme as GAEngine._block_bwd)
+        side = self.async_wgrad and Bk.lane == 0
+        par = ''
+        if side:
+            self._bwd_seq += 1
+            par = str(self._bwd_seq & 1)
+            Bk.join_async(f'blk{self._bwd_seq - 2}')
         dyz = dy
         if dp2 is not None:
-            dyz = self.tmp('dyz', (M, C))
+            dyz = self.tmp('dyz' + par, (M, C))
             Bk.rowscale(dy, dp2, dyz, M * C, HW * C, dt, label=pre + 'dp2')
-        dx1 = self.tmp('dx1', (M, C))
+        dx1 = self.tmp('dx1' + par, (M, C))
         if mg == 1:
             with self._wlane():
                 Bk.wgrad(dyz, st['a'], self.grad(pre + 'mlp.fc2.weight'), M, C, 4 * C, dt, dbias=self.grad(pre + 'mlp.fc2.bias'),
                          label=pre + 'wg2')
-            dh = self.tmp('dh', (M, 4 * C))
+            dh = self.tmp('dh' + par, (M, 4 * C))
             gb1 = self.gbuf((4 * C,))
             Bk.gemm(dyz, W[pre + 'mlp.fc2.weight.T'], dh, M, 4 * C, C, dt, ldb=pad8(C), H=st['g'], ldh=4 * C, h_is_deriv=True,
                     colsum=gb1, label=pre + 'dg2')
@@ -147,14 +156,14 @@ class CSWinEngine(GAEngine):
         # --- attention branch
         dx1z = dx1
         if dp1 is not None:
-            dx1z = self.tmp('dx1z', (M, C))
+            dx1z = self.tmp('dx1z' + par, (M, C))
             Bk.rowscale(dx1, dp1, dx1z, M * C, HW * C, dt, label=pre + 'dp1')
         with self._wlane():
             Bk.wgrad(dx1z, st['att'], self.grad(pre + 'proj.weight'), M, C, C, dt, dbias=self.grad(pre + 'proj.bias'),
                      label=pre + 'proj.wg')
-        datt = self.tmp('datt', (M, C))
+        datt = self.tmp('datt' + par, (M, C))
         Bk.gemm(dx1z, W[pre + 'proj.weight.T'], datt, M, C, C, dt, ldb=pad8(C), label=pre + 'proj.dg')
-        dqkv = self.tmp('dqkv', (M, 3 * C))
+        dqkv = self.tmp('dqkv' + par, (M, 3 * C))
         Bk.cswin_attn_bwd(st['desc'], datt, dqkv, label=pre + 'attnb')
         with self._wlane():
             Bk.cswin_lepe_wgrad(st['desc'], datt, [(self.grad(pre + f'attns.{i}.get_v.weight'), self.grad(pre + f'attns.{i}.get_v.bias'))
@@ -169,6 +178,8 @@ class CSWinEngine(GAEngine):
         gq = self.tmp('g', (M, C))
         Bk.gemm(dqkv, W[pre + 'qkv.weight.T'], gq, M, C, 3 * C, dt, ldb=pad8(3 * C), label=pre + 'qkv.dg')
         Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b')
+        if side:
+            Bk.async_mark(f'blk{self._bwd_seq}')
 
     # ------------------------------------------------------------------------------------------
     # 3x3 / stride-2 conv (+bias) -> LayerNorm   (Merge_Block; the last stem conv without bias)
@@ -218,7 +229,6 @@ class CSWinEngine(GAEngine):
     def _build(self):
         cfg, m = self.cfg, self.m
         B, T, F, dt, P = self.B, self.training, self.fwd, self.dt, self.P
-        self.async_wgrad = False      # first version: every launch of the trunk in stream order
         e, d, dep = cfg['embed_dim'], cfg['dims'], cfg['depth']
         img = self.img
         if T:
@@ -299,6 +309,8 @@ class CSWinEngine(GAEngine):
         # ---------------- backward ----------------
         if T:
             self._build_backward(feats, taps, x4, M4, ctot, cat)
+            if self.async_wgrad:
+                self.bwd.join_async()
             self.bwd.flush('end.')
         self.prep.flush('prep.')
 
@@ -375,6 +387,8 @@ class CSWinEngine(GAEngine):
             Bk.gemm(dc5, W[lp + 'conv.weight.T'], dcat, M4, ctot, cur, dt, ldb=pad8(cur), label=lp + 'dg')
         else:
             self._bottleneck_bwd(dx4, dcat)
+        if self.async_wgrad:
+            Bk.join_async()
         Bk.flush('heads.')
         Bk.mark('heads')      # every gradient of stage5 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
@@ -391,11 +405,13 @@ class CSWinEngine(GAEngine):
         for si in (3, 2, 1, 0):
             reso = stages[si][0].reso
             Mi = B * reso * reso
-            pp = [self.tmp(f'dxA{si}', (Mi, d[si])), self.tmp(f'dxB{si}', (Mi, d[si]))]
+            pp = [self.tmp(f'dxA{si}', (Mi, d[si])), self.tmp(f'dxB{si}', (Mi, d[si])), self.tmp(f'dxC{si}', (Mi, d[si]))]
+            turn = 0
             for j in reversed(range(dep[si])):
                 if si == 2 and j in d_taps:
                     Bk.affine_act(dy, None, None, d_taps[j], dy, Mi, d[si], False, dt, label=f'tap.add.{j}')
-                dx = pp[0] if dy is not pp[0] else pp[1]
+                dx = pp[turn % 3]          # not this block's dy nor the previous block's (still read by its asynchronous wgrads)
+                turn += 1
                 self._cs_block_bwd(f'stage{si + 1}.{j}.', dy, dx)
                 dy = dx
             if si > 0:
@@ -403,6 +419,8 @@ class CSWinEngine(GAEngine):
                 dprev = self.tmp(f'dprev{si}', (B * Hp * Hp, d[si - 1]))
                 self._conv3s2_ln_bwd(self.merges[si], dy, dprev, seed=seed[si - 1])
                 dy = dprev
+            if self.async_wgrad:
+                Bk.join_async()
             Bk.flush(f'stage{si + 1}.')
             Bk.mark(f'stage{si}')   # gradients of trunk stage si+1 (incl. its merge) are final
         # ---------------- deep stem ----------------
@@ -422,13 +440,13 @@ class CSWinEngine(GAEngine):
         da0 = da1   # da1 is dead after the LayerNorm+GELU backward above
         Bk.gemm(dc1, W[sp + '5.weight.T'], da0, M1, e, 9 * e, dt, a_kind=A_CONV3, a_dims=(H1, H1, e), ldb=pad8(9 * e),
                 label=sp + 'conv1.dg')
-        dc0 = dc1
+        dc0 = self.tmp('stem.dc0', (M1, e))   # dc1 is still read by the asynchronous conv1 weight gradient
         Bk.layernorm_gelu_bwd(da0, S['c0'], S['m0'], S['r0'], P[sp + '2.weight'], P[sp + '2.bias'], dc0, self.grad(sp + '2.weight'),
                               self.grad(sp + '2.bias'), M1, e, dt, label=sp + 'ln0b')
         G0 = self.gbuf((e, 72))
         with self._wlane():
             Bk.wgrad(dc0, self.x8, G0, M1, e, 72, dt, x_kind=A_CONV3S2, x_dims=(self.img, self.img, 8), label=sp + 'conv0.wg')
-        Bk.convw_unpack_grad(G0, self.grad(sp + '0.weight'), e, 3, 9, 8, 72, label=sp + 'conv0.unf')
+            Bk.convw_unpack_grad(G0, self.grad(sp + '0.weight'), e, 3, 9, 8, 72, label=sp + 'conv0.unf')   # same lane: after the wgrad
 
     # ------------------------------------------------------------------------------------------
     def set_input(self, x):
