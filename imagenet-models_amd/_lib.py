@@ -115,7 +115,9 @@ _SIGS = {
     'ga_weight_unfold_batch': ([vp, i32, vp], i32),
     'ga_small_batch': ([vp, i32, vp], i32),
     'ga_cswin_attn_fwd': ([C.POINTER(CswinAttnDesc), vp], i32),
-    'ga_cswin_attn_bwd': ([C.POINTER(CswinAttnDesc), vp, vp, vp], i32),
+    'ga_cswin_attn_bwd_workspace': ([C.POINTER(CswinAttnDesc)], C.c_size_t),
+    'ga_cswin_attn_bwd': ([C.POINTER(CswinAttnDesc), vp, vp, vp, C.c_size_t, vp], i32),
+    'ga_cswin_lepe_wgrad_reduce': ([C.POINTER(CswinAttnDesc), vp, vp, vp, vp, vp, vp], i32),
     'ga_cswin_lepe_wgrad': ([C.POINTER(CswinAttnDesc), vp, vp, vp, vp, vp, vp], i32),
     'ga_layernorm_gelu_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_gelu_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp], i32),

@@ -366,6 +366,81 @@ __device__ __forceinline__ void store_tile(unsigned char* stage, const f32x4_t (
     if (t < g.N) *reinterpret_cast<uint4*>(dst + tok_row(d, g, t) * ld + c * 8) = v;
 }
 
+
+// LePE of all the window's tokens by the whole workgroup: lep[t][32] fp32 = bias[c] + sum_taps w[c][tap] * X[t + tap][c]
+// (TR: the transpose, X[t - tap], no bias).  Thread = (token t = tid >> 2 (+64..), 8-channel chunk tid & 3): nine 16-byte
+// LDS reads per item instead of 72 two-byte reads per accumulator lane.
+template <bool TR>
+__device__ __forceinline__ void lepe_pass(float* lep, const unsigned char* Xt, const float* wp, const float* bp, const WinGeom& g) {
+    const int c8 = threadIdx.x & 3;
+    float w[8][9], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        b[e] = TR ? 0.f : bp[c8 * 8 + e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w[e][k] = wp[(c8 * 8 + e) * 9 + k];
+    }
+    for (int t = threadIdx.x >> 2; t < g.N; t += 64) {
+        const int ty = t / g.Ws, tx = t - ty * g.Ws;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = b[e];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = TR ? ty - dy : ty + dy, xx = TR ? tx - dx : tx + dx;
+                if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
+                    const uint4 u = *reinterpret_cast<const uint4*>(Xt + tile_off(yy * g.Ws + xx, c8));
+                    float x[8];
+                    unpack8(u, x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a[e] = fmaf(w[e][(dy + 1) * 3 + dx + 1], x[e], a[e]);
+                }
+            }
+        float4* o = reinterpret_cast<float4*>(lep + t * 32 + c8 * 8);
+        o[0] = make_float4(a[0], a[1], a[2], a[3]);
+        o[1] = make_float4(a[4], a[5], a[6], a[7]);
+    }
+}
+
+// LePE weight-gradient partial of one (window, head): part[ch][k] = sum_t dO[t][ch] * V[t + tap_k][ch] (k < 9), sum_t dO[t][ch]
+// (k = 9), written to ws[item][32][10] with plain stores (ga_cswin_lepe_wgrad_reduce sums the items of each head).
+// `scratch` >= 8 * 320 floats of LDS; ends with a barrier.
+__device__ __forceinline__ void lepe_wgrad_partial(float* scratch, const unsigned char* Gt, const unsigned char* Vt, const WinGeom& g,
+                                                   float* ws_item) {
+    const bf16_t* G16 = reinterpret_cast<const bf16_t*>(Gt);
+    const bf16_t* V16 = reinterpret_cast<const bf16_t*>(Vt);
+    const int ch = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    float acc[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
+    for (int t = tg; t < g.N; t += 8) {
+        const float gv = bf2f(G16[(tile_off(t, ch >> 3) >> 1) + (ch & 7)]);
+        acc[9] += gv;
+        const int ty = t / g.Ws, tx = t - ty * g.Ws;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = ty + dy, xx = tx + dx;
+                if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws)
+                    acc[(dy + 1) * 3 + dx + 1] =
+                        fmaf(gv, bf2f(V16[(tile_off(yy * g.Ws + xx, ch >> 3) >> 1) + (ch & 7)]), acc[(dy + 1) * 3 + dx + 1]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) scratch[tg * 320 + ch * 10 + k] = acc[k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 320; i += 256) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_ += scratch[q * 320 + i];
+        ws_item[i] = s_;
+    }
+    __syncthreads();
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_desc d, const int nwg) {
     using A = AT<NT>;
@@ -374,27 +449,16 @@ __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_d
     unsigned char* Kt = Qt + A::TILE;
     unsigned char* Vt = Kt + A::TILE;
     unsigned char* Stage = Vt + A::TILE;              // 4 x 1 KiB
+    float* Lep = reinterpret_cast<float*>(Stage + 4096);   // [KP][32]
     const WinGeom g = win_geom(d, xcd_walk(blockIdx.x, nwg));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + g.ch;
     load_tile<NT>(Qt, qkv, d.ldq, d, g);
     load_tile<NT>(Kt, qkv + d.C, d.ldq, d, g);
     load_tile<NT>(Vt, qkv + 2 * d.C, d.ldq, d, g);
-    // LePE taps of this lane's two channels (16*dt + lane&15)
-    float w[2][9], bias[2];
-    {
-        const float* wp = d.lepe_w[g.branch] + (long)g.chb * 9;
-        const float* bp = d.lepe_b[g.branch] + g.chb;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const int c = 16 * dt + (lane & 15);
-            bias[dt] = bp[c];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[dt][k] = wp[c * 9 + k];
-        }
-    }
     __syncthreads();
-    const bf16_t* V16 = reinterpret_cast<const bf16_t*>(Vt);
+    lepe_pass<false>(Lep, Vt, d.lepe_w[g.branch] + (long)g.chb * 9, d.lepe_b[g.branch] + g.chb, g);
+    __syncthreads();
     for (int qt = wave; qt < NT; qt += 4) {
         const int q0 = 16 * qt;
         if (q0 >= g.N) break;
@@ -415,24 +479,8 @@ __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = q0 + 4 * (lane >> 4) + r;
-            if (t < g.N) {
-                const int ty = t / g.Ws, tx = t - ty * g.Ws;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    float a = bias[dt];
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int yy = ty + dy, xx = tx + dx;
-                            if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
-                                const int rr = yy * g.Ws + xx, ch = 16 * dt + (lane & 15);
-                                a = fmaf(w[dt][(dy + 1) * 3 + dx + 1], bf2f(V16[(tile_off(rr, ch >> 3) >> 1) + (ch & 7)]), a);
-                            }
-                        }
-                    o[dt][r] += a;
-                }
-            }
+            for (int dt = 0; dt < 2; ++dt) o[dt][r] += Lep[t * 32 + 16 * dt + (lane & 15)];
         }
         store_tile(Stage + wave * 1024, o, q0, reinterpret_cast<bf16_t*>(d.out) + g.ch, d.ldo, d, g, lane);
     }
@@ -443,7 +491,7 @@ __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_d
 // [query][key] layout, whose accumulators are directly the A operands of dV += P^T.dO and dK += dS^T.Q.
 template <int NT>
 __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_desc d, const void* dout_, void* dqkv_,
-                                                           const int nwg) {
+                                                           float* lepe_ws, const int nwg) {
     using A = AT<NT>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Qt = smem;
@@ -453,7 +501,9 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     unsigned char* Stage = Gt + A::TILE;              // 4 x 1 KiB
     float* lse = reinterpret_cast<float*>(Stage + 4096);   // [KP]
     float* dlt = lse + A::KP;                              // [KP]
-    const WinGeom g = win_geom(d, xcd_walk(blockIdx.x, nwg));
+    float* Lep = dlt + A::KP;                              // [max(KP, 80)][32]: LePE^T(dO); before that the wgrad scratch
+    const int item = xcd_walk(blockIdx.x, nwg);
+    const WinGeom g = win_geom(d, item);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + g.ch;
     bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + g.ch;
@@ -463,6 +513,8 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     load_tile<NT>(Gt, reinterpret_cast<const bf16_t*>(dout_) + g.ch, d.ldo, d, g);
     for (int i = threadIdx.x; i < 2 * A::KP; i += 256) lse[i] = 0.f;
     __syncthreads();
+    if (lepe_ws) lepe_wgrad_partial(Lep, Gt, Vt, g, lepe_ws + (long)item * 320);
+    lepe_pass<true>(Lep, Gt, d.lepe_w[g.branch] + (long)g.chb * 9, nullptr, g);    // read by phase B, after the barrier below
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     // ---------------- phase A ----------------
     for (int qt = wave; qt < NT; qt += 4) {
@@ -506,15 +558,6 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     }
     __syncthreads();
     // ---------------- phase B ----------------
-    float w[2][9];
-    {
-        const float* wp = d.lepe_w[g.branch] + (long)g.chb * 9;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) w[dt][k] = wp[(16 * dt + (lane & 15)) * 9 + k];
-    }
-    const bf16_t* G16 = reinterpret_cast<const bf16_t*>(Gt);
     for (int kt = wave; kt < NT; kt += 4) {
         const int k0 = 16 * kt;
         if (k0 >= g.N) break;
@@ -556,24 +599,10 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = k0 + 4 * (lane >> 4) + r;
-            if (t < g.N) {
-                const int ty = t / g.Ws, tx = t - ty * g.Ws;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-                        for (int dx = -1; dx <= 1; ++dx) {
-                            const int yy = ty - dy, xx = tx - dx;
-                            if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
-                                const int rr = yy * g.Ws + xx, ch = 16 * dt + (lane & 15);
-                                a = fmaf(w[dt][(dy + 1) * 3 + dx + 1], bf2f(G16[(tile_off(rr, ch >> 3) >> 1) + (ch & 7)]), a);
-                            }
-                        }
-                    dv[dt][r] += a;
-                    dk[dt][r] *= d.scale;
-                }
+            for (int dt = 0; dt < 2; ++dt) {
+                dv[dt][r] += Lep[t * 32 + 16 * dt + (lane & 15)];
+                dk[dt][r] *= d.scale;
             }
         }
         store_tile(Stage + wave * 1024, dk, k0, dqkv + d.C, d.ldq, d, g, lane);
@@ -633,6 +662,28 @@ __global__ __launch_bounds__(256) void lepe_wgrad_kernel(const ga_cswin_attn_des
         for (int r = 0; r < rpb; ++r) s += red[r * C8 * 80 + i];
         const int c8 = i / 80, k = (i % 80) / 8, e = i % 8;
         const int ch = c8 * 8 + e, br = ch / cb, chb = ch - br * cb;
+        float* dw = br ? dw1 : dw0;
+        float* db = br ? db1 : db0;
+        if (k < 9) atomicAdd(dw + (long)chb * 9 + k, s);
+        else atomicAdd(db + chb, s);
+    }
+}
+
+// sum of the per-(window, head) partials the fused backward wrote: ws[(t * heads + head)][32][10] over t = (image, window).
+// grid (heads, 5, splits); thread = one of 64 outputs x 4 interleaved partial sums; fp32 atomics across the splits.
+__global__ __launch_bounds__(256) void lepe_wgrad_reduce_kernel(const float* __restrict__ ws, int T, int heads, int hpb,
+                                                                float* dw0, float* db0, float* dw1, float* db1) {
+    __shared__ float red[256];
+    const int head = blockIdx.x, i = blockIdx.y * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+    const int per = (T + gridDim.z - 1) / gridDim.z;
+    const int t0 = blockIdx.z * per, t1 = min(T, t0 + per);
+    float s = 0.f;
+    for (int t = t0 + part; t < t1; t += 4) s += ws[((long)t * heads + head) * 320 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        const int br = head / hpb, chb = (head - br * hpb) * 32 + i / 10, k = i % 10;
         float* dw = br ? dw1 : dw0;
         float* db = br ? db1 : db0;
         if (k < 9) atomicAdd(dw + (long)chb * 9 + k, s);
@@ -848,10 +899,10 @@ extern "C" int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream
     for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
     if (use_mfma(d)) {
         if (nmax <= 64) {
-            const size_t lds = 3 * AT<4>::TILE + 4096;
+            const size_t lds = 3 * AT<4>::TILE + 4096 + AT<4>::KP * 128;
             hipLaunchKernelGGL(cswin_attn_fwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, items);
         } else {
-            const size_t lds = 3 * AT<7>::TILE + 4096;
+            const size_t lds = 3 * AT<7>::TILE + 4096 + AT<7>::KP * 128;
             hipLaunchKernelGGL(cswin_attn_fwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, items);
         }
         return ga_check_launch("ga_cswin_attn_fwd");
@@ -871,8 +922,18 @@ extern "C" int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream
     return ga_check_launch("ga_cswin_attn_fwd");
 }
 
-extern "C" int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, ga_stream_t stream) {
+extern "C" size_t ga_cswin_attn_bwd_workspace(const ga_cswin_attn_desc* d) {
+    if (!d || check_desc(d, "ga_cswin_attn_bwd_workspace") || !use_mfma(d)) return 0;
+    const size_t nwin = (size_t)(d->reso / d->Hs[0]) * (d->reso / d->Ws[0]);
+    return (size_t)d->B * nwin * d->heads * 320 * sizeof(float);
+}
+
+extern "C" int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, void* lepe_ws, size_t ws_bytes,
+                                 ga_stream_t stream) {
     if (int rc = check_desc(d, "ga_cswin_attn_bwd")) return rc;
+    GA_REQUIRE(!lepe_ws || (use_mfma(d) && ws_bytes >= ga_cswin_attn_bwd_workspace(d) && aligned16(lepe_ws)),
+               "ga_cswin_attn_bwd: LePE workspace of %zu B given, ga_cswin_attn_bwd_workspace() asks for %zu B (0 = this shape does "
+               "not take one: use ga_cswin_lepe_wgrad)", ws_bytes, ga_cswin_attn_bwd_workspace(d));
     GA_REQUIRE(dout && dqkv && aligned16(dout) && aligned16(dqkv) && d->ldo >= d->C && d->ldo % (d->dtype == GA_BF16 ? 8 : 4) == 0,
                "ga_cswin_attn_bwd: dout / dqkv alignment");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -883,11 +944,11 @@ extern "C" int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, 
     for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
     if (use_mfma(d)) {
         if (nmax <= 64) {
-            const size_t lds = 4 * AT<4>::TILE + 4096 + 2 * AT<4>::KP * sizeof(float);
-            hipLaunchKernelGGL(cswin_attn_bwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, items);
+            const size_t lds = 4 * AT<4>::TILE + 4096 + 2 * AT<4>::KP * sizeof(float) + 80 * 128;
+            hipLaunchKernelGGL(cswin_attn_bwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, (float*)lepe_ws, items);
         } else {
-            const size_t lds = 4 * AT<7>::TILE + 4096 + 2 * AT<7>::KP * sizeof(float);
-            hipLaunchKernelGGL(cswin_attn_bwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, items);
+            const size_t lds = 4 * AT<7>::TILE + 4096 + 2 * AT<7>::KP * sizeof(float) + AT<7>::KP * 128;
+            hipLaunchKernelGGL(cswin_attn_bwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, (float*)lepe_ws, items);
         }
         return ga_check_launch("ga_cswin_attn_bwd");
     }
@@ -924,6 +985,18 @@ extern "C" int ga_cswin_lepe_wgrad(const ga_cswin_attn_desc* d, const void* dout
         hipLaunchKernelGGL(lepe_wgrad_kernel<float>, dim3(grid), dim3(256), lds, s, *d, dout, dw0, db0, dw1, db1);
     }
     return ga_check_launch("ga_cswin_lepe_wgrad");
+}
+
+extern "C" int ga_cswin_lepe_wgrad_reduce(const ga_cswin_attn_desc* d, const void* lepe_ws, float* dw0, float* db0, float* dw1,
+                                          float* db1, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_cswin_lepe_wgrad_reduce")) return rc;
+    GA_REQUIRE(lepe_ws && dw0 && db0 && (d->nbranch == 1 || (dw1 && db1)), "ga_cswin_lepe_wgrad_reduce: null pointer");
+    GA_REQUIRE(use_mfma(d), "ga_cswin_lepe_wgrad_reduce: this shape has no fused partials (ga_cswin_attn_bwd_workspace() == 0)");
+    const int T = d->B * (d->reso / d->Hs[0]) * (d->reso / d->Ws[0]);
+    const int splits = std::max(1, std::min(64, T / 256));
+    hipLaunchKernelGGL(lepe_wgrad_reduce_kernel, dim3(d->heads, 5, splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float*>(lepe_ws), T, d->heads, d->heads / d->nbranch, dw0, db0, dw1, db1);
+    return ga_check_launch("ga_cswin_lepe_wgrad_reduce");
 }
 
 extern "C" int ga_nchw3_to_nhwc8(const float* x, void* y, int B, int H, int W, int dtype, ga_stream_t stream) {

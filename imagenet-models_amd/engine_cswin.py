@@ -17,6 +17,7 @@ a = gelu(h), g = gelu'(h), the block output.
 """
 import torch
 
+from . import ops
 from .engine import GAEngine, pad8
 from .ops import A_CONV3, A_CONV3S2, A_NEIGH2, ACT_GELU, C_UNPATCH2
 
@@ -77,6 +78,7 @@ class CSWinEngine(GAEngine):
         st['att'] = self.blk_act(pre + 'att', (M, C))
         lepe = [(P[pre + f'attns.{i}.get_v.weight'], P[pre + f'attns.{i}.get_v.bias']) for i in range(mod.branch_num)]
         st['desc'] = F.cswin_desc(st['qkv'], st['att'], B, reso, C, heads, mod.stripes(), lepe, (C // heads) ** -0.5, dt)
+        self._lepe_ws_elems = max(getattr(self, '_lepe_ws_elems', 0), ops.cswin_attn_bwd_workspace(st['desc']) // 4)
         F.cswin_attn_fwd(st['desc'], label=pre + 'attn')
         Wp = self._w_plain(pre + 'proj.weight', C, C, 1, 1)
         # x1 is re-read by the affine LayerNorm backward of the grouped-MLP form only
@@ -164,10 +166,18 @@ class CSWinEngine(GAEngine):
         datt = self.tmp('datt' + par, (M, C))
         Bk.gemm(dx1z, W[pre + 'proj.weight.T'], datt, M, C, C, dt, ldb=pad8(C), label=pre + 'proj.dg')
         dqkv = self.tmp('dqkv' + par, (M, 3 * C))
-        Bk.cswin_attn_bwd(st['desc'], datt, dqkv, label=pre + 'attnb')
-        with self._wlane():
-            Bk.cswin_lepe_wgrad(st['desc'], datt, [(self.grad(pre + f'attns.{i}.get_v.weight'), self.grad(pre + f'attns.{i}.get_v.bias'))
-                                                   for i in range(mod.branch_num)], label=pre + 'lepe.wg')
+        lepe_grads = [(self.grad(pre + f'attns.{i}.get_v.weight'), self.grad(pre + f'attns.{i}.get_v.bias'))
+                      for i in range(mod.branch_num)]
+        need = ops.cswin_attn_bwd_workspace(st['desc'])
+        if need:    # the MFMA kernel leaves the LePE weight-gradient partials of its LDS tiles; the reduce follows in stream order
+            lws = self.tmp('lepe_ws', (self._lepe_ws_elems,), torch.float32)
+            assert need <= lws.numel() * 4
+            Bk.cswin_attn_bwd(st['desc'], datt, dqkv, lepe_ws=lws, label=pre + 'attnb')
+            Bk.cswin_lepe_wgrad_reduce(st['desc'], lws, lepe_grads, label=pre + 'lepe.red')
+        else:
+            Bk.cswin_attn_bwd(st['desc'], datt, dqkv, label=pre + 'attnb')
+            with self._wlane():
+                Bk.cswin_lepe_wgrad(st['desc'], datt, lepe_grads, label=pre + 'lepe.wg')
         Gq, gbq = self.gbuf((3 * C, C)), self.gbuf((3 * C,))
         with self._wlane():
             Bk.wgrad(dqkv, st['xn1'], Gq, M, 3 * C, C, dt, dbias=gbq, label=pre + 'qkv.wg')

@@ -525,8 +525,16 @@ class Plan:
     def cswin_attn_fwd(self, d, label=None):
         self._add('ga_cswin_attn_fwd', (C.byref(d),), label, keep=(d,))
 
-    def cswin_attn_bwd(self, d, dout, dqkv, label=None):
-        self._add('ga_cswin_attn_bwd', (C.byref(d), _ptr(dout), _ptr(dqkv)), label, keep=(d, dout, dqkv))
+    def cswin_attn_bwd(self, d, dout, dqkv, lepe_ws=None, label=None):
+        """lepe_ws: fp32 buffer of cswin_attn_bwd_workspace(d) bytes -> the kernel also leaves the LePE weight-gradient partials
+        there (cswin_lepe_wgrad_reduce adds them up); None: use cswin_lepe_wgrad"""
+        nbytes = 0 if lepe_ws is None else lepe_ws.numel() * lepe_ws.element_size()
+        self._add('ga_cswin_attn_bwd', (C.byref(d), _ptr(dout), _ptr(dqkv), _ptr(lepe_ws), nbytes), label, keep=(d, dout, dqkv, lepe_ws))
+
+    def cswin_lepe_wgrad_reduce(self, d, lepe_ws, grads, label=None):
+        g = list(grads) + [(None, None)] * (2 - len(grads))
+        self._add('ga_cswin_lepe_wgrad_reduce', (C.byref(d), _ptr(lepe_ws), _ptr(g[0][0]), _ptr(g[0][1]), _ptr(g[1][0]), _ptr(g[1][1])),
+                  label, keep=(d, lepe_ws) + tuple(t for pair in grads for t in pair))
 
     def cswin_lepe_wgrad(self, d, dout, grads, label=None):
         """grads = [(dw, db)] per branch (fp32, accumulated into)"""
@@ -667,6 +675,11 @@ class Plan:
     def zero(self, t, label=None):
         """memset a persistent buffer (hipMemsetAsync on the plan's stream)."""
         self._add('ga_memset', (_ptr(t), 0, t.numel() * t.element_size()), label or 'zero', keep=(t,))
+
+
+def cswin_attn_bwd_workspace(d):
+    """bytes of the LePE partial buffer Plan.cswin_attn_bwd takes for this descriptor (0: generic form, no fused partials)"""
+    return int(L.load().ga_cswin_attn_bwd_workspace(C.byref(d)))
 
 
 def zero_(t):

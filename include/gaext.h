@@ -352,8 +352,11 @@ int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float limit, int m
  *   out[b, t, ch] = softmax_j((q_t * scale) . k_j) v_j + conv3x3_depthwise(v)(t)   over the tokens j of t's stripe,
  *   the 3x3 (lepe_w[i]: fp32 [C/nbranch][9] = get_v.weight, lepe_b[i]) zero padded at the STRIPE border.
  *   head_dim in {8, 16, 32}; Hs*Ws <= 128.  bf16 with head_dim 32 runs on MFMA, everything else on a generic fp32 form.
- * bwd: dqkv [B*L][ldq] = d(q | k | v) from dout [B*L][ldo]  (dv includes the LePE transpose);
- * lepe_wgrad: dw_i[ch][tap] += sum dout * shifted v, db_i[ch] += sum dout  (fp32 atomics). */
+ * bwd: dqkv [B*L][ldq] = d(q | k | v) from dout [B*L][ldo]  (dv includes the LePE transpose).  With a caller-owned `lepe_ws` of
+ *   ga_cswin_attn_bwd_workspace(d) bytes (16-byte aligned; 0 = this shape runs the generic form, pass NULL) the kernel also
+ *   leaves the per-(window, head) partial LePE weight gradients there from the tiles it already holds in LDS;
+ *   ga_cswin_lepe_wgrad_reduce then adds their sum into dw_i / db_i.  The buffer may be reused once the reduce has run.
+ * lepe_wgrad: the unfused form of the same (any shape): dw_i[ch][tap] += sum dout * shifted v, db_i[ch] += sum dout  (fp32 atomics). */
 typedef struct {
     int B, reso, C, heads, nbranch;
     int Hs[2], Ws[2];
@@ -365,7 +368,10 @@ typedef struct {
     void* out; int64_t ldo;
 } ga_cswin_attn_desc;
 int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream);
-int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, ga_stream_t stream);
+size_t ga_cswin_attn_bwd_workspace(const ga_cswin_attn_desc* d);
+int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, void* dqkv, void* lepe_ws, size_t ws_bytes, ga_stream_t stream);
+int ga_cswin_lepe_wgrad_reduce(const ga_cswin_attn_desc* d, const void* lepe_ws, float* dw0, float* db0, float* dw1, float* db1,
+                               ga_stream_t stream);
 int ga_cswin_lepe_wgrad(const ga_cswin_attn_desc* d, const void* dout, float* dw0, float* db0, float* dw1, float* db1,
                         ga_stream_t stream);
 /* deep-stem helpers (ga_cswin.py:463-477):

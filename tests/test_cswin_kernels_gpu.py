@@ -73,8 +73,21 @@ def _attn_case(dt, B, reso, C, heads, stripes, seed, force_simple=False):
     p = ops.Plan(eager=True)
     d = p.cswin_desc(qkv_g, out, B, reso, C, heads, stripes, list(zip(lwg, lbg)), hd ** -0.5, ops.ga_dtype(dt))
     p.cswin_attn_fwd(d)
-    p.cswin_attn_bwd(d, do_g, dqkv)
-    p.cswin_lepe_wgrad(d, do_g, list(zip(dw, db)))
+    need = ops.cswin_attn_bwd_workspace(d)
+    if need:                                             # MFMA form: the LePE weight gradient comes out of the same kernel
+        lws = torch.empty(need // 4, device='cuda')
+        p.cswin_attn_bwd(d, do_g, dqkv, lepe_ws=lws)
+        p.cswin_lepe_wgrad_reduce(d, lws, list(zip(dw, db)))
+        dw2 = [torch.zeros_like(w) for w in lwg]
+        db2 = [torch.zeros_like(b) for b in lbg]
+        p.cswin_lepe_wgrad(d, do_g, list(zip(dw2, db2)))  # ... and must agree with the unfused kernel
+        torch.cuda.synchronize()
+        for i in range(nb):
+            assert_close(dw[i], dw2[i].cpu(), 1e-3, f'fused vs unfused lepe dw{i}')
+            assert_close(db[i], db2[i].cpu(), 1e-3, f'fused vs unfused lepe db{i}')
+    else:
+        p.cswin_attn_bwd(d, do_g, dqkv)
+        p.cswin_lepe_wgrad(d, do_g, list(zip(dw, db)))
     torch.cuda.synchronize()
     t = tol(dt)
     assert_close(out, ref, t, 'attn out')
