@@ -72,6 +72,18 @@ class CswinAttnDesc(C.Structure):
                 ('scale', f32), ('dtype', i32), ('qkv', vp), ('ldq', i64), ('out', vp), ('ldo', i64)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [('X', vp), ('ldx', i64), ('W1', vp), ('ldw1', i64), ('b1', vp), ('W2', vp), ('ldw2', i64), ('b2', vp),
+                ('R', vp), ('ldr', i64), ('rowscale', vp), ('rows_per_scale', i32), ('Y', vp), ('ldy', i64),
+                ('M', i64), ('C', i32), ('H', i32), ('dtype', i32)]
+
+
+class MlpBwdDesc(C.Structure):
+    _fields_ = [('X', vp), ('ldx', i64), ('DY', vp), ('lddy', i64), ('W1', vp), ('ldw1', i64), ('b1', vp),
+                ('W2T', vp), ('ldw2t', i64), ('W1T', vp), ('ldw1t', i64), ('A', vp), ('lda', i64), ('DH', vp), ('lddh', i64),
+                ('DX', vp), ('lddx', i64), ('M', i64), ('C', i32), ('H', i32), ('dtype', i32)]
+
+
 _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
@@ -139,6 +151,9 @@ _SIGS = {
     'ga_copy2d': ([vp, i64, vp, i64, i64, i32, i32, i32, vp], i32),
     'ga_dropout_mask_sample': ([vp, i64, f32, C.c_uint64, vp, vp], i32),
     'ga_drop_path_sample': ([vp, vp, i32, i32, C.c_uint64, vp, vp], i32),
+    'ga_mlp_supported': ([i32, i32, i32], i32),
+    'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
+    'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),
     'ga_memset': ([vp, i32, C.c_size_t, vp], i32),
     'ga_transpose_f32': ([vp, vp, i32, i32, i32, vp], i32),
     'ga_axpy_f32': ([vp, vp, f32, i64, vp], i32),

@@ -335,6 +335,27 @@ class Plan:
         d.colsum, d.colsumsq, d.strideCol = _ptr(colsum), _ptr(colsumsq), strideCol
         self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq, C2))
 
+    def mlp_fwd(self, X, W1, b1, W2, b2, Y, M, Cdim, dtype, ldw1=None, ldw2=None, R=None, rowscale=None, rows_per_scale=1, label=None):
+        """fused fc1 -> GELU -> fc2 (+ DropPath row scale + residual): Y = R + rowscale * (gelu(X W1^T + b1) W2^T + b2)"""
+        d = L.MlpDesc()
+        H = 4 * Cdim
+        d.X, d.ldx, d.W1, d.ldw1, d.b1 = _ptr(X), Cdim, _ptr(W1), (Cdim if ldw1 is None else ldw1), _ptr(b1)
+        d.W2, d.ldw2, d.b2 = _ptr(W2), (H if ldw2 is None else ldw2), _ptr(b2)
+        d.R, d.ldr, d.rowscale, d.rows_per_scale = _ptr(R), Cdim, _ptr(rowscale), rows_per_scale
+        d.Y, d.ldy, d.M, d.C, d.H, d.dtype = _ptr(Y), Cdim, M, Cdim, H, dtype
+        self._add('ga_mlp_fwd', (C.byref(d),), label, keep=(d, X, W1, b1, W2, b2, R, rowscale, Y))
+
+    def mlp_bwd(self, X, DY, W1, b1, W2T, W1T, A, DH, DX, M, Cdim, dtype, ldw1=None, ldw2t=None, ldw1t=None, label=None):
+        """fused dgrad2 -> dgrad1 with the hidden pre-activation re-computed: A = gelu(X W1^T + b1), DH = (DY W2) gelu'(.), DX = DH W1"""
+        d = L.MlpBwdDesc()
+        H = 4 * Cdim
+        d.X, d.ldx, d.DY, d.lddy = _ptr(X), Cdim, _ptr(DY), Cdim
+        d.W1, d.ldw1, d.b1 = _ptr(W1), (Cdim if ldw1 is None else ldw1), _ptr(b1)
+        d.W2T, d.ldw2t, d.W1T, d.ldw1t = _ptr(W2T), (Cdim if ldw2t is None else ldw2t), _ptr(W1T), (H if ldw1t is None else ldw1t)
+        d.A, d.lda, d.DH, d.lddh, d.DX, d.lddx = _ptr(A), H, _ptr(DH), H, _ptr(DX), Cdim
+        d.M, d.C, d.H, d.dtype = M, Cdim, H, dtype
+        self._add('ga_mlp_bwd', (C.byref(d),), label, keep=(d, X, DY, W1, b1, W2T, W1T, A, DH, DX))
+
     def wgrad(self, Y, X, dW, M, N, K, dtype, ldy=None, ldx=None, ldw=None, batch=1, strideY=0, strideX=0, strideW=0,
               x_kind=A_PLAIN, x_dims=(0, 0, 0), x_act=ACT_NONE, dbias=None, strideDbias=0, alpha=1.0, split_m=None,
               accumulate=True, x_batch_mod=0, label=None):
@@ -675,6 +696,10 @@ class Plan:
     def zero(self, t, label=None):
         """memset a persistent buffer (hipMemsetAsync on the plan's stream)."""
         self._add('ga_memset', (_ptr(t), 0, t.numel() * t.element_size()), label or 'zero', keep=(t,))
+
+
+def mlp_supported(Cdim, H, dtype):
+    return bool(L.load().ga_mlp_supported(Cdim, H, dtype))
 
 
 def cswin_attn_bwd_workspace(d):

@@ -434,6 +434,39 @@ int ga_drop_path_sample(float* out, const float* keep, int sites, int B, uint64_
 /* nn.Dropout masks of the MAP head (map.py:54,82-83): out[i] = Bernoulli(keep) / keep, i < n; *counter advanced by one */
 int ga_dropout_mask_sample(float* out, int64_t n, float keep, uint64_t seed, uint64_t* counter, ga_stream_t stream);
 
+/* Fused MLP bodies of the narrow stages (bf16, C in {96, 192}, H = 4C; ga_mlp_supported tells): the [M][H] hidden activation
+ * stays on chip.  Replaces the fc1 / fc2 pair of ga_gemm launches of a ConvNeXt Block (ga_convnext.py:86-101) and, backward,
+ * the dgrad2 / dgrad1 pair:
+ *   ga_mlp_fwd: Y = R + rowscale[m / rows_per_scale] * (gelu(X W1^T + b1) W2^T + b2)      (R, rowscale optional)
+ *               W1 [H][ldw1] (rows = hidden), W2 [C][ldw2] (rows = output channel): the effective weights of ga_weight_prep;
+ *   ga_mlp_bwd: Hd = X W1^T + b1 re-computed;  A = gelu(Hd) -> A [M][lda];  DH = (DY W2) * gelu'(Hd) -> DH [M][lddh];
+ *               DX = DH W1 -> DX [M][lddx].  W2T [H][ldw2t] = W2 transposed (rows = hidden), W1T [C][ldw1t] = W1 transposed.
+ *               The two weight-gradient GEMMs (ga_wgrad) then read A / DH exactly as they read the stored tensors before.
+ * GELU is the tanh form the bf16 fc1 epilogue of ga_gemm uses (|error| <= 5e-4, below the bf16 rounding of the result). */
+typedef struct {
+    const void* X; int64_t ldx;
+    const void* W1; int64_t ldw1; const float* b1;
+    const void* W2; int64_t ldw2; const float* b2;
+    const void* R; int64_t ldr;
+    const float* rowscale; int rows_per_scale;
+    void* Y; int64_t ldy;
+    int64_t M; int C, H, dtype;
+} ga_mlp_desc;
+typedef struct {
+    const void* X; int64_t ldx;
+    const void* DY; int64_t lddy;
+    const void* W1; int64_t ldw1; const float* b1;
+    const void* W2T; int64_t ldw2t;
+    const void* W1T; int64_t ldw1t;
+    void* A; int64_t lda;
+    void* DH; int64_t lddh;
+    void* DX; int64_t lddx;
+    int64_t M; int C, H, dtype;
+} ga_mlp_bwd_desc;
+int ga_mlp_supported(int C, int H, int dtype);
+int ga_mlp_fwd(const ga_mlp_desc* d, ga_stream_t stream);
+int ga_mlp_bwd(const ga_mlp_bwd_desc* d, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
