@@ -240,6 +240,15 @@ def _dp(x, mask):
     return x * mask.reshape([-1] + [1] * (x.ndim - 1)).to(x.dtype)
 
 
+# 'erf' = nn.GELU() of the reference (ga_convnext.py:94).  'tanh' exists ONLY so that tests can measure how much of the bf16
+# throughput mode's deviation comes from the tanh-form GELU its fc1 epilogue evaluates (csrc/common.h gelu_both_fast).
+GELU_FORM = 'erf'
+
+
+def _gelu(y):
+    return F.gelu(y, approximate='tanh') if GELU_FORM == 'tanh' else F.gelu(y)
+
+
 def convnext_block(sd, pre, x, dp_mask=None):
     """ConvNeXtBlock.forward (ga_convnext.py:98-112)."""
     c = x.shape[1]
@@ -247,7 +256,7 @@ def convnext_block(sd, pre, x, dp_mask=None):
     y = y.permute(0, 2, 3, 1)
     y = F.layer_norm(y, (c,), sd[pre + 'norm.weight'], sd[pre + 'norm.bias'], 1e-6)
     y = F.linear(y, sd[pre + 'mlp.fc1.weight'], sd[pre + 'mlp.fc1.bias'])
-    y = F.gelu(y)
+    y = _gelu(y)
     y = F.linear(y, sd[pre + 'mlp.fc2.weight'], sd[pre + 'mlp.fc2.bias'])
     y = y.permute(0, 3, 1, 2)
     y = y * sd[pre + 'gamma'].reshape(1, -1, 1, 1)

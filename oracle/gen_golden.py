@@ -121,9 +121,37 @@ def do_train(tag, cfg, batch, lam=-0.8):
                         bn_head=np.stack([new_sd[n].reshape(-1)[:8].numpy() for n in bn_names]))
 
 
+def do_train_fp64(tag, cfg, batch, lam=-0.8):
+    """float64 ground truth of one train step from the oracle restatement (same weights / input / target as do_train):
+    per-tensor gradient norms, sums and 16-value heads, logits and loss.  The fp32-mode library gradients are gated at
+    5e-3 against THESE (the fp32 reference's own backward round-off is up to 4e-3, see do_train)."""
+    sd = O.fill_state(cfg, dtype=torch.float64)
+    x = O.gen_input(batch, seed=1).double()
+    tg = torch.Generator().manual_seed(99)
+    target = torch.randint(0, cfg['num_classes'], (batch,), generator=tg)
+    loss, outs, grads, _ = O.train_step_grads(sd, x, target, cfg, lam=lam)
+    assert all(g.dtype == torch.float64 for g in grads.values()) and outs[0].dtype == torch.float64
+    names = list(grads.keys())
+    norm = np.array([float(grads[n].norm()) for n in names])
+    ssum = np.array([float(grads[n].sum()) for n in names])
+    amax = np.array([float(grads[n].abs().max()) for n in names])
+    head = np.zeros((len(names), 16), dtype=np.float64)
+    for i, n in enumerate(names):
+        f = grads[n].reshape(-1)[:16]
+        head[i, :f.numel()] = f.numpy()
+    print(f'[{tag}] fp64 oracle train B={batch}: loss {float(loss):.9f}')
+    np.savez_compressed(os.path.join(OUT, f'{tag}_train_b{batch}_fp64.npz'), cfg=json.dumps(cfg), batch=batch, lam=lam,
+                        target=target.numpy(), loss=float(loss), logits=torch.stack(outs)[:, :, :40].numpy(),
+                        grad_names=np.array(names), grad_norm=norm, grad_sum=ssum, grad_absmax=amax, grad_head=head)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if '--fp64-only' in sys.argv:      # the float64 ground-truth fixtures need only the oracle
+        do_train_fp64('v2', O.make_cfg(**V2), 4)
+        do_train_fp64('t768', O.make_cfg('ga_convnext_tiny_768'), 4)
+        sys.exit(0)
     v2 = O.make_cfg(**V2)
     do_eval('v2', v2, 2, 40)
     do_train('v2', v2, 4)
@@ -131,6 +159,8 @@ if __name__ == '__main__':
     t768 = O.make_cfg('ga_convnext_tiny_768')
     do_eval('t768', t768, 2, 16)
     do_train('t768', t768, 4)
+    do_train_fp64('v2', v2, 4)
+    do_train_fp64('t768', t768, 4)
     b1024 = O.make_cfg('ga_convnext_base_1024')
     do_eval('b1024', b1024, 2, 16)
     print('golden vectors written to', OUT)
