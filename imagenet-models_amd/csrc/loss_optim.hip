@@ -32,12 +32,22 @@ template <typename T>
 __global__ __launch_bounds__(256) void ga_loss_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target,
                                                       float* __restrict__ loss, T* __restrict__ dlogits, int K, int B,
                                                       int NC, float lam, int kind, float smooth, float gscale,
-                                                      const float* __restrict__ avg, T* __restrict__ davg) {
+                                                      const float* __restrict__ avg, T* __restrict__ davg,
+                                                      const float* __restrict__ dense, float thr) {
     extern __shared__ float sm[];  // mean logits -> r[NC]; red[8]
     float* r = sm;
     float* red = sm + NC;
     const long b = blockIdx.x;
-    const int y = (int)target[b];
+    const int y = dense ? -1 : (int)target[b];
+    // dense targets (mixup / cutmix: SoftTargetCrossEntropy, or BinaryCrossEntropy on the mixed targets): row sum for the
+    // cross-entropy gradient (p * sum_t - t); thr >= 0 binarises the BCE target (timm BinaryCrossEntropy target_threshold)
+    const float* trow = dense ? dense + b * NC : nullptr;
+    float tsum = 1.f;
+    if (dense && kind == 0) {
+        float ts = 0.f;
+        for (int c = threadIdx.x; c < NC; c += 256) ts += trow[c];
+        tsum = block_sum(ts, red);
+    }
     const float invB = 1.f / (float)B, invBN = 1.f / ((float)B * (float)NC);
     // r = softmax(mean_k out_k)
     float mx = -3.0e38f;
@@ -72,10 +82,11 @@ __global__ __launch_bounds__(256) void ga_loss_kernel(const float* __restrict__ 
             // KL term: exp(target) * (target - input), mean over B*NC
             total += lam * rr * (logr - logp) * invBN;
             float g = lam * invBN * (p - rr);
-            const float t = (c == y) ? on : off;
+            float t = trow ? trow[c] : ((c == y) ? on : off);
+            if (kind == 1 && thr >= 0.f) t = t > thr ? 1.f : 0.f;
             if (kind == 0) {
                 total += -t * logp * invB;
-                g += (p - t) * invB;
+                g += (p * tsum - t) * invB;
             } else {
                 const float x = o[c];
                 // BCE with logits: max(x,0) - x*t + log(1 + exp(-|x|))
@@ -187,7 +198,15 @@ extern "C" int ga_loss_fwd_bwd(const float* logits, const int64_t* target, float
 extern "C" int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int64_t* target, float* loss, void* dorg, void* davg,
                                    int K, int B, int NC, float lam, int kind, float smoothing, float grad_scale, int dtype,
                                    ga_stream_t stream) {
-    GA_REQUIRE(org && target && loss && K >= 1 && B >= 1 && NC >= 1 && (kind == 0 || kind == 1), "ga_loss_fwd_bwd: bad args");
+    return ga_loss_dense_fwd_bwd(org, avg, target, nullptr, loss, dorg, davg, K, B, NC, lam, kind, smoothing, -1.f, grad_scale, dtype,
+                                 stream);
+}
+
+extern "C" int ga_loss_dense_fwd_bwd(const float* org, const float* avg, const int64_t* target, const float* dense, float* loss,
+                                     void* dorg, void* davg, int K, int B, int NC, float lam, int kind, float smoothing,
+                                     float bce_threshold, float grad_scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(org && (target || dense) && !(target && dense) && loss && K >= 1 && B >= 1 && NC >= 1 && (kind == 0 || kind == 1),
+               "ga_loss_fwd_bwd: bad args (exactly one of the class-index and the dense target)");
     GA_REQUIRE(NC <= 36000, "ga_loss_fwd_bwd: num_classes=%d exceeds the LDS row buffer (36000)", NC);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t lds = (NC + 8) * sizeof(float);
@@ -200,10 +219,10 @@ extern "C" int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int
     }
     if (dtype == GA_BF16)
         hipLaunchKernelGGL(ga_loss_kernel<bf16_t>, dim3(B), dim3(256), lds, s, org, target, loss, (bf16_t*)dorg, K,
-                           B, NC, lam, kind, smoothing, grad_scale, avg, (bf16_t*)davg);
+                           B, NC, lam, kind, smoothing, grad_scale, avg, (bf16_t*)davg, dense, bce_threshold);
     else
         hipLaunchKernelGGL(ga_loss_kernel<float>, dim3(B), dim3(256), lds, s, org, target, loss, (float*)dorg, K, B,
-                           NC, lam, kind, smoothing, grad_scale, avg, (float*)davg);
+                           NC, lam, kind, smoothing, grad_scale, avg, (float*)davg, dense, bce_threshold);
     return ga_check_launch("ga_loss_fwd_bwd");
 }
 
@@ -286,6 +305,96 @@ extern "C" int ga_clip_grad_f32(float* g, int64_t n, const float* sumsq, float l
     if (mode == 0) hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, s, g, (long)n, sumsq, limit);
     else hipLaunchKernelGGL(clip_value_kernel, dim3(blocks), dim3(256), 0, s, g, (long)n, limit);
     return ga_check_launch("ga_clip_grad_f32");
+}
+
+// ------------------------------------------------------------------------------------------------
+// mixup / cutmix of one batch on the device (timm.data.Mixup, mode 'batch', as GA/train.py:544-557,727-728 applies it):
+//   mixup:  out[b] = x[b] * lam + x[B-1-b] * (1 - lam)          (two rounded products, one rounded sum: as torch's mul_ / add_)
+//   cutmix: out[b] = x[B-1-b] inside the box [yl, yh) x [xl, xh), x[b] outside
+//   target: out[b][c] = lam * onehot_s(t[b])[c] + (1 - lam) * onehot_s(t[B-1-b])[c],  onehot_s: on = 1 - s + s/NC, off = s/NC
+// lam and the box are drawn on the host (numpy, as timm does)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void mixup_batch_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int CH, int H,
+                                                          int W, float lam, float oml, int cutmix, int yl, int yh, int xl, int xh) {
+#pragma clang fp contract(off)      // two rounded products and a rounded sum, as torch's mul_ / add_ (hipcc would fuse them into an FMA)
+    const long per = (long)CH * H * W, n = (long)B * per;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long b = i / per, r = i - b * per;
+        const long j = (B - 1 - b) * per + r;
+        if (cutmix) {
+            const int px = (int)(r % W), py = (int)((r / W) % H);
+            out[i] = (py >= yl && py < yh && px >= xl && px < xh) ? x[j] : x[i];
+        } else {
+            out[i] = x[i] * lam + x[j] * oml;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mixup_target_kernel(const int64_t* __restrict__ t, float* __restrict__ out, int B, int NC,
+                                                           float lam, float oml, float on, float off) {
+#pragma clang fp contract(off)
+    const long n = (long)B * NC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / NC), c = (int)(i - (long)b * NC);
+        const float y1 = c == (int)t[b] ? on : off, y2 = c == (int)t[B - 1 - b] ? on : off;
+        out[i] = y1 * lam + y2 * oml;
+    }
+}
+
+// adaptive gradient clipping (timm.utils.agc.adaptive_clip_grad, reached through dispatch_clip_grad(mode='agc'),
+// GA/train.py:752-756): per UNIT (row of a >= 2-d parameter, the whole tensor otherwise)
+//   max_norm = max(|p|_2, eps) * clip_factor;   g *= max_norm / max(|g|_2, 1e-6)  where |g|_2 >= max_norm
+// one wave per unit; units = device table {offset, length} into the flat parameter / gradient buffers
+__global__ __launch_bounds__(256) void agc_kernel(const float* __restrict__ p, float* __restrict__ g, const int64_t* __restrict__ units,
+                                                  int nunits, float clip_factor, float eps) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= nunits) return;
+    const long off = units[2 * u], len = units[2 * u + 1];
+    float sp = 0.f, sg = 0.f;
+    for (long i = lane; i < len; i += 64) {
+        const float a = p[off + i], b = g[off + i];
+        sp = fmaf(a, a, sp);
+        sg = fmaf(b, b, sg);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sp += __shfl_xor(sp, o, 64);
+        sg += __shfl_xor(sg, o, 64);
+    }
+    const float max_norm = fmaxf(sqrtf(sp), eps) * clip_factor, gn = sqrtf(sg);
+    if (gn < max_norm) return;
+    const float sc = max_norm / fmaxf(gn, 1e-6f);
+    for (long i = lane; i < len; i += 64) g[off + i] *= sc;
+}
+}  // namespace
+
+extern "C" int ga_mixup_batch(const float* x, float* out, int B, int CH, int H, int W, double lam, int cutmix, int yl, int yh, int xl,
+                              int xh, ga_stream_t stream) {
+    GA_REQUIRE(x && out && x != out && B > 0 && CH > 0 && H > 0 && W > 0, "ga_mixup_batch: bad args (out of place only)");
+    GA_REQUIRE(!cutmix || (0 <= yl && yl <= yh && yh <= H && 0 <= xl && xl <= xh && xh <= W), "ga_mixup_batch: box outside the image");
+    const long n = (long)B * CH * H * W;
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
+    hipLaunchKernelGGL(mixup_batch_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, B, CH, H, W, (float)lam,
+                       (float)(1.0 - lam), cutmix, yl, yh, xl, xh);
+    return ga_check_launch("ga_mixup_batch");
+}
+
+extern "C" int ga_mixup_target(const int64_t* target, float* out, int B, int NC, double lam, double smoothing, ga_stream_t stream) {
+    GA_REQUIRE(target && out && B > 0 && NC > 0, "ga_mixup_target: bad args");
+    const long n = (long)B * NC;
+    const int blocks = (int)std::max<long>(1, std::min<long>(4096, (n + 255) / 256));
+    hipLaunchKernelGGL(mixup_target_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), target, out, B, NC, (float)lam,
+                       (float)(1.0 - lam), (float)(1.0 - smoothing + smoothing / NC), (float)(smoothing / NC));
+    return ga_check_launch("ga_mixup_target");
+}
+
+extern "C" int ga_agc_clip(const float* params, float* grads, const int64_t* units, int nunits, float clip_factor, float eps,
+                           ga_stream_t stream) {
+    GA_REQUIRE(params && grads && units && nunits > 0 && clip_factor > 0.f, "ga_agc_clip: bad args");
+    hipLaunchKernelGGL(agc_kernel, dim3((nunits + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), params, grads, units,
+                       nunits, clip_factor, eps);
+    return ga_check_launch("ga_agc_clip");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1210,22 +1210,30 @@ class GAEngine:
             self.m.count_training_forward()     # num_batches_tracked: host-side count, written on state_dict()
         return self.logits.view_as(self.logits)
 
-    def build_loss(self, lam, kind=0, smoothing=0.0, grad_scale=1.0):
-        """fused GA loss writing d(loss)/d(logits) * grad_scale straight into the backward plan's input buffer"""
-        K, B, NC = self.logits.shape
+    def _loss_operands(self):
+        """(per-head logits, extra logits, d logits, d extra, heads) of the fused loss: the K GA heads here"""
+        return self.logits, None, self.dlogits, None, self.logits.shape[0]
+
+    def build_loss(self, lam, kind=0, smoothing=0.0, grad_scale=1.0, dense=False, bce_threshold=-1.0):
+        """fused loss writing d(loss)/d(logits) * grad_scale straight into the backward plan's input buffer; dense: the target
+        is a (B, NC) fp32 tensor (mixup / cutmix) instead of class indices"""
+        org, avg, dorg, davg, K = self._loss_operands()
+        _, B, NC = self.logits.shape
         self.loss_buf = self.buf('loss', (1,), torch.float32)
-        self.target_buf = self.buf('target', (B,), torch.int64)
+        self.target_buf = self.buf('target.dense', (B, NC), torch.float32) if dense else self.buf('target', (B,), torch.int64)
         lp = Plan(name='loss')
         lp.zero(self.loss_buf)
-        lp.loss_fwd_bwd(self.logits, self.target_buf, self.loss_buf, self.dlogits, K, B, NC, float(lam), int(kind),
-                        float(smoothing), float(grad_scale), self.dt)
+        lp.loss_dense_fwd_bwd(org, avg, None if dense else self.target_buf, self.target_buf if dense else None, self.loss_buf, dorg, davg,
+                              K, B, NC, float(lam), int(kind), float(smoothing), float(bce_threshold), float(grad_scale), self.dt)
         self.loss_plan = lp
-        self.loss_cfg = (lam, kind, smoothing, grad_scale)
+        self.loss_cfg = (lam, kind, smoothing, grad_scale, dense, bce_threshold)
 
-    def forward_loss(self, x, target, lam, kind=0, smoothing=0.0, grad_scale=1.0):
-        """forward + loss (+ dlogits) without autograd; follow with backward_range()/bwd.run(). Returns the loss buffer."""
-        if getattr(self, 'loss_cfg', None) != (lam, kind, smoothing, grad_scale):
-            self.build_loss(lam, kind, smoothing, grad_scale)
+    def forward_loss(self, x, target, lam, kind=0, smoothing=0.0, grad_scale=1.0, bce_threshold=-1.0):
+        """forward + loss (+ dlogits) without autograd; follow with backward_range()/bwd.run(). Returns the loss buffer.
+        target: class indices (B,) or a dense (B, NC) floating-point target"""
+        dense = target.dim() == 2
+        if getattr(self, 'loss_cfg', None) != (lam, kind, smoothing, grad_scale, dense, bce_threshold):
+            self.build_loss(lam, kind, smoothing, grad_scale, dense, bce_threshold)
         self.forward(x)
         self.target_buf.copy_(target, non_blocking=True)
         self.loss_plan.run()

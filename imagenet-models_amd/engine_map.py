@@ -427,16 +427,7 @@ class MAPEngine(GAEngine):
             perm = self.groups[k]['mlp']['perm'].long()
             v['mlp'].copy_(m['mlp'].reshape(v['mlp'].shape).to(self.dev)[:, perm])
 
-    def build_loss(self, lam, kind=0, smoothing=0.0, grad_scale=1.0):
-        """fused MAP loss (MAP/train.py:792-839) writing d(loss)/d(org logits) and d(loss)/d(avg logits) * grad_scale
-        straight into the backward plan's input buffer"""
+    def _loss_operands(self):
+        """fused MAP loss (MAP/train.py:792-839): org logits of the G groups, their avg logits, and the two gradients"""
         G = self.G
-        _, B, NC = self.logits.shape
-        self.loss_buf = self.buf('loss', (1,), torch.float32)
-        self.target_buf = self.buf('target', (B,), torch.int64)
-        lp = Plan(name='loss')
-        lp.zero(self.loss_buf)
-        lp.map_loss_fwd_bwd(self.logits[:G], self.logits[G:], self.target_buf, self.loss_buf, self.dlogits[:G], self.dlogits[G:], G, B,
-                            NC, float(lam), int(kind), float(smoothing), float(grad_scale), self.dt)
-        self.loss_plan = lp
-        self.loss_cfg = (lam, kind, smoothing, grad_scale)
+        return self.logits[:G], self.logits[G:], self.dlogits[:G], self.dlogits[G:], G

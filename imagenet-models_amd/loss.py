@@ -11,20 +11,34 @@ from .ops import GA_F32, Plan
 _KINDS = {'ce': 0, 'bce': 1}
 
 
+def _split_target(target, B, NC):
+    """class indices (B,) int64 -> (target, None);  dense (B, NC) floating point (mixup / cutmix, SoftTargetCrossEntropy /
+    BinaryCrossEntropy of GA/train.py:616-621) -> (None, fp32 dense)"""
+    if target.dim() == 2 and target.dtype.is_floating_point:
+        if tuple(target.shape) != (B, NC):
+            raise ValueError(f'dense target {tuple(target.shape)} does not match the logits ({B}, {NC})')
+        return None, target.float().contiguous()
+    if target.dim() != 1 or target.dtype != torch.int64:
+        raise TypeError('target must be int64 class indices (B,) or a floating-point dense target (B, num_classes)')
+    return target.contiguous(), None
+
+
 class _GALossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, lam, kind, smoothing):
+    def forward(ctx, logits, target, lam, kind, smoothing, thr):
         K, B, NC = logits.shape
         loss = torch.zeros(1, device=logits.device)
         dl = torch.empty_like(logits)
-        Plan(eager=True).loss_fwd_bwd(logits, target, loss, dl, K, B, NC, float(lam), kind, float(smoothing), 1.0, GA_F32)
+        idx, dense = _split_target(target, B, NC)
+        Plan(eager=True).loss_dense_fwd_bwd(logits, None, idx, dense, loss, dl, None, K, B, NC, float(lam), kind, float(smoothing),
+                                            float(thr), 1.0, GA_F32)
         ctx.save_for_backward(dl)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None, None, None
+        return dl * g, None, None, None, None, None
 
 
 def stack_heads(outputs):
@@ -36,12 +50,14 @@ def stack_heads(outputs):
     return torch.stack(list(outputs))
 
 
-def ga_loss(outputs, target, lam=0.0, kind='ce', smoothing=0.0):
-    """outputs: list of K (B,NC) fp32 logits; target: int64 (B,). Returns the scalar GA loss (differentiable)."""
+def ga_loss(outputs, target, lam=0.0, kind='ce', smoothing=0.0, bce_target_thresh=None):
+    """outputs: list of K (B,NC) fp32 logits; target: int64 (B,) class indices, or a dense (B,NC) target as mixup / cutmix
+    produce (then `smoothing` is already inside the target, GA/train.py:617).  Returns the scalar GA loss (differentiable)."""
     logits = stack_heads(outputs)
     if not logits.is_cuda:
         raise RuntimeError('ga_loss runs on the HIP kernels only (no CPU fallback)')
-    return _GALossFn.apply(logits.float().contiguous(), target.contiguous(), lam, _KINDS[kind], smoothing)
+    thr = -1.0 if bce_target_thresh is None else float(bce_target_thresh)
+    return _GALossFn.apply(logits.float().contiguous(), target, lam, _KINDS[kind], smoothing, thr)
 
 
 def heads_topk(outputs, k=5):
@@ -62,23 +78,25 @@ def accuracy_from_topk(idx, target, topk=(1, 5)):
 
 class _MAPLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, lam, kind, smoothing, G):
+    def forward(ctx, logits, target, lam, kind, smoothing, G, thr):
         n, B, NC = logits.shape
         loss = torch.zeros(1, device=logits.device)
         dl = torch.empty_like(logits)
         has_avg = n == 2 * G
-        Plan(eager=True).map_loss_fwd_bwd(logits[:G], logits[G:] if has_avg else None, target, loss, dl[:G], dl[G:] if has_avg else None,
-                                          G, B, NC, float(lam), kind, float(smoothing), 1.0, GA_F32)
+        idx, dense = _split_target(target, B, NC)
+        Plan(eager=True).loss_dense_fwd_bwd(logits[:G], logits[G:] if has_avg else None, idx, dense, loss, dl[:G],
+                                            dl[G:] if has_avg else None, G, B, NC, float(lam), kind, float(smoothing), float(thr), 1.0,
+                                            GA_F32)
         ctx.save_for_backward(dl)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None, None, None, None
+        return dl * g, None, None, None, None, None, None
 
 
-def map_loss(outputs, target, dec_lam=0.0, kind='ce', smoothing=0.0):
+def map_loss(outputs, target, dec_lam=0.0, kind='ce', smoothing=0.0, bce_target_thresh=None):
     """MAP/train.py:792-839 (`multi_group_loss`, distill_tokens == 0) on the fused HIP kernel.  outputs: the model's train-mode
     list of [org_out, avg_out] pairs (or a plain list of logits: then it is the GA loss with lam = dec_lam)."""
     if isinstance(outputs[0], (list, tuple)):
@@ -94,7 +112,8 @@ def map_loss(outputs, target, dec_lam=0.0, kind='ce', smoothing=0.0):
         logits = stack_heads(outputs)
     if not logits.is_cuda:
         raise RuntimeError('map_loss runs on the HIP kernels only (no CPU fallback)')
-    return _MAPLossFn.apply(logits.float().contiguous(), target.contiguous(), dec_lam, _KINDS[kind], smoothing, G)
+    thr = -1.0 if bce_target_thresh is None else float(bce_target_thresh)
+    return _MAPLossFn.apply(logits.float().contiguous(), target, dec_lam, _KINDS[kind], smoothing, G, thr)
 
 
 def heads_mean_topk(outputs, k=5):

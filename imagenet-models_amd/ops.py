@@ -612,6 +612,25 @@ class Plan:
         self._add('ga_map_loss_fwd_bwd', (_ptr(org), _ptr(avg), _ptr(target), _ptr(loss), _ptr(dorg), _ptr(davg), K, B, NC, lam, kind,
                                           smoothing, grad_scale, dtype), label, keep=(org, avg, target, loss, dorg, davg))
 
+    def loss_dense_fwd_bwd(self, org, avg, target, dense, loss, dorg, davg, K, B, NC, lam, kind, smoothing, bce_threshold, grad_scale,
+                           dtype, label=None):
+        """GA (avg None) / MAP loss on class indices (`target`) or on a dense [B, NC] fp32 target (`dense`: mixup / cutmix)"""
+        self._add('ga_loss_dense_fwd_bwd', (_ptr(org), _ptr(avg), _ptr(target), _ptr(dense), _ptr(loss), _ptr(dorg), _ptr(davg), K, B, NC,
+                                            lam, kind, smoothing, bce_threshold, grad_scale, dtype), label,
+                  keep=(org, avg, target, dense, loss, dorg, davg))
+
+    def mixup_batch(self, x, out, lam, cutmix=False, box=(0, 0, 0, 0), label=None):
+        B, CH, H, W = x.shape
+        yl, yh, xl, xh = (int(v) for v in box)
+        self._add('ga_mixup_batch', (_ptr(x), _ptr(out), B, CH, H, W, float(lam), int(cutmix), yl, yh, xl, xh), label, keep=(x, out))
+
+    def mixup_target(self, target, out, NC, lam, smoothing, label=None):
+        self._add('ga_mixup_target', (_ptr(target), _ptr(out), target.numel(), NC, float(lam), float(smoothing)), label, keep=(target, out))
+
+    def agc_clip(self, params, grads, units, nunits, clip_factor, eps=1e-3, label=None):
+        self._add('ga_agc_clip', (_ptr(params), _ptr(grads), _ptr(units), nunits, float(clip_factor), float(eps)), label,
+                  keep=(params, grads, units))
+
     def gelu_fwd(self, x, y, n, dtype, label=None):
         self._add('ga_gelu_fwd', (_ptr(x), _ptr(y), n, dtype), label, keep=(x, y))
 

@@ -64,10 +64,15 @@ def distribute_bn(model, world, reduce=False, group=None):
 
 class TrainStep:
     def __init__(self, model, optimizer, batch, lam=0.0, loss='ce', smoothing=0.0, grad_accumulation=1,
-                 process_group=None, clip_grad=None, clip_mode='norm', broadcast_buffers=True, bucket_elems=BUCKET_ELEMS):
+                 process_group=None, clip_grad=None, clip_mode='norm', broadcast_buffers=True, bucket_elems=BUCKET_ELEMS,
+                 mixup_fn=None, bce_target_thresh=None):
         self.model, self.opt = model, optimizer
         self.eng = model.engine(batch, True)
         self.lam, self.kind, self.smoothing = lam, _KINDS[loss], smoothing
+        # mixup / cutmix (imagenet_models_amd.Mixup, GA/train.py:727-728): applied to every batch, the loss then runs on the
+        # dense target it returns (SoftTargetCrossEntropy / BinaryCrossEntropy, train.py:616-621)
+        self.mixup_fn = mixup_fn
+        self.bce_threshold = -1.0 if bce_target_thresh is None else float(bce_target_thresh)
         self.accum = grad_accumulation
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -80,15 +85,30 @@ class TrainStep:
         self.buckets = make_buckets(st, model.grad_groups(), bucket_elems) if self.world > 1 else []
         # gradient clipping (timm dispatch_clip_grad through NativeScaler, GA/train.py:312-333): global L2 norm or
         # value clamp over the flat gradient buffer, after the all-reduce, before the optimizer
-        if clip_mode not in ('norm', 'value'):
-            raise NotImplementedError(f"clip_mode {clip_mode!r}: only 'norm' and 'value' are built ('agc' is not)")
+        if clip_mode not in ('norm', 'value', 'agc'):
+            raise ValueError(f"clip_mode {clip_mode!r}: 'norm', 'value' or 'agc'")
         self.clip_plan = None
         if clip_grad is not None:
             from . import ops
             self.gnorm_sq = torch.zeros(1, device=self.flat_g.device)
             p = ops.Plan(name='clip')
             n = self.flat_g.numel()
-            if clip_mode == 'norm':
+            if clip_mode == 'agc':
+                # timm adaptive_clip_grad over model_parameters(model, exclude_head=True) = parameters()[:-2] (train.py:755):
+                # one unit per row of a >= 2-d parameter, per tensor otherwise
+                units = []
+                named = list(model.named_parameters())[:-2]
+                offs = st['slices']
+                for name, prm in named:
+                    o = offs[name][0]
+                    if prm.dim() > 1:
+                        row = prm[0].numel()
+                        units.extend((o + r * row, row) for r in range(prm.shape[0]))
+                    else:
+                        units.append((o, prm.numel()))
+                self.agc_units = torch.tensor(units, dtype=torch.int64, device=self.flat_g.device)
+                p.agc_clip(st['params'], self.flat_g, self.agc_units, len(units), clip_grad)
+            elif clip_mode == 'norm':
                 p.zero(self.gnorm_sq)
                 p.sumsq_f32(self.flat_g, n, self.gnorm_sq)
                 p.clip_grad_f32(self.flat_g, n, self.gnorm_sq, clip_grad, 0)
@@ -104,7 +124,9 @@ class TrainStep:
             dist.broadcast(self.flat_buffers, 0, group=self.pg)      # rank 0's BatchNorm statistics before every forward
         # the reference divides the loss by grad_accumulation (train.py:750); DDP averages over ranks
         scale = 1.0 / (self.accum * self.world)
-        loss = eng.forward_loss(x, target, self.lam, self.kind, self.smoothing, scale)
+        if self.mixup_fn is not None:
+            x, target = self.mixup_fn(x, target)
+        loss = eng.forward_loss(x, target, self.lam, self.kind, self.smoothing, scale, self.bce_threshold)
         bwd = eng.bwd
         if self.world > 1 and last_micro:
             works, pos = [], 0

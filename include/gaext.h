@@ -419,6 +419,25 @@ int ga_class_attn_mt_bwd(const void* dout, const void* q, const void* kv_cls, co
                          int heads, int hd, float scale, int dtype, ga_stream_t stream);
 int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int64_t* target, float* loss, void* dorg, void* davg, int K,
                         int B, int NC, float lam, int kind, float smoothing, float grad_scale, int dtype, ga_stream_t stream);
+/* the same losses on DENSE targets [B][NC] fp32 (mixup / cutmix, GA/train.py:616-621: SoftTargetCrossEntropy for kind 0 --
+ * mean_b sum_c -t log_softmax(x) -- and BinaryCrossEntropy on the mixed targets for kind 1); exactly one of `target` (class
+ * indices, with `smoothing`) and `dense` is given; bce_threshold >= 0 binarises the BCE target (--bce-target-thresh), < 0: off.
+ * avg / davg as ga_map_loss_fwd_bwd (NULL for the GA loss). */
+int ga_loss_dense_fwd_bwd(const float* org, const float* avg, const int64_t* target, const float* dense, float* loss, void* dorg,
+                          void* davg, int K, int B, int NC, float lam, int kind, float smoothing, float bce_threshold,
+                          float grad_scale, int dtype, ga_stream_t stream);
+/* timm.data.Mixup (mode 'batch') on the device, lam / box drawn by the host as timm does (GA/train.py:544-557,727-728):
+ *   ga_mixup_batch:  fp32 NCHW x -> out (out of place): mixup out[b] = x[b]*lam + x[B-1-b]*(1-lam), or cutmix (x[B-1-b] inside
+ *                    the box [yl,yh) x [xl,xh));
+ *   ga_mixup_target: class indices -> dense [B][NC]: lam * onehot_s(t[b]) + (1-lam) * onehot_s(t[B-1-b]).
+ * lam / smoothing are doubles: 1 - lam and the on / off values are formed in double and rounded to fp32 once, as torch does. */
+int ga_mixup_batch(const float* x, float* out, int B, int CH, int H, int W, double lam, int cutmix, int yl, int yh, int xl, int xh,
+                   ga_stream_t stream);
+int ga_mixup_target(const int64_t* target, float* out, int B, int NC, double lam, double smoothing, ga_stream_t stream);
+/* adaptive gradient clipping (timm adaptive_clip_grad, clip_mode 'agc'): units = int64 {offset, length} pairs into the flat fp32
+ * parameter / gradient buffers (a row of a >= 2-d parameter or a whole <= 1-d one); per unit
+ * g *= max(|p|, eps) * clip_factor / max(|g|, 1e-6) where |g| exceeds max(|p|, eps) * clip_factor */
+int ga_agc_clip(const float* params, float* grads, const int64_t* units, int nunits, float clip_factor, float eps, ga_stream_t stream);
 int ga_gelu_fwd(const void* x, void* y, int64_t n, int dtype, ga_stream_t stream);
 int ga_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, int dtype, ga_stream_t stream);
 int ga_relu_drop(const void* a, const float* mask, void* out, void* deriv, int64_t n, int dtype, ga_stream_t stream);

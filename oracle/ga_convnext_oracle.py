@@ -393,7 +393,14 @@ def _bce_target(target, num_classes, smoothing):
     return t.scatter_(1, target.view(-1, 1), on)
 
 
-def head_loss(out, target, kind='ce', smoothing=0.0):
+def head_loss(out, target, kind='ce', smoothing=0.0, bce_threshold=None):
+    """the per-head loss GA/train.py:608-630 selects.  A floating-point (B, C) target is the dense target mixup / cutmix
+    produce: 'ce' then is timm SoftTargetCrossEntropy, 'bce' timm BinaryCrossEntropy on it (smoothing already inside)."""
+    if target.dim() == 2:
+        if kind in ('ce', 'soft'):
+            return torch.sum(-target * F.log_softmax(out, dim=-1), dim=-1).mean()
+        t = target.gt(bce_threshold).to(target.dtype) if bce_threshold is not None else target
+        return F.binary_cross_entropy_with_logits(out, t, reduction='mean')
     if kind == 'ce':
         if smoothing > 0:  # timm LabelSmoothingCrossEntropy
             logp = F.log_softmax(out, dim=-1)
@@ -401,19 +408,22 @@ def head_loss(out, target, kind='ce', smoothing=0.0):
             return ((1 - smoothing) * nll + smoothing * (-logp.mean(dim=-1))).mean()
         return F.cross_entropy(out, target)
     if kind == 'bce':
-        return F.binary_cross_entropy_with_logits(out, _bce_target(target, out.shape[1], smoothing), reduction='mean')
+        t = _bce_target(target, out.shape[1], smoothing).to(out.dtype)
+        if bce_threshold is not None:
+            t = t.gt(bce_threshold).to(t.dtype)
+        return F.binary_cross_entropy_with_logits(out, t, reduction='mean')
     if kind == 'soft':  # timm SoftTargetCrossEntropy; target is (B, C) float
         return torch.sum(-target * F.log_softmax(out, dim=-1), dim=-1).mean()
     raise ValueError(kind)
 
 
-def ga_loss(outputs, target, lam, kind='ce', smoothing=0.0):
+def ga_loss(outputs, target, lam, kind='ce', smoothing=0.0, bce_threshold=None):
     """GA/train.py:735-745: sum_k L(out_k) + lam * sum_k KL_mean(log_softmax(out_k) || log_softmax(mean_j out_j.detach()))
     with reduction='mean' (divide by B*C) and log_target=True."""
     loss = 0
     summed = 0
     for out in outputs:
-        loss = loss + head_loss(out, target, kind, smoothing)
+        loss = loss + head_loss(out, target, kind, smoothing, bce_threshold)
         summed = summed + out.detach()
     ref = F.log_softmax(summed / len(outputs), dim=1)
     for out in outputs:

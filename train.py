@@ -43,6 +43,15 @@ parser.add_argument('--min-lr', type=float, default=1e-6)
 parser.add_argument('--warmup-epochs', type=int, default=3)
 parser.add_argument('--smoothing', type=float, default=0.1)
 parser.add_argument('--bce-loss', action='store_true')
+parser.add_argument('--bce-target-thresh', type=float, default=None, help='threshold for binarizing softened BCE targets')
+# mixup / cutmix: the defaults are the reference's (GA/train.py:215-228: both ON); 0 / 0 turns them off
+parser.add_argument('--mixup', type=float, default=0.2, help='mixup alpha, mixup enabled if > 0')
+parser.add_argument('--cutmix', type=float, default=1.0, help='cutmix alpha, cutmix enabled if > 0')
+parser.add_argument('--cutmix-minmax', type=float, nargs='+', default=None)
+parser.add_argument('--mixup-prob', type=float, default=1.0)
+parser.add_argument('--mixup-switch-prob', type=float, default=0.5)
+parser.add_argument('--mixup-mode', default='batch', help='only "batch" is built')
+parser.add_argument('--mixup-off-epoch', type=int, default=0)
 parser.add_argument('--drop-path', type=float, default=None)
 parser.add_argument('--grad-accumulation', type=int, default=1)
 parser.add_argument('--GA_lam', type=float, default=0)
@@ -55,7 +64,7 @@ parser.add_argument('--dist-bn', default='reduce', help='"reduce" | "broadcast" 
 parser.add_argument('--model-ema', action='store_true', help='track an EMA of the weights (timm ModelEmaV2)')
 parser.add_argument('--model-ema-decay', type=float, default=0.9998)
 parser.add_argument('--clip-grad', type=float, default=None, help='clip gradients (GA/train.py --clip-grad)')
-parser.add_argument('--clip-mode', default='norm', help='"norm" or "value" ("agc" is not built)')
+parser.add_argument('--clip-mode', default='norm', help='"norm", "value" or "agc"')
 parser.add_argument('--amp', action='store_true', help='bf16 math mode (default)')
 parser.add_argument('--fp32', action='store_true', help='fp32 parity math mode')
 parser.add_argument('--channels-last', action='store_true', help='accepted for CLI compatibility (activations are always NHWC)')
@@ -158,8 +167,10 @@ def main():
             dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend, init_method='env://')
+    import numpy as np
     import imagenet_models_amd as A
     torch.manual_seed(args.seed + rank)
+    np.random.seed(args.seed + rank)          # timm random_seed(): mixup draws lam / boxes from numpy's global generator
     model = A.create_model(args.model, pretrained=False, num_classes=args.num_classes, drop_path_rate=args.drop_path,
                            math_mode='fp32' if args.fp32 else 'bf16').cuda()
     if world > 1:
@@ -172,9 +183,17 @@ def main():
     sched = A.CosineLRScheduler(opt, t_initial=args.epochs, lr_min=args.min_lr, warmup_t=args.warmup_epochs,
                                 warmup_lr_init=args.warmup_lr) if args.sched == 'cosine' else None
     lam = args.dec_lam if args.dec_lam is not None else args.GA_lam
+    # mixup / cutmix (GA/train.py:544-557): smoothing then lives in the dense target and the loss is SoftTargetCrossEntropy /
+    # BinaryCrossEntropy on it (:616-621)
+    mixup_fn = None
+    if args.mixup > 0 or args.cutmix > 0. or args.cutmix_minmax is not None:
+        mixup_fn = A.Mixup(mixup_alpha=args.mixup, cutmix_alpha=args.cutmix, cutmix_minmax=args.cutmix_minmax, prob=args.mixup_prob,
+                           switch_prob=args.mixup_switch_prob, mode=args.mixup_mode, label_smoothing=args.smoothing,
+                           num_classes=model.num_classes)
     step_fn = A.TrainStep(model, opt, args.batch_size, lam=lam, loss='bce' if args.bce_loss else 'ce',
                           smoothing=args.smoothing, grad_accumulation=args.grad_accumulation,
-                          clip_grad=args.clip_grad, clip_mode=args.clip_mode, broadcast_buffers=not args.no_ddp_bb)
+                          clip_grad=args.clip_grad, clip_mode=args.clip_mode, broadcast_buffers=not args.no_ddp_bb,
+                          mixup_fn=mixup_fn, bce_target_thresh=args.bce_target_thresh)
     model_ema = A.ModelEma(model, args.model_ema_decay) if args.model_ema else None
     loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda')
     eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda')
@@ -182,6 +201,8 @@ def main():
     for epoch in range(args.epochs):
         if sched is not None:
             sched.step(epoch)
+        if mixup_fn is not None and args.mixup_off_epoch and epoch >= args.mixup_off_epoch:
+            mixup_fn.mixup_enabled = False      # GA/train.py:705-709
         train_metrics = train_one_epoch(epoch, step_fn, loader, args, world, rank, model_ema)
         if world > 1 and args.dist_bn in ('broadcast', 'reduce'):
             A.distribute_bn(model, world, args.dist_bn == 'reduce')
