@@ -152,6 +152,7 @@ _SIGS = {
     'ga_dropout_mask_sample': ([vp, i64, f32, C.c_uint64, vp, vp], i32),
     'ga_drop_path_sample': ([vp, vp, i32, i32, C.c_uint64, vp, vp], i32),
     'ga_loss_dense_fwd_bwd': ([vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, f32, i32, vp], i32),
+    'ga_u8_normalize': ([vp, vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp], i32),
     'ga_mixup_batch': ([vp, vp, i32, i32, i32, i32, C.c_double, i32, i32, i32, i32, i32, vp], i32),
     'ga_mixup_target': ([vp, vp, i32, i32, C.c_double, C.c_double, vp], i32),
     'ga_agc_clip': ([vp, vp, vp, i32, f32, f32, vp], i32),

@@ -369,6 +369,40 @@ __global__ __launch_bounds__(256) void agc_kernel(const float* __restrict__ p, f
 }
 }  // namespace
 
+// uint8 NCHW batch -> normalised fp32 NCHW: out = (float(x) - mean[c]) / std[c] -- what timm's PrefetchLoader does on the device
+// to the uint8 batches of fast_collate (GA/train.py:567-595: `.float().sub_(mean).div_(std)`, mean / std already x 255)
+namespace {
+struct NormCh { float mean[4], std[4]; };
+__global__ __launch_bounds__(256) void u8_normalize_kernel(const unsigned char* __restrict__ x, float* __restrict__ out, long n, int CH,
+                                                           long HW, NormCh nc) {
+    // 4 pixels per thread (HW % 4 == 0 is required): one 32-bit load, one 16-byte store
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+        const int c = (int)((i / HW) % CH);
+        const unsigned v = *reinterpret_cast<const unsigned*>(x + i);
+        const float m = nc.mean[c], s = nc.std[c];
+        *reinterpret_cast<float4*>(out + i) = make_float4(((float)(v & 255u) - m) / s, ((float)((v >> 8) & 255u) - m) / s,
+                                                           ((float)((v >> 16) & 255u) - m) / s, ((float)(v >> 24) - m) / s);
+    }
+}
+}  // namespace
+
+extern "C" int ga_u8_normalize(const void* x, float* out, int B, int CH, int H, int W, const float* mean, const float* std,
+                               ga_stream_t stream) {
+    GA_REQUIRE(x && out && mean && std && B > 0 && CH > 0 && CH <= 4 && H > 0 && W > 0, "ga_u8_normalize: bad args (at most 4 channels)");
+    GA_REQUIRE(((long)H * W) % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0,
+               "ga_u8_normalize: H*W must be a multiple of 4 and the buffers 4 / 16-byte aligned");
+    NormCh nc;
+    for (int c = 0; c < 4; ++c) {
+        nc.mean[c] = c < CH ? mean[c] : 0.f;     // host arrays
+        nc.std[c] = c < CH ? std[c] : 1.f;
+    }
+    const long n = (long)B * CH * H * W;
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n / 4 + 255) / 256));
+    hipLaunchKernelGGL(u8_normalize_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned char*>(x), out, n, CH, (long)H * W, nc);
+    return ga_check_launch("ga_u8_normalize");
+}
+
 extern "C" int ga_mixup_batch(const float* x, float* out, int B, int CH, int H, int W, double lam, int cutmix, int yl, int yh, int xl,
                               int xh, ga_stream_t stream) {
     GA_REQUIRE(x && out && x != out && B > 0 && CH > 0 && H > 0 && W > 0, "ga_mixup_batch: bad args (out of place only)");

@@ -1182,7 +1182,23 @@ class GAEngine:
     # ------------------------------------------------------------------------------------------
     # run
     # ------------------------------------------------------------------------------------------
+    # ImageNet statistics x 255, as timm's PrefetchLoader holds them for the uint8 batches of fast_collate (GA/train.py:567-595)
+    U8_MEAN = (0.485 * 255, 0.456 * 255, 0.406 * 255)
+    U8_STD = (0.229 * 255, 0.224 * 255, 0.225 * 255)
+
+    def _normalize_u8(self, x):
+        """a uint8 (B, 3, H, W) batch is normalised on the device into an engine-owned fp32 buffer (no host round trip)"""
+        if x.dtype != torch.uint8:
+            return x
+        assert x.is_cuda and tuple(x.shape) == (self.B, 3, self.img, self.img), f'uint8 input of shape {tuple(x.shape)}'
+        out = self.buf('x.u8norm', (self.B, 3, self.img, self.img), torch.float32)
+        mean = getattr(self.m, 'input_mean', None) or self.U8_MEAN
+        std = getattr(self.m, 'input_std', None) or self.U8_STD
+        Plan(eager=True).u8_normalize(x.contiguous(), out, mean, std)
+        return out
+
     def set_input(self, x):
+        x = self._normalize_u8(x)
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.B, 3, self.img, self.img), \
             f'input must be a float32 CUDA tensor of shape {(self.B, 3, self.img, self.img)}, got {tuple(x.shape)} {x.dtype}'
         if not x.is_contiguous():

@@ -460,6 +460,7 @@ class CSWinEngine(GAEngine):
 
     # ------------------------------------------------------------------------------------------
     def set_input(self, x):
+        x = self._normalize_u8(x)
         assert x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (self.B, 3, self.img, self.img), \
             f'input must be a float32 CUDA tensor of shape {(self.B, 3, self.img, self.img)}, got {tuple(x.shape)} {x.dtype}'
         if not x.is_contiguous():

@@ -619,6 +619,13 @@ class Plan:
                                             lam, kind, smoothing, bce_threshold, grad_scale, dtype), label,
                   keep=(org, avg, target, dense, loss, dorg, davg))
 
+    def u8_normalize(self, x, out, mean, std, label=None):
+        """uint8 (B, C, H, W) -> fp32, (x - mean[c]) / std[c]; mean / std: python sequences in 0..255 units"""
+        B, CH, H, W = x.shape
+        m = (C.c_float * CH)(*[float(v) for v in mean])
+        s = (C.c_float * CH)(*[float(v) for v in std])
+        self._add('ga_u8_normalize', (_ptr(x), _ptr(out), B, CH, H, W, m, s), label, keep=(x, out, m, s))
+
     def mixup_batch(self, x, out, lam, cutmix=False, box=(0, 0, 0, 0), label=None):
         B, CH, H, W = x.shape
         yl, yh, xl, xh = (int(v) for v in box)

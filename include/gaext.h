@@ -434,6 +434,9 @@ int ga_loss_dense_fwd_bwd(const float* org, const float* avg, const int64_t* tar
 int ga_mixup_batch(const float* x, float* out, int B, int CH, int H, int W, double lam, int cutmix, int yl, int yh, int xl, int xh,
                    ga_stream_t stream);
 int ga_mixup_target(const int64_t* target, float* out, int B, int NC, double lam, double smoothing, ga_stream_t stream);
+/* uint8 NCHW batch (timm fast_collate) -> fp32 NCHW, out = (x - mean[c]) / std[c]; mean / std are HOST arrays of CH <= 4 floats
+ * (already scaled by 255 as timm's PrefetchLoader holds them, GA/train.py:567-595); H*W a multiple of 4 */
+int ga_u8_normalize(const void* x, float* out, int B, int CH, int H, int W, const float* mean, const float* std, ga_stream_t stream);
 /* adaptive gradient clipping (timm adaptive_clip_grad, clip_mode 'agc'): units = int64 {offset, length} pairs into the flat fp32
  * parameter / gradient buffers (a row of a >= 2-d parameter or a whole <= 1-d one); per unit
  * g *= max(|p|, eps) * clip_factor / max(|g|, 1e-6) where |g| exceeds max(|p|, eps) * clip_factor */

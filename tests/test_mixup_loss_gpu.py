@@ -141,3 +141,28 @@ def test_train_step_with_mixup_and_agc():
     assert abs(loss - ref) / abs(ref) < 1e-3, (loss, ref)
     l2 = float(step(x.cuda(), t.cuda()))
     assert np.isfinite(l2)
+
+
+def test_uint8_batches_are_normalised_on_the_device():
+    """timm fast_collate hands uint8 NCHW batches to the device, PrefetchLoader does .float().sub_(mean).div_(std) there
+    (GA/train.py:567-595): the model takes the uint8 tensor and produces the logits of the normalised float batch"""
+    import imagenet_models_amd as A
+    from imagenet_models_amd import ops
+    O, _, _ = _oracles()
+    g = torch.Generator().manual_seed(11)
+    x8 = torch.randint(0, 256, (2, 3, 224, 224), generator=g, dtype=torch.uint8)
+    mean = torch.tensor([0.485 * 255, 0.456 * 255, 0.406 * 255]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229 * 255, 0.224 * 255, 0.225 * 255]).view(1, 3, 1, 1)
+    ref = x8.float().sub_(mean).div_(std)
+    out = torch.empty(2, 3, 224, 224, device='cuda')
+    ops.Plan(eager=True).u8_normalize(x8.cuda(), out, mean.flatten().tolist(), std.flatten().tolist())
+    assert torch.equal(out.cpu(), ref)
+    cfg = O.make_cfg(dims=(16, 32, 64, 128, 128), depths=(1, 1, 6, 1, 1), gram_dim=32, dim_embed=64, num_classes=40, naggre=2)
+    m = A.GA_ConvNeXt(num_classes=40, depths=cfg['depths'], dims=cfg['dims'], gram_dim=32, dim_embed=64, stage3_naggre=2,
+                      drop_path_rate=0.0, math_mode='fp32')
+    m.load_state_dict(O.fill_state(cfg))
+    m = m.cuda().eval()
+    with torch.no_grad():
+        a = torch.stack(m(x8.cuda())).cpu()
+        b = torch.stack(m(ref.cuda())).cpu()
+    assert torch.equal(a, b)
