@@ -367,78 +367,143 @@ __device__ __forceinline__ void store_tile(unsigned char* stage, const f32x4_t (
 }
 
 
-// LePE of all the window's tokens by the whole workgroup: lep[t][32] fp32 = bias[c] + sum_taps w[c][tap] * X[t + tap][c]
-// (TR: the transpose, X[t - tap], no bias).  Thread = (token t = tid >> 2 (+64..), 8-channel chunk tid & 3): nine 16-byte
-// LDS reads per item instead of 72 two-byte reads per accumulator lane.
+// ---------------------------------------------------------------------------------------------------------------
+// LePE on the matrix cores.  out[t][c] += sum_tap w[c][tap] * X[nbr(t, tap)][c] is, per 16-channel half dt and per PAIR
+// of taps, one 16x16x32 product  D[t][c] += sum_{k = (s, c')} A[t][k] * B[k][c]  with
+//     A[t][(s, c')] = X[nbr(t, tap_{2p+s})][16 dt + c']   (0 outside the window)         -- one 16-byte LDS read per lane
+//     B[(s, c')][c] = (c' == c) * w[16 dt + c][tap_{2p+s}]                                   -- 10 fragments held in registers
+// (tap 9 does not exist: its B rows are zero).  5 MFMAs per half instead of ~36 VALU multiply-adds, bounds tests and 2-byte
+// LDS reads per accumulator element; the transpose (backward, X = dO) only flips the neighbour offsets.
+// ---------------------------------------------------------------------------------------------------------------
+struct LepeW { bf16x8_t f[2][5]; };
+
+__device__ __forceinline__ LepeW lepe_wfrags(const float* wp, int lane) {
+    LepeW W;
+    const int g = lane >> 4, c = lane & 15, e0 = c - 8 * (g & 1);          // this lane's non-zero element, if 0 <= e0 < 8
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int p = 0; p < 5; ++p) {
+            const int tap = 2 * p + (g >> 1);
+            const float w = tap < 9 ? wp[(16 * dt + c) * 9 + tap] : 0.f;
+            const unsigned wb = (unsigned)f2bf(w);
+            unsigned u[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) u[q] = (e0 == 2 * q ? wb : 0u) | (e0 == 2 * q + 1 ? wb << 16 : 0u);
+            const uint4 v = make_uint4(u[0], u[1], u[2], u[3]);
+            W.f[dt][p] = *reinterpret_cast<const bf16x8_t*>(&v);
+        }
+    return W;
+}
+
+// o[dt] (+)= LePE rows q0 .. q0+15 of `tile` (TR: the transpose); zoff = LDS byte offset (relative to tile) of 16 zero bytes
 template <bool TR>
-__device__ __forceinline__ void lepe_pass(float* lep, const unsigned char* Xt, const float* wp, const float* bp, const WinGeom& g) {
-    const int c8 = threadIdx.x & 3;
-    float w[8][9], b[8];
+__device__ __forceinline__ void lepe_mfma(f32x4_t (&o)[2], const unsigned char* tile, int q0, const WinGeom& g, const LepeW& W,
+                                          int lane, const unsigned char* zero16) {
+    const int gq = lane >> 4, t = q0 + (lane & 15);
+    const int ty = t / g.Ws, tx = t - ty * g.Ws;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        b[e] = TR ? 0.f : bp[c8 * 8 + e];
+    for (int p = 0; p < 5; ++p) {
+        const int tap = 2 * p + (gq >> 1);
+        const int dy = (tap * 11 >> 5) - 1, dx = tap - 3 * (tap * 11 >> 5) - 1;      // tap / 3 for tap < 12
+        const int yy = TR ? ty - dy : ty + dy, xx = TR ? tx - dx : tx + dx;
+        const bool ok = tap < 9 && t < g.N && (unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws;
+        const int row = yy * g.Ws + xx;
+        const unsigned base = row * 64, sw = (row >> 2) & 3;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) w[e][k] = wp[(c8 * 8 + e) * 9 + k];
-    }
-    for (int t = threadIdx.x >> 2; t < g.N; t += 64) {
-        const int ty = t / g.Ws, tx = t - ty * g.Ws;
-        float a[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = b[e];
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = TR ? ty - dy : ty + dy, xx = TR ? tx - dx : tx + dx;
-                if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws) {
-                    const uint4 u = *reinterpret_cast<const uint4*>(Xt + tile_off(yy * g.Ws + xx, c8));
-                    float x[8];
-                    unpack8(u, x);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = fmaf(w[e][(dy + 1) * 3 + dx + 1], x[e], a[e]);
-                }
-            }
-        float4* o = reinterpret_cast<float4*>(lep + t * 32 + c8 * 8);
-        o[0] = make_float4(a[0], a[1], a[2], a[3]);
-        o[1] = make_float4(a[4], a[5], a[6], a[7]);
+        for (int dt = 0; dt < 2; ++dt) {
+            const unsigned char* src = ok ? tile + base + (((2 * dt + (gq & 1)) ^ sw) << 4) : zero16;
+            const bf16x8_t af = *reinterpret_cast<const bf16x8_t*>(src);
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, W.f[dt][p], o[dt], 0, 0, 0);
+        }
     }
 }
 
-// LePE weight-gradient partial of one (window, head): part[ch][k] = sum_t dO[t][ch] * V[t + tap_k][ch] (k < 9), sum_t dO[t][ch]
-// (k = 9), written to ws[item][32][10] with plain stores (ga_cswin_lepe_wgrad_reduce sums the items of each head).
-// `scratch` >= 8 * 320 floats of LDS; ends with a barrier.
-__device__ __forceinline__ void lepe_wgrad_partial(float* scratch, const unsigned char* Gt, const unsigned char* Vt, const WinGeom& g,
-                                                   float* ws_item) {
-    const bf16_t* G16 = reinterpret_cast<const bf16_t*>(Gt);
-    const bf16_t* V16 = reinterpret_cast<const bf16_t*>(Vt);
-    const int ch = threadIdx.x & 31, tg = threadIdx.x >> 5;
-    float acc[10];
+// B fragments (both 16-channel halves) of the SHIFTED tile taken column-wise in the k order of col_frag_acc: element j of
+// lane (g, i) is tile[nbr(row, tap)][16 dt + i] with row = k0 + 16 (j >> 2) + 4 g + (j & 3); rows whose neighbour is outside
+// the window read zeros.  ty / tx: window coordinates of this lane's two rows (h = 0, 1), computed once per k step.
+__device__ __forceinline__ void col_frag_shift2(bf16x8_t (&out)[2], const unsigned char* tile, int lane, int dy, int dx, const WinGeom& g,
+                                                const int (&ty)[2], const int (&tx)[2], const bool (&rok)[2], const unsigned char* zero16) {
+    const int i = lane & 15;
+    s16x4_t half[2][2];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.f;
-    for (int t = tg; t < g.N; t += 8) {
-        const float gv = bf2f(G16[(tile_off(t, ch >> 3) >> 1) + (ch & 7)]);
-        acc[9] += gv;
-        const int ty = t / g.Ws, tx = t - ty * g.Ws;
+    for (int h = 0; h < 2; ++h) {
+        const int yy = ty[h] + dy, xx = tx[h] + dx;
+        const bool ok = rok[h] && (unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws;
+        const int row = yy * g.Ws + xx;
+        const unsigned base = row * 64 + 8 * (i & 1), sw = (row >> 2) & 3;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dt = 0; dt < 2; ++dt) {
+            const unsigned char* src = ok ? tile + base + (((2 * dt + ((i & 3) >> 1)) ^ sw) << 4) : zero16 + 8 * (i & 1);
+            half[dt][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)src);
+        }
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = ty + dy, xx = tx + dx;
-                if ((unsigned)yy < (unsigned)g.Hs && (unsigned)xx < (unsigned)g.Ws)
-                    acc[(dy + 1) * 3 + dx + 1] =
-                        fmaf(gv, bf2f(V16[(tile_off(yy * g.Ws + xx, ch >> 3) >> 1) + (ch & 7)]), acc[(dy + 1) * 3 + dx + 1]);
+    for (int dt = 0; dt < 2; ++dt) {
+        const s16x8_t v = {half[dt][0][0], half[dt][0][1], half[dt][0][2], half[dt][0][3],
+                           half[dt][1][0], half[dt][1][1], half[dt][1][2], half[dt][1][3]};
+        out[dt] = *reinterpret_cast<const bf16x8_t*>(&v);
+    }
+}
+
+// LePE weight-gradient partial of one (window, head) on the matrix cores: per tap, D[c][c''] = sum_t dO[t][c] * V[nbr(t, tap)][c'']
+// over the window's tokens (k = token, both operands read column-wise); its diagonal is dw[c][tap], and with an all-ones
+// operand db[c].  Wave w takes taps w, w+4 and (w = 0) 8 / (w = 1) the bias.  ws_item[32][10] gets plain stores.
+template <int NT>
+__device__ __forceinline__ void lepe_wgrad_mfma(const unsigned char* Gt, const unsigned char* Vt, const WinGeom& g, float* ws_item,
+                                                int lane, int wave, const unsigned char* zero16) {
+    constexpr int KS = AT<NT>::KS;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    bf16x8_t gf[2][KS];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) gf[dt][ks] = col_frag_acc(Gt, 32 * ks, dt, lane);
+    const bool diag = ((lane & 15) >> 2) == (lane >> 4);
+    // window coordinates of this lane's rows of every k step (row = 32 ks + 16 h + 4 g + (i >> 2)): shared by the wave's taps
+    int ty[KS][2], tx[KS][2];
+    bool rok[KS][2];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 32 * ks + 16 * h + 4 * (lane >> 4) + ((lane & 15) >> 2);
+            ty[ks][h] = r / g.Ws;
+            tx[ks][h] = r - ty[ks][h] * g.Ws;
+            rok[ks][h] = r < g.N;
+        }
+#pragma unroll 1
+    for (int n = 0; n < 3; ++n) {
+        const int tap = wave + 4 * n;                       // 0..11; 9 = bias, > 9: nothing
+        if (tap > 9) break;
+        f32x4_t acc[2] = {zero, zero};
+        if (tap < 9) {
+            const int dy = tap / 3 - 1, dx = tap - 3 * (tap / 3) - 1;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8_t vf[2];
+                col_frag_shift2(vf, Vt, lane, dy, dx, g, ty[ks], tx[ks], rok[ks], zero16);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[dt][ks], vf[dt], acc[dt], 0, 0, 0);
             }
-    }
+        } else {
+            const uint4 o4 = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);      // bf16 ones
+            const bf16x8_t ones = *reinterpret_cast<const bf16x8_t*>(&o4);
 #pragma unroll
-    for (int k = 0; k < 10; ++k) scratch[tg * 320 + ch * 10 + k] = acc[k];
-    __syncthreads();
-    for (int i = threadIdx.x; i < 320; i += 256) {
-        float s_ = 0.f;
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s_ += scratch[q * 320 + i];
-        ws_item[i] = s_;
+                for (int dt = 0; dt < 2; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[dt][ks], ones, acc[dt], 0, 0, 0);
+        }
+        if (diag) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const int r = lane & 3;
+                const float v = r == 0 ? acc[dt][0] : r == 1 ? acc[dt][1] : r == 2 ? acc[dt][2] : acc[dt][3];
+                ws_item[(16 * dt + (lane & 15)) * 10 + tap] = v;
+            }
+        }
     }
-    __syncthreads();
 }
 
 template <int NT>
@@ -449,15 +514,18 @@ __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_d
     unsigned char* Kt = Qt + A::TILE;
     unsigned char* Vt = Kt + A::TILE;
     unsigned char* Stage = Vt + A::TILE;              // 4 x 1 KiB
-    float* Lep = reinterpret_cast<float*>(Stage + 4096);   // [KP][32]
+    unsigned char* Zero16 = Stage + 4096;              // 16 zero bytes: the LePE operand of neighbours outside the window
     const WinGeom g = win_geom(d, xcd_walk(blockIdx.x, nwg));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + g.ch;
     load_tile<NT>(Qt, qkv, d.ldq, d, g);
     load_tile<NT>(Kt, qkv + d.C, d.ldq, d, g);
     load_tile<NT>(Vt, qkv + 2 * d.C, d.ldq, d, g);
-    __syncthreads();
-    lepe_pass<false>(Lep, Vt, d.lepe_w[g.branch] + (long)g.chb * 9, d.lepe_b[g.branch] + g.chb, g);
+    if (threadIdx.x < 4) reinterpret_cast<unsigned*>(Zero16)[threadIdx.x] = 0u;
+    const LepeW LW = lepe_wfrags(d.lepe_w[g.branch] + (long)g.chb * 9, lane);
+    float lbias[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) lbias[dt] = d.lepe_b[g.branch][g.chb + 16 * dt + (lane & 15)];
     __syncthreads();
     for (int qt = wave; qt < NT; qt += 4) {
         const int q0 = 16 * qt;
@@ -475,13 +543,12 @@ __global__ __launch_bounds__(256) void cswin_attn_fwd_mfma(const ga_cswin_attn_d
             for (int dt = 0; dt < 2; ++dt)
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Vt, 32 * ks, dt, lane), o[dt], 0, 0, 0);
         }
-        // + LePE (rows 4g + r of this tile, channels 16dt + lane&15)
+        // + LePE of these 16 rows (5 + 5 MFMAs against the banded tap operand), + its bias
+        lepe_mfma<false>(o, Vt, q0, g, LW, lane, Zero16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = q0 + 4 * (lane >> 4) + r;
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) o[dt][r] += Lep[t * 32 + 16 * dt + (lane & 15)];
-        }
+            for (int r = 0; r < 4; ++r) o[dt][r] += lbias[dt];
         store_tile(Stage + wave * 1024, o, q0, reinterpret_cast<bf16_t*>(d.out) + g.ch, d.ldo, d, g, lane);
     }
 }
@@ -501,7 +568,7 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     unsigned char* Stage = Gt + A::TILE;              // 4 x 1 KiB
     float* lse = reinterpret_cast<float*>(Stage + 4096);   // [KP]
     float* dlt = lse + A::KP;                              // [KP]
-    float* Lep = dlt + A::KP;                              // [max(KP, 80)][32]: LePE^T(dO); before that the wgrad scratch
+    unsigned char* Zero16 = reinterpret_cast<unsigned char*>(dlt + A::KP);
     const int item = xcd_walk(blockIdx.x, nwg);
     const WinGeom g = win_geom(d, item);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -511,10 +578,9 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     load_tile<NT>(Kt, qkv + d.C, d.ldq, d, g);
     load_tile<NT>(Vt, qkv + 2 * d.C, d.ldq, d, g);
     load_tile<NT>(Gt, reinterpret_cast<const bf16_t*>(dout_) + g.ch, d.ldo, d, g);
-    for (int i = threadIdx.x; i < 2 * A::KP; i += 256) lse[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * A::KP + 4; i += 256) lse[i] = 0.f;     // (+ the 16 zero bytes behind dlt)
     __syncthreads();
-    if (lepe_ws) lepe_wgrad_partial(Lep, Gt, Vt, g, lepe_ws + (long)item * 320);
-    lepe_pass<true>(Lep, Gt, d.lepe_w[g.branch] + (long)g.chb * 9, nullptr, g);    // read by phase B, after the barrier below
+    if (lepe_ws) lepe_wgrad_mfma<NT>(Gt, Vt, g, lepe_ws + (long)item * 320, lane, wave, Zero16);
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     // ---------------- phase A ----------------
     for (int qt = wave; qt < NT; qt += 4) {
@@ -558,6 +624,7 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
     }
     __syncthreads();
     // ---------------- phase B ----------------
+    const LepeW LW = lepe_wfrags(d.lepe_w[g.branch] + (long)g.chb * 9, lane);
     for (int kt = wave; kt < NT; kt += 4) {
         const int k0 = 16 * kt;
         if (k0 >= g.N) break;
@@ -596,15 +663,11 @@ __global__ __launch_bounds__(256) void cswin_attn_bwd_mfma(const ga_cswin_attn_d
             }
         }
         // dv += LePE^T(dO); dk *= scale
+        lepe_mfma<true>(dv, Gt, k0, g, LW, lane, Zero16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = k0 + 4 * (lane >> 4) + r;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                dv[dt][r] += Lep[t * 32 + 16 * dt + (lane & 15)];
-                dk[dt][r] *= d.scale;
-            }
-        }
+            for (int dt = 0; dt < 2; ++dt) dk[dt][r] *= d.scale;
         store_tile(Stage + wave * 1024, dk, k0, dqkv + d.C, d.ldq, d, g, lane);
         store_tile(Stage + wave * 1024, dv, k0, dqkv + 2 * d.C, d.ldq, d, g, lane);
     }
@@ -899,10 +962,10 @@ extern "C" int ga_cswin_attn_fwd(const ga_cswin_attn_desc* d, ga_stream_t stream
     for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
     if (use_mfma(d)) {
         if (nmax <= 64) {
-            const size_t lds = 3 * AT<4>::TILE + 4096 + AT<4>::KP * 128;
+            const size_t lds = 3 * AT<4>::TILE + 4096 + 16;
             hipLaunchKernelGGL(cswin_attn_fwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, items);
         } else {
-            const size_t lds = 3 * AT<7>::TILE + 4096 + AT<7>::KP * 128;
+            const size_t lds = 3 * AT<7>::TILE + 4096 + 16;
             hipLaunchKernelGGL(cswin_attn_fwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, items);
         }
         return ga_check_launch("ga_cswin_attn_fwd");
@@ -944,10 +1007,10 @@ extern "C" int ga_cswin_attn_bwd(const ga_cswin_attn_desc* d, const void* dout, 
     for (int i = 0; i < d->nbranch; ++i) nmax = std::max(nmax, d->Hs[i] * d->Ws[i]);
     if (use_mfma(d)) {
         if (nmax <= 64) {
-            const size_t lds = 4 * AT<4>::TILE + 4096 + 2 * AT<4>::KP * sizeof(float) + 80 * 128;
+            const size_t lds = 4 * AT<4>::TILE + 4096 + 2 * AT<4>::KP * sizeof(float) + 16;
             hipLaunchKernelGGL(cswin_attn_bwd_mfma<4>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, (float*)lepe_ws, items);
         } else {
-            const size_t lds = 4 * AT<7>::TILE + 4096 + 2 * AT<7>::KP * sizeof(float) + AT<7>::KP * 128;
+            const size_t lds = 4 * AT<7>::TILE + 4096 + 2 * AT<7>::KP * sizeof(float) + 16;
             hipLaunchKernelGGL(cswin_attn_bwd_mfma<7>, dim3(items), dim3(256), lds, s, *d, dout, dqkv, (float*)lepe_ws, items);
         }
         return ga_check_launch("ga_cswin_attn_bwd");

@@ -138,6 +138,8 @@ class Plan:
         for k, v in kw.items():
             setattr(d, k, v)
         self._pend['small'].append(d)
+        if os.environ.get('GAEXT_SMALL_SINGLE'):      # diagnosis: one launch per small job, labelled with its geometry
+            self.flush(f'single.k{d.kind}.R{d.R}.C{d.C}.n{d.n}.')
 
     # -- core ---------------------------------------------------------------------------------------
     def _add(self, fname, args, label=None, keep=()):

@@ -22,7 +22,7 @@ def run(B, reso, C, heads, stripes, probe, bwd=False, iters=20):
     lws = torch.empty(max(need // 4, 1), device='cuda')
     def once():
         if bwd:
-            p.cswin_attn_bwd(d, do, dqkv, lepe_ws=lws if need else None)
+            p.cswin_attn_bwd(d, do, dqkv, lepe_ws=lws if (need and not os.environ.get('PROBE_NOWG')) else None)
         else:
             p.cswin_attn_fwd(d)
     for _ in range(3): once()
