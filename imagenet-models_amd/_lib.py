@@ -84,6 +84,12 @@ class MlpBwdDesc(C.Structure):
                 ('DX', vp), ('lddx', i64), ('M', i64), ('C', i32), ('H', i32), ('dtype', i32)]
 
 
+class SmallLinearDesc(C.Structure):
+    _fields_ = [('rows', i32), ('groups', i32), ('Ng', i32), ('Kg', i32), ('A', vp), ('lda', i64), ('a_gstride', i64), ('a_perm', vp),
+                ('W', vp), ('bias', vp), ('col_scale', vp), ('rowscale', vp), ('rows_per_scale', i32), ('R', vp), ('ldr', i64),
+                ('Y', vp), ('ldy', i64), ('Yraw', vp), ('dtype', i32)]
+
+
 _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
@@ -156,6 +162,10 @@ _SIGS = {
     'ga_mixup_batch': ([vp, vp, i32, i32, i32, i32, C.c_double, i32, i32, i32, i32, i32, vp], i32),
     'ga_mixup_target': ([vp, vp, i32, i32, C.c_double, C.c_double, vp], i32),
     'ga_agc_clip': ([vp, vp, vp, i32, f32, f32, vp], i32),
+    'ga_small_linear_fwd': ([C.POINTER(SmallLinearDesc), vp], i32),
+    'ga_small_linear_bwd': ([C.POINTER(SmallLinearDesc), vp, vp, i32, vp, vp, vp, vp], i32),
+    'ga_colstats': ([vp, i64, i32, i32, vp, vp, i32, vp], i32),
+    'ga_pad_copy_f32': ([vp, vp, i64, i64, i64, i64, i32, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

@@ -1,0 +1,214 @@
+// Alignment-free helpers for the odd-width variants (ga_convnext_{tiny,small}_688, base_976: ga_convnext.py:572-613).
+//
+// 688 / 8 = 86 and 688 / 4 = 172 channels per group put the per-group operands of the heads' grouped 1x1 convolutions
+// (gram_embedding, GroupConvMlp: ga_convnext.py:190-222,418-420) off the 16-byte grid every MFMA kernel of this library
+// loads on.  Those layers act on ONE token per image (M = batch rows), a few hundred MFLOP: they run here as LDS-tiled
+// fp32 products with element-wise (any alignment) loads, straight from the fp32 master weights -- no weight preparation,
+// no padding of the model.  The 172-wide stage-4 Bottleneck (50,176 rows) does use the MFMA kernels: its parameters are
+// copied into zero-padded 176-wide buffers by ga_pad_copy_f32 (and their gradients copied back).
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+// C[i][j] = sum_l a(i, l) * b(l, j) over a 32 x 64 tile per workgroup (256 threads: column j0 + (t & 63), 8 rows)
+template <typename FA, typename FB, typename FS>
+__device__ __forceinline__ void tiled_mm(int M, int N, int K, FA a, FB b, FS store) {
+    __shared__ float As[16][33], Bs[16][65];
+    const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 64;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int e = t; e < 16 * 32; e += 256) {
+            const int kk = e & 15, ii = e >> 4;            // consecutive threads walk l: the fast index of most operands
+            As[kk][ii] = (i0 + ii < M && k0 + kk < K) ? a(i0 + ii, k0 + kk) : 0.f;
+        }
+        for (int e = t; e < 16 * 64; e += 256) {
+            const int jj = e & 63, kk = e >> 6;
+            Bs[kk][jj] = (j0 + jj < N && k0 + kk < K) ? b(k0 + kk, j0 + jj) : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float bv = Bs[kk][tx];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = fmaf(As[kk][ty * 8 + r], bv, acc[r]);
+        }
+        __syncthreads();
+    }
+    if (j0 + tx < N) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (i0 + ty * 8 + r < M) store(i0 + ty * 8 + r, j0 + tx, acc[r]);
+    }
+}
+
+template <typename T> __device__ __forceinline__ float ldel(const void* p, long i) { return elt<T>::ld(reinterpret_cast<const T*>(p) + i); }
+template <typename T> __device__ __forceinline__ void stel(void* p, long i, float v) { elt<T>::st(reinterpret_cast<T*>(p) + i, v); }
+
+// Y[r][g*Ng + n] = R + rowscale * col_scale[.] * (sum_k A[r][acol(g*a_gstride + k)] W[g*Ng + n][k] + bias[.])
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const ga_small_linear_desc d) {
+    const int g = blockIdx.z;
+    const long abase = (long)g * d.a_gstride;
+    auto a = [&](int i, int l) {
+        const long c = abase + l;
+        return ldel<T>(d.A, (long)i * d.lda + (d.a_perm ? d.a_perm[c] : c));
+    };
+    auto b = [&](int l, int j) { return d.W[((long)g * d.Ng + j) * d.Kg + l]; };
+    auto st = [&](int i, int j, float v) {
+        const long n = (long)g * d.Ng + j;
+        if (d.bias) v += d.bias[n];
+        if (d.Yraw) stel<T>(d.Yraw, (long)i * d.ldy + n, v);
+        if (d.col_scale) v *= d.col_scale[n];
+        if (d.rowscale) v *= d.rowscale[i / d.rows_per_scale];
+        if (d.R) v += ldel<T>(d.R, (long)i * d.ldr + n);
+        stel<T>(d.Y, (long)i * d.ldy + n, v);
+    };
+    tiled_mm(d.rows, d.Ng, d.Kg, a, b, st);
+}
+
+// the gradient reaching the product: dY * rowscale * col_scale
+template <typename T> __device__ __forceinline__ float dy_eff(const ga_small_linear_desc& d, const void* dY, int r, long n) {
+    float v = ldel<T>(dY, (long)r * d.ldy + n);
+    if (d.col_scale) v *= d.col_scale[n];
+    if (d.rowscale) v *= d.rowscale[r / d.rows_per_scale];
+    return v;
+}
+
+// dA[r][acol(g*a_gstride + k)] (+)= sum_n dYeff[r][g*Ng + n] W[g*Ng + n][k]
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const ga_small_linear_desc d, const void* dY, void* dA, int accumulate) {
+    const int g = blockIdx.z;
+    const long abase = (long)g * d.a_gstride;
+    auto a = [&](int i, int l) { return dy_eff<T>(d, dY, i, (long)g * d.Ng + l); };
+    auto b = [&](int l, int j) { return d.W[((long)g * d.Ng + l) * d.Kg + j]; };
+    auto st = [&](int i, int j, float v) {
+        const long c = abase + j;
+        const long o = (long)i * d.lda + (d.a_perm ? d.a_perm[c] : c);
+        stel<T>(dA, o, accumulate ? v + ldel<T>(dA, o) : v);
+    };
+    tiled_mm(d.rows, d.Kg, d.Ng, a, b, st);
+}
+
+// dW[g*Ng + n][k] += sum_r dYeff[r][g*Ng + n] A[r][acol(g*a_gstride + k)]
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const ga_small_linear_desc d, const void* dY, float* dW) {
+    const int g = blockIdx.z;
+    const long abase = (long)g * d.a_gstride;
+    auto a = [&](int i, int l) { return dy_eff<T>(d, dY, l, (long)g * d.Ng + i); };
+    auto b = [&](int l, int j) {
+        const long c = abase + j;
+        return ldel<T>(d.A, (long)l * d.lda + (d.a_perm ? d.a_perm[c] : c));
+    };
+    auto st = [&](int i, int j, float v) { dW[((long)g * d.Ng + i) * d.Kg + j] += v; };
+    tiled_mm(d.Ng, d.Kg, d.rows, a, b, st);
+}
+
+// per output column n: dbias[n] += sum_r dYeff[r][n];  dcol_scale[n] += sum_r dY[r][n] * rowscale * Yraw[r][n]
+template <typename T>
+__global__ __launch_bounds__(256) void small_linear_colgrad_kernel(const ga_small_linear_desc d, const void* dY, float* dbias,
+                                                                   float* dcs) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= (long)d.groups * d.Ng) return;
+    float sb = 0.f, sc = 0.f;
+    for (int r = 0; r < d.rows; ++r) {
+        float v = ldel<T>(dY, (long)r * d.ldy + n);
+        if (d.rowscale) v *= d.rowscale[r / d.rows_per_scale];
+        if (dcs) sc = fmaf(v, ldel<T>(d.Yraw, (long)r * d.ldy + n), sc);
+        sb += d.col_scale ? v * d.col_scale[n] : v;
+    }
+    if (dbias) dbias[n] += sb;
+    if (dcs) dcs[n] += sc;
+}
+
+// column sums / sums of squares of x [rows][C] (row stride ld): the BatchNorm batch statistics the MFMA GEMM's epilogue
+// otherwise delivers
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const void* x, long ld, int rows, int C, float* s, float* q) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float v = ldel<T>(x, (long)r * ld + c);
+        a += v;
+        b = fmaf(v, v, b);
+    }
+    s[c] += a;
+    if (q) q[c] += b;
+}
+
+__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols,
+                                                       long lds, long ldd, int accumulate) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols, c = i - r * cols;
+        const float v = src[r * lds + c];
+        if (accumulate) dst[r * ldd + c] += v;
+        else dst[r * ldd + c] = v;
+    }
+}
+
+int check_desc(const ga_small_linear_desc* d, const char* what) {
+    GA_REQUIRE(d && d->A && d->W && d->rows > 0 && d->groups > 0 && d->Ng > 0 && d->Kg > 0, "%s: null / empty descriptor", what);
+    GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "%s: bad dtype", what);
+    GA_REQUIRE(!d->rowscale || d->rows_per_scale > 0, "%s: rows_per_scale", what);
+    return GA_OK;
+}
+
+}  // namespace
+
+extern "C" int ga_small_linear_fwd(const ga_small_linear_desc* d, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_small_linear_fwd")) return rc;
+    GA_REQUIRE(d->Y, "ga_small_linear_fwd: no output");
+    const dim3 grid((d->Ng + 63) / 64, (d->rows + 31) / 32, d->groups);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->dtype == GA_BF16) hipLaunchKernelGGL(small_linear_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, *d);
+    else hipLaunchKernelGGL(small_linear_fwd_kernel<float>, grid, dim3(256), 0, s, *d);
+    return ga_check_launch("ga_small_linear_fwd");
+}
+
+extern "C" int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY, void* dA, int accumulate_dA, float* dW, float* dbias,
+                                   float* dcol_scale, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_small_linear_bwd")) return rc;
+    GA_REQUIRE(dY, "ga_small_linear_bwd: no output gradient");
+    GA_REQUIRE(!dcol_scale || d->Yraw, "ga_small_linear_bwd: the column-scale gradient needs the stored pre-scale output (Yraw)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool bf = d->dtype == GA_BF16;
+    if (dA) {
+        const dim3 grid((d->Kg + 63) / 64, (d->rows + 31) / 32, d->groups);
+        if (bf) hipLaunchKernelGGL(small_linear_dgrad_kernel<bf16_t>, grid, dim3(256), 0, s, *d, dY, dA, accumulate_dA);
+        else hipLaunchKernelGGL(small_linear_dgrad_kernel<float>, grid, dim3(256), 0, s, *d, dY, dA, accumulate_dA);
+    }
+    if (dW) {
+        const dim3 grid((d->Kg + 63) / 64, (d->Ng + 31) / 32, d->groups);
+        if (bf) hipLaunchKernelGGL(small_linear_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, *d, dY, dW);
+        else hipLaunchKernelGGL(small_linear_wgrad_kernel<float>, grid, dim3(256), 0, s, *d, dY, dW);
+    }
+    if (dbias || dcol_scale) {
+        const int n = d->groups * d->Ng;
+        if (bf) hipLaunchKernelGGL(small_linear_colgrad_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
+        else hipLaunchKernelGGL(small_linear_colgrad_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
+    }
+    return ga_check_launch("ga_small_linear_bwd");
+}
+
+extern "C" int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && sum && rows > 0 && C > 0 && ld >= C, "ga_colstats: bad args");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
+    return ga_check_launch("ga_colstats");
+}
+
+extern "C" int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate,
+                               ga_stream_t stream) {
+    GA_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "ga_pad_copy_f32: bad args");
+    const long n = rows * cols;
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + 255) / 256));
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, (long)rows,
+                       (long)cols, (long)lds, (long)ldd, accumulate);
+    return ga_check_launch("ga_pad_copy_f32");
+}

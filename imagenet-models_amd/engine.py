@@ -411,7 +411,7 @@ class GAEngine:
     # effective weights (recorded into self.prep)
     # ------------------------------------------------------------------------------------------
     def _w_plain(self, name, Co, Ci, KH, KW, stem=False, need_T=True, flip=False, groups=1, rs=None, cs=None,
-                 row_perm=None, ldo=None, key=None):
+                 row_perm=None, ldo=None, key=None, src=None):
         """effective copy (and transposed copy when training) of a conv/linear weight; returns the forward copy"""
         key = key or name
         if key in self.W:
@@ -429,7 +429,7 @@ class GAEngine:
                 ldt = pad8(Co)
                 outT = self.buf('wT.' + key, (groups * KK, ldt))
             self.W[key + '.T'] = outT
-        self.prep.weight_prep(self.P[name], groups, Co, Ci, KH, KW, self.dt, out=out, ldo=ldo, outT=outT, ldt=ldt, rs=rs,
+        self.prep.weight_prep(self.P[name] if src is None else src, groups, Co, Ci, KH, KW, self.dt, out=out, ldo=ldo, outT=outT, ldt=ldt, rs=rs,
                               cs=cs, flip=flip, stem=stem, row_perm=row_perm, label='prep.' + key)
         self.W[key] = out
         return out
@@ -585,43 +585,73 @@ class GAEngine:
         self.bn_pool_off = off + C
         return self.bn_pool[off:off + C]
 
-    def _bn_bufs(self, pre, C):
+    def _bn_bufs(self, pre, C, zero=False):
         return dict(s=self._bn_pool(C), q=self._bn_pool(C),
-                    mean=self.buf(pre + 'bmean', (C,), torch.float32), rstd=self.buf(pre + 'brstd', (C,), torch.float32),
-                    scale=self.buf(pre + 'scale', (C,), torch.float32), shift=self.buf(pre + 'shift', (C,), torch.float32))
+                    mean=self.buf(pre + 'bmean', (C,), torch.float32, zero=zero), rstd=self.buf(pre + 'brstd', (C,), torch.float32, zero=zero),
+                    scale=self.buf(pre + 'scale', (C,), torch.float32, zero=zero), shift=self.buf(pre + 'shift', (C,), torch.float32, zero=zero))
 
     def _bn_finalize(self, pre, bn, n, C):
         self.fwd.bn_finalize(bn['s'], bn['q'], n, self.P[pre + 'weight'], self.P[pre + 'bias'], 1e-5, 0.1,
                              self.Bf[pre + 'running_mean'], self.Bf[pre + 'running_var'], bn['mean'], bn['rstd'],
                              bn['scale'], bn['shift'], C, self.training, label=pre + 'fin')
 
-    def _bn_bwd(self, pre, bn, dy, y_relu, x, dx, rows, C, rowscale=None, rps=1, ldx=0, lddx=0):
+    def _bn_bwd(self, pre, bn, dy, y_relu, x, dx, rows, C, rowscale=None, rps=1, ldx=0, lddx=0, weight=None, c_real=None):
+        """weight / c_real: the zero-padded copy of the BatchNorm weight and the real channel count of a padded branch"""
         Bk = self.bwd
         s1, s2 = self.gbuf((C,)), self.gbuf((C,))
         Bk.bn_bwd_reduce(dy, y_relu, x, bn['mean'], bn['rstd'], s1, s2, rows, C, self.dt, rowscale=rowscale,
                          rows_per_scale=rps, ldx=ldx, label=pre + 'bnr')
-        Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'], s1, s2, rows, dx, rows, C, self.dt,
-                        rowscale=rowscale, rows_per_scale=rps, ldx=ldx, lddx=lddx, label=pre + 'bna')
-        Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, C)
-        Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, C)
+        Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'] if weight is None else weight, s1, s2, rows, dx,
+                        rows, C, self.dt, rowscale=rowscale, rows_per_scale=rps, ldx=ldx, lddx=lddx, label=pre + 'bna')
+        Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, c_real or C)
+        Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, c_real or C)
 
     # ------------------------------------------------------------------------------------------
     # Bottleneck (ga_convnext.py:294-318)
     # ------------------------------------------------------------------------------------------
+    def _bott_pad(self, pre, w, wp, ctot, cout):
+        """odd-width variants (688 / 976: the Bottleneck is 172 / 244 channels wide, rows of 344 / 488 bytes): the branch runs
+        wp = pad8(w) channels wide on zero-padded COPIES of its parameters (ga_pad_copy_f32 in the weight-prep plan); the extra
+        channels carry exact zeros through conv / BN / ReLU / SE, their gradients are zero, and the real part of every
+        gradient is copied back after the backward pass.  Returns (params, pending gradient copies)."""
+        P = self.P
+        R = P[pre + 'se.fc1.weight'].shape[0]
+        spec = {'conv1.weight': ((wp, ctot), w, ctot, ctot, ctot), 'conv2.weight': ((wp, wp, 3, 3), w, 9 * w, 9 * w, 9 * wp),
+                'conv3.weight': ((cout, wp), cout, w, w, wp), 'se.fc1.weight': ((R, wp), R, w, w, wp),
+                'se.fc2.weight': ((wp, R), w, R, R, R), 'se.fc2.bias': ((wp,), 1, w, w, wp)}
+        for bn in ('bn1', 'bn2'):
+            spec[bn + '.weight'] = ((wp,), 1, w, w, wp)
+            spec[bn + '.bias'] = ((wp,), 1, w, w, wp)
+        PB, back = {}, []
+        for name, (shape, rows, cols, lds, ldd) in spec.items():
+            # (conv2: a source row is [ci][9], contiguous; the padded row [wp][9] holds it at its head)
+            buf = self.buf('pad.' + pre + name, shape, torch.float32, zero=True)
+            self.prep.pad_copy_f32(P[pre + name], buf, rows, cols, lds, ldd, label='prep.pad.' + pre + name)
+            PB[pre + name] = buf
+            back.append((name, rows, cols, lds, ldd))
+        return PB, back
+
     def _bottleneck_fwd(self, cat, M4, ctot, cout):
         F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
         pre = self.bott_prefix
-        w = cout // 4
+        w_real = cout // 4
+        w = pad8(w_real)
         HW = M4 // B
-        st = self.bott = dict(cat=cat, w=w, cout=cout, ctot=ctot)
+        st = self.bott = dict(cat=cat, w=w, w_real=w_real, cout=cout, ctot=ctot, PB=None)
+        if w != w_real:
+            st['PB'], st['back'] = self._bott_pad(pre, w_real, w, ctot, cout)
+            P = dict(P)                      # the padded copies shadow the Bottleneck's odd-width parameters
+            P.update(st['PB'])
+        st['P'] = P
         stats = T  # batch statistics only in train mode
 
-        def conv_bn(name, bnname, A, Wt, N, Kdim, bias=None, **kw):
+        def conv_bn(name, bnname, A, Wt, N, Kdim, bias=None, n_real=None, **kw):
             c = self.act(pre + name + '.out', (M4, N))
-            bn = self._bn_bufs(pre + bnname + '.', N)
+            bn = self._bn_bufs(pre + bnname + '.', N, zero=bool(n_real) and n_real != N)
             F.gemm(A, Wt, c, M4, N, Kdim, dt, bias=bias, colsum=bn['s'] if stats else None,
                    colsumsq=bn['q'] if stats else None, label=pre + name, **kw)
-            self._bn_finalize(pre + bnname + '.', bn, M4, N)
+            # (padded width: the statistics buffers are N wide, zero beyond the real channels -> scale = shift = 0 there)
+            self._bn_finalize(pre + bnname + '.', bn, M4, n_real or N)
             return c, bn
 
         # the shortcut branch (conv 1x1 of the 2208-channel concat + BN) only needs `cat`: it runs on the plan's
@@ -632,12 +662,12 @@ class GAEngine:
         t = self.tmp('bott.t', (M4, cout))
         F.affine_act(st['sc'], st['bnd']['scale'], st['bnd']['shift'], None, t, M4, cout, False, dt, label=pre + 'bnd')
         F.lane = 0
-        Wc1 = self._w_plain(pre + 'conv1.weight', w, ctot, 1, 1)
-        st['c1'], st['bn1'] = conv_bn('conv1', 'bn1', cat, Wc1, w, ctot)
+        Wc1 = self._w_plain(pre + 'conv1.weight', w, ctot, 1, 1, src=P[pre + 'conv1.weight'])
+        st['c1'], st['bn1'] = conv_bn('conv1', 'bn1', cat, Wc1, w, ctot, n_real=w_real)
         st['y1'] = self.act(pre + 'y1', (M4, w))
         F.affine_act(st['c1'], st['bn1']['scale'], st['bn1']['shift'], None, st['y1'], M4, w, True, dt, label=pre + 'bn1')
-        Wc2 = self._w_plain(pre + 'conv2.weight', w, w, 3, 3, flip=True)
-        st['c2'], st['bn2'] = conv_bn('conv2', 'bn2', st['y1'], Wc2, w, 9 * w, a_kind=A_CONV3, a_dims=(14, 14, w))
+        Wc2 = self._w_plain(pre + 'conv2.weight', w, w, 3, 3, flip=True, src=P[pre + 'conv2.weight'])
+        st['c2'], st['bn2'] = conv_bn('conv2', 'bn2', st['y1'], Wc2, w, 9 * w, n_real=w_real, a_kind=A_CONV3, a_dims=(14, 14, w))
         st['y2'] = self.act(pre + 'y2', (M4, w))
         F.affine_act(st['c2'], st['bn2']['scale'], st['bn2']['shift'], None, st['y2'], M4, w, True, dt, label=pre + 'bn2')
         # squeeze-excite
@@ -651,7 +681,7 @@ class GAEngine:
                      P[pre + 'se.fc2.bias'], st['hid'], st['gate'], B, w, R, label=pre + 'se.mlp')
         st['z'] = self.act(pre + 'se.z', (M4, w))
         F.chan_scale(st['y2'], st['gate'], None, st['z'], B, HW, w, dt, label=pre + 'se.scale')
-        Wc3 = self._w_plain(pre + 'conv3.weight', cout, w, 1, 1)
+        Wc3 = self._w_plain(pre + 'conv3.weight', cout, w, 1, 1, src=P[pre + 'conv3.weight'])
         st['c3'], st['bn3'] = conv_bn('conv3', 'bn3', st['z'], Wc3, cout, w)
         x4 = self.buf(pre + 'out', (M4, cout))
         if self.par_branch:
@@ -662,10 +692,16 @@ class GAEngine:
         return x4
 
     def _bottleneck_bwd(self, dx4, dcat):
-        Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
+        Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.bott['P'], self.W
         pre = self.bott_prefix
         st = self.bott
         w, cout, ctot = st['w'], st['cout'], st['ctot']
+        padded = st['PB'] is not None
+        GB = {pre + name: self.gbuf(tuple(st['PB'][pre + name].shape)) for name, *_ in st['back']} if padded else {}
+
+        def grad(name):          # gradient buffer of a Bottleneck parameter: the zeroed padded one where the branch is padded
+            return GB[name] if name in GB else self.grad(name)
+
         M4 = dx4.shape[0]
         HW = M4 // B
         dp = self.dp_scale.get(pre)
@@ -680,7 +716,7 @@ class GAEngine:
             Bk.gemm(dsc, W[pre + 'downsample.0.weight.T'], dcat, M4, ctot, cout, dt, ldb=pad8(cout), label=pre + 'ds.dg')
         # conv3
         with self._wlane():
-            Bk.wgrad(dc3, st['z'], self.grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
+            Bk.wgrad(dc3, st['z'], grad(pre + 'conv3.weight'), M4, cout, w, dt, label=pre + 'conv3.wg')
         dz = self.tmp('bott.dz', (M4, w))
         Bk.gemm(dc3, W[pre + 'conv3.weight.T'], dz, M4, w, cout, dt, label=pre + 'conv3.dg')
         # squeeze-excite
@@ -688,28 +724,36 @@ class GAEngine:
         dsp = self.tmp('bott.dsp', (B, w), torch.float32)
         Bk.spatial_sum(dz, st['y2'], dgate, B, HW, w, 1.0, dt, label=pre + 'se.dgate')
         Bk.se_mlp_bwd(dgate, st['gate'], st['hid'], st['sp'], P[pre + 'se.fc1.weight'], P[pre + 'se.fc2.weight'], dsp,
-                      self.grad(pre + 'se.fc1.weight'), self.grad(pre + 'se.fc1.bias'), self.grad(pre + 'se.fc2.weight'),
-                      self.grad(pre + 'se.fc2.bias'), B, w, st['R'], ds_scale=1.0 / HW, label=pre + 'se.mlpb')
+                      grad(pre + 'se.fc1.weight'), grad(pre + 'se.fc1.bias'), grad(pre + 'se.fc2.weight'),
+                      grad(pre + 'se.fc2.bias'), B, w, st['R'], ds_scale=1.0 / HW, label=pre + 'se.mlpb')
         dy2 = self.tmp('bott.dy2', (M4, w))
         Bk.chan_scale(dz, st['gate'], dsp, dy2, B, HW, w, dt, label=pre + 'se.back')
         dc2 = self.tmp('bott.dc2', (M4, w))
-        self._bn_bwd(pre + 'bn2.', st['bn2'], dy2, st['y2'], st['c2'], dc2, M4, w)
+        self._bn_bwd(pre + 'bn2.', st['bn2'], dy2, st['y2'], st['c2'], dc2, M4, w, weight=P[pre + 'bn2.weight'] if padded else None,
+                     c_real=st['w_real'])
         # conv2 3x3
         G = self.gbuf((w, 9 * w))
         with self._wlane():
             Bk.wgrad(dc2, st['y1'], G, M4, w, 9 * w, dt, x_kind=A_CONV3, x_dims=(14, 14, w), label=pre + 'conv2.wg')
-        Bk.weight_unfold(G, 9 * w, w, w, 3, 3, dW=self.grad(pre + 'conv2.weight'), label=pre + 'conv2.unf')
+        Bk.weight_unfold(G, 9 * w, w, w, 3, 3, dW=grad(pre + 'conv2.weight'), label=pre + 'conv2.unf')
         dy1 = self.tmp('bott.dy1', (M4, w))
         Bk.gemm(dc2, W[pre + 'conv2.weight.T'], dy1, M4, w, 9 * w, dt, a_kind=A_CONV3, a_dims=(14, 14, w),
                 ldb=pad8(9 * w), label=pre + 'conv2.dg')
         dc1 = self.tmp('bott.dc1', (M4, w))
-        self._bn_bwd(pre + 'bn1.', st['bn1'], dy1, st['y1'], st['c1'], dc1, M4, w)
+        self._bn_bwd(pre + 'bn1.', st['bn1'], dy1, st['y1'], st['c1'], dc1, M4, w, weight=P[pre + 'bn1.weight'] if padded else None,
+                     c_real=st['w_real'])
         # conv1 and the shortcut conv both read `cat`; conv1's dgrad adds onto the shortcut's (already written) dcat
         with self._wlane():
-            Bk.wgrad(dc1, st['cat'], self.grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
+            Bk.wgrad(dc1, st['cat'], grad(pre + 'conv1.weight'), M4, w, ctot, dt, label=pre + 'conv1.wg')
         if self.async_wgrad:
             Bk.join_async()
         Bk.gemm(dc1, W[pre + 'conv1.weight.T'], dcat, M4, ctot, w, dt, ldb=pad8(w), R=dcat, ldr=ctot, label=pre + 'conv1.dg')
+        if padded:     # the real part of every padded gradient back into the parameter's gradient (the weight-gradient lane has joined)
+            skip = ('bn1.weight', 'bn1.bias', 'bn2.weight', 'bn2.bias')       # accumulated by _bn_bwd at the real width
+            Bk.flush(pre + 'pad.')      # the deferred weight-unfold job of conv2 writes the padded gradient: run it first
+            for name, rows, cols, lds, ldd in st['back']:
+                if name not in skip:
+                    Bk.pad_copy_f32(GB[pre + name], self.grad(pre + name), rows, cols, ldd, lds, accumulate=True, label=pre + name + '.unpad')
 
     # ------------------------------------------------------------------------------------------
     # one GA head (ga_convnext.py:491-504)
@@ -729,9 +773,26 @@ class GAEngine:
         gc_ = Hd // mg
         Nv = gc_ // mg          # rows per virtual group (fc1 input group is constant inside one)
         cin = C // mg
-        assert gc_ % mg == 0 and Nv % 8 == 0 and cin % 8 == 0, (pre, C, mg)
         n_idx = torch.arange(Hd)
         perm = ((n_idx % gc_) * mg + n_idx // gc_).to(torch.int32).to(self.dev)
+        if Nv % 8 or cin % 8:
+            # odd widths (688 / 4 = 172 channels per group): one-token layers on the alignment-free kernels, fp32 master weights,
+            # the channel_shuffle as a column map of fc2's input (hidden kept in the ORIGINAL channel order, pre-activation saved)
+            assert act == 'gelu' and drop_mask is None and rows <= 4096, (pre, C, mg, rows)
+            st = dict(naive=True, Hd=Hd, hpre=self.act(pre + 'hpre', (rows, Hd)), am=self.act(pre + 'am', (rows, Hd)),
+                      yraw=self.act(pre + 'yraw', (rows, C)) if T else None)
+            st['d1'] = F.small_linear_desc(t, P[pre + 'fc1.weight'], st['hpre'], rows, mg, gc_, cin, dt, lda=C, a_gstride=cin, ldy=Hd,
+                                           bias=P[pre + 'fc1.bias'])
+            F.small_linear_fwd(st['d1'], label=pre + 'fc1')
+            F.gelu_fwd(st['hpre'], st['am'], rows * Hd, dt, label=pre + 'gelu')
+            kw = dict(bias=P[pre + 'fc2.bias'], a_perm=perm, col_scale=gamma, Yraw=st['yraw'])
+            d2 = F.small_linear_desc(st['am'], P[pre + 'fc2.weight'], out, rows, mg, cin, gc_, dt, lda=Hd, a_gstride=gc_, ldy=C,
+                                     rowscale=rowscale, rows_per_scale=rps, R=R, ldr=C, **kw)
+            F.small_linear_fwd(d2, label=pre + 'fc2')
+            # the backward sees a gradient that already carries the DropPath scale: same layer without the row scale
+            st['d2b'] = F.small_linear_desc(st['am'], P[pre + 'fc2.weight'], out, rows, mg, cin, gc_, dt, lda=Hd, a_gstride=gc_, ldy=C, **kw)
+            return st
+        assert gc_ % mg == 0, (pre, C, mg)
         Wm1 = self._w_plain(pre + 'fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
         bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
@@ -763,6 +824,15 @@ class GAEngine:
         """dmz: gradient wrt the MLP branch output (DropPath scale already applied) -> dtk = gradient wrt the input t"""
         Bk, dt, P, W = self.bwd, self.dt, self.P, self.W
         gamma = P[gamma_name] if gamma_name else None
+        if st.get('naive'):
+            Hd = st['Hd']
+            dam, dh = self.tmp('dam', (rows, Hd)), self.tmp('dhm', (rows, Hd))
+            Bk.small_linear_bwd(st['d2b'], dmz, dA=dam, dW=self.grad(pre + 'fc2.weight'), dbias=self.grad(pre + 'fc2.bias'),
+                                dcol_scale=self.grad(gamma_name) if gamma_name else None, label=pre + 'fc2.bwd')
+            Bk.gelu_bwd(dam, st['hpre'], dh, rows * Hd, dt, label=pre + 'geluB')
+            Bk.small_linear_bwd(st['d1'], dh, dA=dtk, dW=self.grad(pre + 'fc1.weight'), dbias=self.grad(pre + 'fc1.bias'),
+                                label=pre + 'fc1.bwd')
+            return
         Hd, gc_, Nv, cin = st['Hd'], st['gc'], st['Nv'], st['cin']
         # fc2 (mg groups)
         Gm2, gbm2 = self.gbuf((C, gc_)), self.gbuf((C,))
@@ -792,7 +862,9 @@ class GAEngine:
     def _head_supported(self):
         cfg, cout = self.cfg, self.cout
         g, E, nh, mg, groups = cfg['gram_dim'], cfg['dim_embed'], cfg['num_heads'], cfg['mlp_groups'], cfg['gram_groups']
-        return E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % (8 * groups) == 0 and cout % (8 * mg) == 0
+        # (cout / groups and cout / mg need NOT be multiples of 8: the 688 / 976 variants run those grouped one-token layers
+        #  on the alignment-free ga_small_linear kernels)
+        return E % nh == 0 and E % 8 == 0 and g % 8 == 0 and cout % 8 == 0 and cout % groups == 0 and cout % mg == 0
 
     def _head_fwd(self, k, x4, M4, cout, Hc):
         cfg = self.cfg
@@ -860,12 +932,20 @@ class GAEngine:
         # --- gram_embedding: grouped 1x1 + BN on (B, cout)
         pre = f'gram_embedding.{k}.'
         cg = cout // groups
-        Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp)
         h['e'] = self.act(pre + 'out', (B, cout))
         h['bn_e'] = self._bn_bufs(pre + '1.', cout)
-        F.gemm(h['vec'], Wemb, h['e'], B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
-               ldc=cout, strideC=cg, bias=P[pre + '0.bias'], strideBias=cg, colsum=h['bn_e']['s'] if T else None,
-               colsumsq=h['bn_e']['q'] if T else None, strideCol=cg, label=pre + 'conv')
+        h['emb_small'] = None
+        if cg % 8:      # 688 / 8 = 86 (976 / 8 = 122) channels per group: off the 16-byte grid -> alignment-free form on the master weights
+            h['emb_small'] = F.small_linear_desc(h['vec'], P[pre + '0.weight'], h['e'], B, groups, cg, Kg, dt, lda=groups * Kp,
+                                                 a_gstride=Kp, ldy=cout, bias=P[pre + '0.bias'])
+            F.small_linear_fwd(h['emb_small'], label=pre + 'conv')
+            if T:
+                F.colstats(h['e'], cout, B, cout, h['bn_e']['s'], h['bn_e']['q'], dt, label=pre + 'stats')
+        else:
+            Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp)
+            F.gemm(h['vec'], Wemb, h['e'], B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
+                   ldc=cout, strideC=cg, bias=P[pre + '0.bias'], strideBias=cg, colsum=h['bn_e']['s'] if T else None,
+                   colsumsq=h['bn_e']['q'] if T else None, strideCol=cg, label=pre + 'conv')
         self._bn_finalize(pre + '1.', h['bn_e'], B, cout)
         h['cls0'] = self.buf(pre + 'cls0', (B, cout))
         F.affine_act(h['e'], h['bn_e']['scale'], h['bn_e']['shift'], None, h['cls0'], B, cout, False, dt, label=pre + 'bn')
@@ -1012,11 +1092,14 @@ class GAEngine:
         de = self.tmp('de', (B, cout))
         self._bn_bwd(pre + '1.', h['bn_e'], dcls1, None, h['e'], de, B, cout)
         gW = self.grad(pre + '0.weight')
-        Bk.wgrad(de, h['vec'], gW, B, cg, Kg, dt, ldy=cout, ldx=groups * Kp, ldw=Kg, batch=groups, strideY=cg, strideX=Kp,
-                 strideW=cg * Kg, dbias=self.grad(pre + '0.bias'), strideDbias=cg, label=pre + 'wg')
         dvec = self.buf(f'gram.{k}.dvec', (B, groups * Kp), zero=True)   # pad columns stay zero
-        Bk.gemm(de, W[pre + '0.weight.T'], dvec, B, Kg, cg, dt, lda=cout, batch=groups, strideA=cg, strideB=Kg * pad8(cg),
-                ldb=pad8(cg), ldc=groups * Kp, strideC=Kp, label=pre + 'dg')
+        if h['emb_small'] is not None:
+            Bk.small_linear_bwd(h['emb_small'], de, dA=dvec, dW=gW, dbias=self.grad(pre + '0.bias'), label=pre + 'bwd')
+        else:
+            Bk.wgrad(de, h['vec'], gW, B, cg, Kg, dt, ldy=cout, ldx=groups * Kp, ldw=Kg, batch=groups, strideY=cg, strideX=Kp,
+                     strideW=cg * Kg, dbias=self.grad(pre + '0.bias'), strideDbias=cg, label=pre + 'wg')
+            Bk.gemm(de, W[pre + '0.weight.T'], dvec, B, Kg, cg, dt, lda=cout, batch=groups, strideA=cg, strideB=Kg * pad8(cg),
+                    ldb=pad8(cg), ldc=groups * Kp, strideC=Kp, label=pre + 'dg')
         S = self.tmp('gramS', (B, g, g))
         Bk.gram_pack_bwd(dvec, h['vec'], h['inv'], S, B, g, groups, Kp, dt, label=f'gram.{k}.packb')
         dg1 = self.tmp('dg1', (M4, g))

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .flat_model import FlatModel, Holder as _Holder
-from .registry import mark_unsupported, register_model
+from .registry import register_model
 
 __all__ = ['GA_ConvNeXt']
 
@@ -205,9 +205,3 @@ def ga_convnext_small(pretrained=False, **kwargs):
 @register_model
 def ga_convnext_base(pretrained=False, **kwargs):
     return ga_convnext_base_1024(pretrained, **kwargs)
-
-
-for _n in ('ga_convnext_tiny_688', 'ga_convnext_small_688', 'ga_convnext_base_976'):
-    mark_unsupported(_n, 'constructs (reference parameter layout, checkpoints load) but the HIP engine refuses it: the 172 / 244-wide '
-                         'Bottleneck and the 86 / 172 / 122 / 244-channel groups of the head are off the 16-byte grid (padded layouts not '
-                         'built); use the *_768 / *_1024 variants')

@@ -337,6 +337,31 @@ class Plan:
         d.colsum, d.colsumsq, d.strideCol = _ptr(colsum), _ptr(colsumsq), strideCol
         self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq, C2))
 
+    # -- alignment-free forms (odd-width variants) -------------------------------------------------
+    def small_linear_desc(self, A, W, Y, rows, groups, Ng, Kg, dtype, lda, a_gstride, ldy, bias=None, a_perm=None, col_scale=None,
+                          rowscale=None, rows_per_scale=1, R=None, ldr=0, Yraw=None):
+        d = L.SmallLinearDesc()
+        d.rows, d.groups, d.Ng, d.Kg, d.dtype = rows, groups, Ng, Kg, dtype
+        d.A, d.lda, d.a_gstride, d.a_perm = _ptr(A), lda, a_gstride, _ptr(a_perm)
+        d.W, d.bias, d.col_scale = _ptr(W), _ptr(bias), _ptr(col_scale)
+        d.rowscale, d.rows_per_scale, d.R, d.ldr = _ptr(rowscale), rows_per_scale, _ptr(R), ldr
+        d.Y, d.ldy, d.Yraw = _ptr(Y), ldy, _ptr(Yraw)
+        self.keep.extend([d, A, W, Y, bias, a_perm, col_scale, rowscale, R, Yraw])
+        return d
+
+    def small_linear_fwd(self, d, label=None):
+        self._add('ga_small_linear_fwd', (C.byref(d),), label, keep=(d,))
+
+    def small_linear_bwd(self, d, dY, dA=None, accumulate_dA=False, dW=None, dbias=None, dcol_scale=None, label=None):
+        self._add('ga_small_linear_bwd', (C.byref(d), _ptr(dY), _ptr(dA), int(accumulate_dA), _ptr(dW), _ptr(dbias), _ptr(dcol_scale)),
+                  label, keep=(d, dY, dA, dW, dbias, dcol_scale))
+
+    def colstats(self, x, ld, rows, Cdim, s, q, dtype, label=None):
+        self._add('ga_colstats', (_ptr(x), ld, rows, Cdim, _ptr(s), _ptr(q), dtype), label, keep=(x, s, q))
+
+    def pad_copy_f32(self, src, dst, rows, cols, lds, ldd, accumulate=False, label=None):
+        self._add('ga_pad_copy_f32', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate)), label, keep=(src, dst))
+
     def mlp_fwd(self, X, W1, b1, W2, b2, Y, M, Cdim, dtype, ldw1=None, ldw2=None, R=None, rowscale=None, rows_per_scale=1, label=None):
         """fused fc1 -> GELU -> fc2 (+ DropPath row scale + residual): Y = R + rowscale * (gelu(X W1^T + b1) W2^T + b2)"""
         d = L.MlpDesc()

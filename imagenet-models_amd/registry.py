@@ -8,12 +8,18 @@ _entrypoints = {}
 _unsupported = {}   # name -> reason: registered for state_dict / checkpoint compatibility, refused by the HIP engine
 
 
-def register_model(fn):
-    _entrypoints[fn.__name__] = fn
-    mod = sys.modules[fn.__module__]
-    if hasattr(mod, '__all__') and fn.__name__ not in mod.__all__:
-        mod.__all__.append(fn.__name__)
+def register_model(fn, name=None):
+    name = name or fn.__name__
+    _entrypoints[name] = fn
+    mod = sys.modules.get(fn.__module__)
+    if name == fn.__name__ and mod is not None and hasattr(mod, '__all__') and name not in mod.__all__:
+        mod.__all__.append(name)
     return fn
+
+
+def _unregister(name):
+    _entrypoints.pop(name, None)
+    _unsupported.pop(name, None)
 
 
 def is_model(name):

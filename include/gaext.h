@@ -489,6 +489,32 @@ int ga_mlp_supported(int C, int H, int dtype);
 int ga_mlp_fwd(const ga_mlp_desc* d, ga_stream_t stream);
 int ga_mlp_bwd(const ga_mlp_bwd_desc* d, ga_stream_t stream);
 
+/* Alignment-free forms for the odd-width variants (ga_convnext_*_688, base_976: 86 / 172 / 122 / 244 channels per group are off
+ * the 16-byte grid of the MFMA kernels).  The heads' grouped 1x1 convolutions act on one token per image (rows = batch):
+ *   ga_small_linear_fwd: Y[r][g*Ng + n] = R + rowscale[r / rps] * col_scale[.] * (sum_k A[r][col(g*a_gstride + k)] W[g*Ng + n][k] + bias[.])
+ *     A / Y / R / Yraw in `dtype`, element-wise loads (any alignment); W [groups*Ng][Kg], bias, col_scale: the fp32 MASTER
+ *     parameters, no weight preparation; col(c) = a_perm ? a_perm[c] : c (the channel_shuffle of GroupConvMlp, ga_convnext.py:557-566);
+ *     Yraw (optional, leading dimension ldy) keeps the value before col_scale for the col_scale gradient.
+ *   ga_small_linear_bwd (same descriptor): dA (+)= dYeff W;  dW += dYeff^T A;  dbias += colsum(dYeff);  dcol_scale += colsum(dY * rowscale * Yraw)
+ *     with dYeff = dY * rowscale * col_scale; any of dA / dW / dbias / dcol_scale may be NULL.
+ *   ga_colstats: sum[c] += sum_r x[r][c], sumsq[c] += sum_r x^2 (the BatchNorm batch statistics ga_gemm's epilogue otherwise delivers).
+ *   ga_pad_copy_f32: dst[r][0..cols) (+)= src[r][0..cols), row strides lds / ldd in elements: parameters of the 172 / 244-wide stage-4
+ *     Bottleneck into zero-padded 176 / 248-wide buffers for the MFMA kernels, and their gradients back. */
+typedef struct {
+    int rows, groups, Ng, Kg;
+    const void* A; int64_t lda; int64_t a_gstride; const int* a_perm;
+    const float* W; const float* bias; const float* col_scale;
+    const float* rowscale; int rows_per_scale;
+    const void* R; int64_t ldr;
+    void* Y; int64_t ldy; void* Yraw;
+    int dtype;
+} ga_small_linear_desc;
+int ga_small_linear_fwd(const ga_small_linear_desc* d, ga_stream_t stream);
+int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY, void* dA, int accumulate_dA, float* dW, float* dbias,
+                        float* dcol_scale, ga_stream_t stream);
+int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream);
+int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */

@@ -148,6 +148,12 @@ def do_train_fp64(tag, cfg, batch, lam=-0.8):
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
+    if '--odd-widths-only' in sys.argv:      # the 688 / 976 variants (a14), added in round 2
+        t688 = O.make_cfg('ga_convnext_tiny_688')
+        do_eval('t688', t688, 2, 16)
+        do_train('t688', t688, 4)
+        do_eval('b976', O.make_cfg('ga_convnext_base_976'), 2, 16)
+        sys.exit(0)
     if '--fp64-only' in sys.argv:      # the float64 ground-truth fixtures need only the oracle
         do_train_fp64('v2', O.make_cfg(**V2), 4)
         do_train_fp64('t768', O.make_cfg('ga_convnext_tiny_768'), 4)
@@ -163,4 +169,8 @@ if __name__ == '__main__':
     do_train_fp64('t768', t768, 4)
     b1024 = O.make_cfg('ga_convnext_base_1024')
     do_eval('b1024', b1024, 2, 16)
+    t688 = O.make_cfg('ga_convnext_tiny_688')
+    do_eval('t688', t688, 2, 16)
+    do_train('t688', t688, 4)
+    do_eval('b976', O.make_cfg('ga_convnext_base_976'), 2, 16)
     print('golden vectors written to', OUT)

@@ -61,18 +61,28 @@ def test_descriptor_structs_match_header_field_order():
 
 def test_registry_and_factories():
     import imagenet_models_amd as A
-    names = A.list_models(include_unsupported=True)
-    assert 'ga_convnext_tiny_688' not in A.list_models() and 'ga_convnext_tiny_768' in A.list_models()
+    import warnings
+    from imagenet_models_amd import registry
+    names = A.list_models()
     for n in ('ga_convnext_tiny_688', 'ga_convnext_tiny_768', 'ga_convnext_small_688', 'ga_convnext_small_768',
-              'ga_convnext_base_976', 'ga_convnext_base_1024'):
-        assert n in names and A.is_model(n)
+              'ga_convnext_base_976', 'ga_convnext_base_1024'):      # all six registered variants (ga_convnext.py:572-613) run on the engine
+        assert n in names and A.is_model(n) and registry.is_supported(n)
     # timm create_model drops None kwargs (GA/train.py:407-420 passes many that are None)
-    with pytest.warns(UserWarning, match='refuses'):
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
         m = A.create_model('ga_convnext_tiny_688', pretrained=False, num_classes=10, drop_rate=None, drop_path_rate=0.1,
                            drop_block_rate=None, global_pool=None, bn_momentum=None, bn_eps=None, scriptable=None)
     assert m.num_classes == 10 and m.cfg['dims'][-1] == 688 and m.cfg['dim_embed'] == 168
-    with pytest.warns(UserWarning):
-        assert sum(p.numel() for p in A.create_model('ga_convnext_tiny_688').parameters()) == 47821324
+    assert sum(p.numel() for p in A.create_model('ga_convnext_tiny_688').parameters()) == 47821324
+    # an entry point the engine cannot run stays constructible but is hidden from list_models() and warns when created
+    registry.register_model(lambda pretrained=False, **kw: A.create_model('ga_convnext_tiny_768', **kw), name='_test_unsupported_entry')
+    registry.mark_unsupported('_test_unsupported_entry', 'refuses: test entry')
+    try:
+        assert '_test_unsupported_entry' not in A.list_models() and '_test_unsupported_entry' in A.list_models(include_unsupported=True)
+        with pytest.warns(UserWarning, match='refuses'):
+            A.create_model('_test_unsupported_entry')
+    finally:
+        registry._unregister('_test_unsupported_entry')
     with pytest.raises(RuntimeError):
         A.create_model('ga_convnext_tiny_768', pretrained=True)
     with pytest.raises(RuntimeError):

@@ -508,13 +508,62 @@ def test_variant_train_step_fp32_vs_oracle(name):
     assert worst[0][1] < 3e-2, worst
 
 
-def test_688_variants_fail_loudly():
-    """*_688 / *_976: 86 / 172 / 122 / 244 channels per group are not multiples of 8 -- refused with a clear message
-    (no silent fallback); parameter layout and registry entries exist (tests/test_host_cpu.py)"""
+@pytest.mark.parametrize('name,golden', [('ga_convnext_tiny_688', 't688_eval.npz'), ('ga_convnext_base_976', 'b976_eval.npz')])
+@pytest.mark.parametrize('mode,tol', [('fp32', 1e-3), ('bf16', 6e-2)])
+def test_odd_width_variants_eval_vs_reference_golden(name, golden, mode, tol):
+    """*_688 / *_976 (ga_convnext.py:572-613): 86 / 172 / 122 / 244 channels per group and a 172 / 244-wide Bottleneck -- the
+    grouped one-token layers of the heads run on the alignment-free kernels, the Bottleneck on zero-padded parameter copies;
+    logits vs the REAL reference's golden (<= 1e-3 in fp32 mode), top-5 bit-exact"""
     import imagenet_models_amd as A
-    m = A.create_model('ga_convnext_tiny_688').cuda().eval()
-    with pytest.raises(NotImplementedError, match='per-group channel counts'):
-        m(torch.zeros(1, 3, 224, 224, device='cuda'))
+    O = _oracle()
+    z, cfg = load_golden(golden)
+    m = A.create_model(name, math_mode=mode)
+    m.load_state_dict(O.fill_state(cfg))
+    m = m.cuda().eval()
+    x = O.gen_input(int(z['batch']), seed=0)
+    with torch.no_grad():
+        outs = m(x.cuda())
+    err = rel(torch.stack(outs)[:, :, :16], torch.from_numpy(z['logits']))
+    print(f'[{name} {mode}] eval logits rel err vs reference golden {err:.3e}')
+    assert err < tol
+    if mode == 'fp32':
+        _, idx = A.heads_topk(outs, 5)
+        assert np.array_equal(idx.cpu().numpy(), z['top5'])
+
+
+@pytest.mark.parametrize('mode,tols', [('fp32', (1e-3, 1e-3, 2e-2)), ('bf16', (6e-2, 2e-2, 0.6))])
+def test_tiny_688_train_step_vs_oracle_and_reference(mode, tols):
+    """one train step of ga_convnext_tiny_688 at B = 4 against the oracle (every gradient) and the reference golden (logits, loss)"""
+    import imagenet_models_amd as A
+    O = _oracle()
+    z, cfg = load_golden('t688_train_b4.npz')
+    m = A.create_model('ga_convnext_tiny_688', math_mode=mode)
+    sd = O.fill_state(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    x = O.gen_input(4, seed=1)
+    target = torch.from_numpy(z['target'])
+    m.zero_grad()
+    outs = m(x.cuda())
+    loss = A.ga_loss(outs, target.cuda(), float(z['lam']))
+    loss.backward()
+    oloss, oouts, ograds, ostats = O.train_step_grads(sd, x, target, cfg, lam=float(z['lam']))
+    e_out = max(rel(a, b) for a, b in zip(outs, oouts))
+    e_loss = abs(float(loss) - float(oloss)) / abs(float(oloss))
+    grads = {n: p.grad.detach().cpu() for n, p in m.named_parameters()}
+    errs = O.grad_errors(grads, ograds)
+    if mode == 'bf16':
+        gmax = max(float(g_.abs().max()) for g_ in ograds.values())
+        errs = {n: e for n, e in errs.items() if float(ograds[n].abs().max()) >= 1e-4 * gmax}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    new_sd = m.state_dict()
+    e_bn = max(rel(new_sd[n], ostats[n].float()) for n in ostats if not n.endswith('num_batches_tracked'))
+    print(f'[tiny_688 {mode}] logits {e_out:.2e} loss {e_loss:.2e} bn {e_bn:.2e} worst grads {worst}')
+    assert e_out < tols[0] and e_loss < tols[1] and worst[0][1] < tols[2], worst
+    assert e_bn < max(tols[0], 2e-3)
+    if mode == 'fp32':
+        assert rel(torch.stack(outs)[:, :, :40], torch.from_numpy(z['logits'])) < 1e-3
+        assert abs(float(loss) - float(z['loss'])) / abs(float(z['loss'])) < 1e-3
 
 
 def _train_losses(monkeypatch, lanes_on, steps=6, batch=16):
