@@ -11,22 +11,24 @@
 
 namespace {
 
-// C[i][j] = sum_l a(i, l) * b(l, j) over a 32 x 64 tile per workgroup (256 threads: column j0 + (t & 63), 8 rows)
-template <typename FA, typename FB, typename FS>
+// C[i][j] = sum_l a(i, l) * b(l, j) over a TM x 64 tile per workgroup (256 threads: column j0 + (t & 63), TM / 4 rows each).
+// AL / BL: the operand's memory-contiguous index is l (else i resp. j) -- consecutive threads then walk that index.
+template <int TM, bool AL, bool BL, typename FA, typename FB, typename FS>
 __device__ __forceinline__ void tiled_mm(int M, int N, int K, FA a, FB b, FS store) {
-    __shared__ float As[16][33], Bs[16][65];
+    constexpr int RPT = TM / 4;
+    __shared__ float As[16][TM + 1], Bs[16][65];
     const int t = threadIdx.x, tx = t & 63, ty = t >> 6;
-    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 64;
-    float acc[8];
+    const int i0 = blockIdx.y * TM, j0 = blockIdx.x * 64;
+    float acc[RPT];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RPT; ++r) acc[r] = 0.f;
     for (int k0 = 0; k0 < K; k0 += 16) {
-        for (int e = t; e < 16 * 32; e += 256) {
-            const int kk = e & 15, ii = e >> 4;            // consecutive threads walk l: the fast index of most operands
+        for (int e = t; e < 16 * TM; e += 256) {
+            const int kk = AL ? e & 15 : e / TM, ii = AL ? e >> 4 : e % TM;
             As[kk][ii] = (i0 + ii < M && k0 + kk < K) ? a(i0 + ii, k0 + kk) : 0.f;
         }
         for (int e = t; e < 16 * 64; e += 256) {
-            const int jj = e & 63, kk = e >> 6;
+            const int kk = BL ? e & 15 : e >> 6, jj = BL ? e >> 4 : e & 63;
             Bs[kk][jj] = (j0 + jj < N && k0 + kk < K) ? b(k0 + kk, j0 + jj) : 0.f;
         }
         __syncthreads();
@@ -34,14 +36,14 @@ __device__ __forceinline__ void tiled_mm(int M, int N, int K, FA a, FB b, FS sto
         for (int kk = 0; kk < 16; ++kk) {
             const float bv = Bs[kk][tx];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r] = fmaf(As[kk][ty * 8 + r], bv, acc[r]);
+            for (int r = 0; r < RPT; ++r) acc[r] = fmaf(As[kk][ty * RPT + r], bv, acc[r]);
         }
         __syncthreads();
     }
     if (j0 + tx < N) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (i0 + ty * 8 + r < M) store(i0 + ty * 8 + r, j0 + tx, acc[r]);
+        for (int r = 0; r < RPT; ++r)
+            if (i0 + ty * RPT + r < M) store(i0 + ty * RPT + r, j0 + tx, acc[r]);
     }
 }
 
@@ -49,7 +51,7 @@ template <typename T> __device__ __forceinline__ float ldel(const void* p, long 
 template <typename T> __device__ __forceinline__ void stel(void* p, long i, float v) { elt<T>::st(reinterpret_cast<T*>(p) + i, v); }
 
 // Y[r][g*Ng + n] = R + rowscale * col_scale[.] * (sum_k A[r][acol(g*a_gstride + k)] W[g*Ng + n][k] + bias[.])
-template <typename T>
+template <typename T, int TM>
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const ga_small_linear_desc d) {
     const int g = blockIdx.z;
     const long abase = (long)g * d.a_gstride;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const ga_small_li
         if (d.R) v += ldel<T>(d.R, (long)i * d.ldr + n);
         stel<T>(d.Y, (long)i * d.ldy + n, v);
     };
-    tiled_mm(d.rows, d.Ng, d.Kg, a, b, st);
+    tiled_mm<TM, true, true>(d.rows, d.Ng, d.Kg, a, b, st);
 }
 
 // the gradient reaching the product: dY * rowscale * col_scale
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void small_linear_dgrad_kernel(const ga_small_
         const long o = (long)i * d.lda + (d.a_perm ? d.a_perm[c] : c);
         stel<T>(dA, o, accumulate ? v + ldel<T>(dA, o) : v);
     };
-    tiled_mm(d.rows, d.Kg, d.Ng, a, b, st);
+    tiled_mm<32, true, false>(d.rows, d.Kg, d.Ng, a, b, st);
 }
 
 // dW[g*Ng + n][k] += sum_r dYeff[r][g*Ng + n] A[r][acol(g*a_gstride + k)]
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const ga_small_
         return ldel<T>(d.A, (long)l * d.lda + (d.a_perm ? d.a_perm[c] : c));
     };
     auto st = [&](int i, int j, float v) { dW[((long)g * d.Ng + i) * d.Kg + j] += v; };
-    tiled_mm(d.Ng, d.Kg, d.rows, a, b, st);
+    tiled_mm<32, false, false>(d.Ng, d.Kg, d.rows, a, b, st);
 }
 
 // per output column n: dbias[n] += sum_r dYeff[r][n];  dcol_scale[n] += sum_r dY[r][n] * rowscale * Yraw[r][n]
@@ -163,10 +165,17 @@ int check_desc(const ga_small_linear_desc* d, const char* what) {
 extern "C" int ga_small_linear_fwd(const ga_small_linear_desc* d, ga_stream_t stream) {
     if (int rc = check_desc(d, "ga_small_linear_fwd")) return rc;
     GA_REQUIRE(d->Y, "ga_small_linear_fwd: no output");
-    const dim3 grid((d->Ng + 63) / 64, (d->rows + 31) / 32, d->groups);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (d->dtype == GA_BF16) hipLaunchKernelGGL(small_linear_fwd_kernel<bf16_t>, grid, dim3(256), 0, s, *d);
-    else hipLaunchKernelGGL(small_linear_fwd_kernel<float>, grid, dim3(256), 0, s, *d);
+    const int ct = (d->Ng + 63) / 64;
+    if ((long)ct * ((d->rows + 31) / 32) * d->groups >= 512) {
+        const dim3 grid(ct, (d->rows + 31) / 32, d->groups);
+        if (d->dtype == GA_BF16) hipLaunchKernelGGL((small_linear_fwd_kernel<bf16_t, 32>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((small_linear_fwd_kernel<float, 32>), grid, dim3(256), 0, s, *d);
+    } else {        // few output tiles (86-column groups): 8-row tiles put 4x the workgroups on the chip
+        const dim3 grid(ct, (d->rows + 7) / 8, d->groups);
+        if (d->dtype == GA_BF16) hipLaunchKernelGGL((small_linear_fwd_kernel<bf16_t, 8>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((small_linear_fwd_kernel<float, 8>), grid, dim3(256), 0, s, *d);
+    }
     return ga_check_launch("ga_small_linear_fwd");
 }
 
