@@ -110,36 +110,66 @@ __global__ __launch_bounds__(256) void small_linear_wgrad_kernel(const ga_small_
 }
 
 // per output column n: dbias[n] += sum_r dYeff[r][n];  dcol_scale[n] += sum_r dY[r][n] * rowscale * Yraw[r][n]
+// workgroup = 32 columns x 8 interleaved row ranges (a single thread per column walking every row is latency-bound)
 template <typename T>
 __global__ __launch_bounds__(256) void small_linear_colgrad_kernel(const ga_small_linear_desc d, const void* dY, float* dbias,
                                                                    float* dcs) {
-    const long n = (long)blockIdx.x * 256 + threadIdx.x;
-    if (n >= (long)d.groups * d.Ng) return;
+    __shared__ float red[2][8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const long n = (long)blockIdx.x * 32 + cl;
+    const bool ok = n < (long)d.groups * d.Ng;
     float sb = 0.f, sc = 0.f;
-    for (int r = 0; r < d.rows; ++r) {
-        float v = ldel<T>(dY, (long)r * d.ldy + n);
-        if (d.rowscale) v *= d.rowscale[r / d.rows_per_scale];
-        if (dcs) sc = fmaf(v, ldel<T>(d.Yraw, (long)r * d.ldy + n), sc);
-        sb += d.col_scale ? v * d.col_scale[n] : v;
+    if (ok) {
+        for (int r = rg; r < d.rows; r += 8) {
+            float v = ldel<T>(dY, (long)r * d.ldy + n);
+            if (d.rowscale) v *= d.rowscale[r / d.rows_per_scale];
+            if (dcs) sc = fmaf(v, ldel<T>(d.Yraw, (long)r * d.ldy + n), sc);
+            sb += d.col_scale ? v * d.col_scale[n] : v;
+        }
     }
-    if (dbias) dbias[n] += sb;
-    if (dcs) dcs[n] += sc;
+    red[0][rg][cl] = sb;
+    red[1][rg][cl] = sc;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float a = 0.f, c = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            a += red[0][q][cl];
+            c += red[1][q][cl];
+        }
+        if (dbias) dbias[n] += a;
+        if (dcs) dcs[n] += c;
+    }
 }
 
 // column sums / sums of squares of x [rows][C] (row stride ld): the BatchNorm batch statistics the MFMA GEMM's epilogue
 // otherwise delivers
 template <typename T>
 __global__ __launch_bounds__(256) void colstats_kernel(const void* x, long ld, int rows, int C, float* s, float* q) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][8][33];
+    const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float a = 0.f, b = 0.f;
-    for (int r = 0; r < rows; ++r) {
-        const float v = ldel<T>(x, (long)r * ld + c);
-        a += v;
-        b = fmaf(v, v, b);
+    if (c < C) {
+        for (int r = rg; r < rows; r += 8) {
+            const float v = ldel<T>(x, (long)r * ld + c);
+            a += v;
+            b = fmaf(v, v, b);
+        }
     }
-    s[c] += a;
-    if (q) q[c] += b;
+    red[0][rg][cl] = a;
+    red[1][rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sa += red[0][k][cl];
+            sb += red[1][k][cl];
+        }
+        s[c] += sa;
+        if (q) q[c] += sb;
+    }
 }
 
 __global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols,
@@ -198,8 +228,8 @@ extern "C" int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY
     }
     if (dbias || dcol_scale) {
         const int n = d->groups * d->Ng;
-        if (bf) hipLaunchKernelGGL(small_linear_colgrad_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
-        else hipLaunchKernelGGL(small_linear_colgrad_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
+        if (bf) hipLaunchKernelGGL(small_linear_colgrad_kernel<bf16_t>, dim3((n + 31) / 32), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
+        else hipLaunchKernelGGL(small_linear_colgrad_kernel<float>, dim3((n + 31) / 32), dim3(256), 0, s, *d, dY, dbias, dcol_scale);
     }
     return ga_check_launch("ga_small_linear_bwd");
 }
@@ -207,8 +237,8 @@ extern "C" int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY
 extern "C" int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream) {
     GA_REQUIRE(x && sum && rows > 0 && C > 0 && ld >= C, "ga_colstats: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == GA_BF16) hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((C + 255) / 256), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3((C + 255) / 256), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(colstats_kernel<bf16_t>, dim3((C + 31) / 32), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3((C + 31) / 32), dim3(256), 0, s, x, (long)ld, rows, C, sum, sumsq);
     return ga_check_launch("ga_colstats");
 }
 

@@ -495,6 +495,8 @@ class GAEngine:
         B = 256: forward 0.66 -> 0.27 ms, backward pair 0.45 -> 0.54 ms per block; at C = 192 the backward loses more than the
         forward gains)"""
         allowed = [int(v) for v in os.environ.get('GA_FUSED_MLP', '96').split(',') if v.strip()]
+        if not self.training and 'GA_FUSED_MLP' not in os.environ:
+            allowed.append(192)          # forward only: the fused body wins at C = 192 too (0.36 -> 0.29 ms per block)
         return C in allowed and ops.mlp_supported(C, 4 * C, self.dt)
 
     def _block_bwd(self, pre, dy, dx, next_pre=None):
