@@ -166,6 +166,7 @@ _SIGS = {
     'ga_small_linear_bwd': ([C.POINTER(SmallLinearDesc), vp, vp, i32, vp, vp, vp, vp], i32),
     'ga_colstats': ([vp, i64, i32, i32, vp, vp, i32, vp], i32),
     'ga_pad_copy_f32': ([vp, vp, i64, i64, i64, i64, i32, vp], i32),
+    'ga_pad_copy': ([vp, vp, i64, i64, i64, i64, i32, i32, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const void* x, long ld, i
     }
 }
 
-__global__ __launch_bounds__(256) void pad_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long rows, long cols,
+template <typename T>
+__global__ __launch_bounds__(256) void pad_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long rows, long cols,
                                                        long lds, long ldd, int accumulate) {
     const long n = rows * cols;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long r = i / cols, c = i - r * cols;
-        const float v = src[r * lds + c];
-        if (accumulate) dst[r * ldd + c] += v;
-        else dst[r * ldd + c] = v;
+        const float v = elt<T>::ld(src + r * lds + c);
+        elt<T>::st(dst + r * ldd + c, accumulate ? v + elt<T>::ld(dst + r * ldd + c) : v);
     }
 }
 
@@ -242,12 +242,23 @@ extern "C" int ga_colstats(const void* x, int64_t ld, int rows, int C, float* su
     return ga_check_launch("ga_colstats");
 }
 
-extern "C" int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate,
-                               ga_stream_t stream) {
-    GA_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "ga_pad_copy_f32: bad args");
+extern "C" int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, int dtype,
+                           ga_stream_t stream) {
+    GA_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols && (dtype == GA_F32 || dtype == GA_BF16),
+               "ga_pad_copy: bad args");
     const long n = rows * cols;
     const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + 255) / 256));
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, (long)rows,
-                       (long)cols, (long)lds, (long)ldd, accumulate);
-    return ga_check_launch("ga_pad_copy_f32");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16)
+        hipLaunchKernelGGL(pad_copy_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const bf16_t*>(src),
+                           reinterpret_cast<bf16_t*>(dst), (long)rows, (long)cols, (long)lds, (long)ldd, accumulate);
+    else
+        hipLaunchKernelGGL(pad_copy_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(src),
+                           reinterpret_cast<float*>(dst), (long)rows, (long)cols, (long)lds, (long)ldd, accumulate);
+    return ga_check_launch("ga_pad_copy");
+}
+
+extern "C" int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate,
+                               ga_stream_t stream) {
+    return ga_pad_copy(src, dst, rows, cols, lds, ldd, accumulate, GA_F32, stream);
 }

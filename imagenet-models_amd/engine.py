@@ -937,10 +937,17 @@ class GAEngine:
         h['e'] = self.act(pre + 'out', (B, cout))
         h['bn_e'] = self._bn_bufs(pre + '1.', cout)
         h['emb_small'] = None
-        if cg % 8:      # 688 / 8 = 86 (976 / 8 = 122) channels per group: off the 16-byte grid -> alignment-free form on the master weights
+        if cg % 8:      # 688 / 8 = 86 (976 / 8 = 122) channels per group: off the 16-byte grid
+            # backward: alignment-free form on the master weights.  Forward (the expensive product: K = 2316 per group): the
+            # batched MFMA GEMM into a group-padded buffer [B][groups][pad8(cg)] -- aligned group bases, ragged N -- then compacted
             h['emb_small'] = F.small_linear_desc(h['vec'], P[pre + '0.weight'], h['e'], B, groups, cg, Kg, dt, lda=groups * Kp,
                                                  a_gstride=Kp, ldy=cout, bias=P[pre + '0.bias'])
-            F.small_linear_fwd(h['emb_small'], label=pre + 'conv')
+            cgp = pad8(cg)
+            ep = self.tmp('emb_pad', (B, groups * cgp))
+            Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp, need_T=False)
+            F.gemm(h['vec'], Wemb, ep, B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
+                   ldc=groups * cgp, strideC=cgp, bias=P[pre + '0.bias'], strideBias=cg, label=pre + 'conv')
+            F.pad_copy(ep, h['e'], B * groups, cg, cgp, cg, dt, label=pre + 'compact')
             if T:
                 F.colstats(h['e'], cout, B, cout, h['bn_e']['s'], h['bn_e']['q'], dt, label=pre + 'stats')
         else:

@@ -362,6 +362,9 @@ class Plan:
     def pad_copy_f32(self, src, dst, rows, cols, lds, ldd, accumulate=False, label=None):
         self._add('ga_pad_copy_f32', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate)), label, keep=(src, dst))
 
+    def pad_copy(self, src, dst, rows, cols, lds, ldd, dtype, accumulate=False, label=None):
+        self._add('ga_pad_copy', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate), dtype), label, keep=(src, dst))
+
     def mlp_fwd(self, X, W1, b1, W2, b2, Y, M, Cdim, dtype, ldw1=None, ldw2=None, R=None, rowscale=None, rows_per_scale=1, label=None):
         """fused fc1 -> GELU -> fc2 (+ DropPath row scale + residual): Y = R + rowscale * (gelu(X W1^T + b1) W2^T + b2)"""
         d = L.MlpDesc()

@@ -514,6 +514,9 @@ int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY, void* dA,
                         float* dcol_scale, ga_stream_t stream);
 int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream);
 int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, ga_stream_t stream);
+/* the same element-wise strided copy for activations in `dtype` (group compaction: [rows*groups][88] -> [rows*groups][86]) */
+int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, int dtype,
+                ga_stream_t stream);
 
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
