@@ -1116,7 +1116,8 @@ size_t tn2_plan(const ga_wgrad_desc* d, int* split_out) {
     split = cdiv(stages, cdiv(stages, split));                                // no empty row range
     *split_out = split;
     const long nk = (long)d->N * d->K;
-    return (split > 1 && nk >= 131072) ? (size_t)d->batch * split * nk * sizeof(float) : 0;   // small outputs: atomics are cheaper
+    static const long nk_min = [] { const char* e = getenv("GAEXT_TN2_PART_MIN"); return e ? atol(e) : 65536L; }();      // 256 x 256 outputs (CSWin proj) included: -0.2 ms/step there, neutral elsewhere
+    return (split > 1 && nk >= nk_min) ? (size_t)d->batch * split * nk * sizeof(float) : 0;   // small outputs: atomics are cheaper
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
