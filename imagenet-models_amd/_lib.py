@@ -90,6 +90,11 @@ class SmallLinearDesc(C.Structure):
                 ('Y', vp), ('ldy', i64), ('Yraw', vp), ('dtype', i32)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [('B', i32), ('N', i32), ('H', i32), ('hd', i32), ('scale', f32), ('dtype', i32), ('qkv', vp), ('ldq', i64),
+                ('out', vp), ('ldo', i64), ('lse', vp)]
+
+
 _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
@@ -167,6 +172,9 @@ _SIGS = {
     'ga_colstats': ([vp, i64, i32, i32, vp, vp, i32, vp], i32),
     'ga_pad_copy_f32': ([vp, vp, i64, i64, i64, i64, i32, vp], i32),
     'ga_pad_copy': ([vp, vp, i64, i64, i64, i64, i32, i32, vp], i32),
+    'ga_attn_fwd': ([C.POINTER(AttnDesc), vp], i32),
+    'ga_attn_bwd_workspace': ([C.POINTER(AttnDesc)], C.c_size_t),
+    'ga_attn_bwd': ([C.POINTER(AttnDesc), vp, vp, vp, C.c_size_t, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

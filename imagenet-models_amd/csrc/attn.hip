@@ -1,0 +1,500 @@
+// Global multi-head self-attention over token sequences (timm vision_transformer.Attention as the reference uses it through
+// `Block`: MAP/models/map_pit.py:14,35-44):  out = softmax(q k^T * scale) v  per (image, head), N tokens, head_dim 64.
+//
+//   qkv [B*N][ldq]: q | k | v column blocks of width C = H * hd (head h owns columns h*hd .. of each block), out [B*N][ldo].
+//
+// bf16, head_dim 64: flash-style on the matrix cores.  A workgroup (4 waves) owns 64 query rows of one (image, head); keys /
+// values stream through LDS in blocks of 64.  As in the stripe-attention kernels (cswin.hip) the scores are computed
+// TRANSPOSED, S^T = K . Q^T with v_mfma_f32_16x16x32_bf16: a lane then holds 16 keys of ONE query, so the running maximum /
+// sum of the online softmax are in-lane reductions plus two shuffles, and the P^T accumulators are directly the A operand
+// of the next product (O += P . V; the V fragment is read with the transposing ds_read_b64_tr_b16 in the matching k order).
+// Backward = three launches: delta[q] = dO . O, a dQ kernel (per query block, streaming keys) and a dK / dV kernel (per key
+// block, streaming queries; S and dP recomputed in the [query][key] layout whose accumulators are the A operands of
+// dV += P^T dO and dK += dS^T Q).  The row statistics lse[b][h][q] are kept by the forward pass.
+//
+// Everything else (fp32 parity mode, other head dims): a plain fp32 kernel, one thread per query (forward / dQ) or per key
+// (dK / dV) streaming the other side from L2 -- meant for the parity tests at small batches, not for throughput.
+#include <algorithm>
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS tile = [rows][32 bf16] slabs (64-byte rows, 16-byte unit c of row r at c ^ ((r >> 2) & 3)); a 64-wide head = 2 slabs
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned tile_off(int r, int chunk) { return r * 64 + ((chunk ^ ((r >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ bf16x8_t row_frag(const unsigned char* slab, int r0, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(slab + tile_off(r0 + (lane & 15), lane >> 4));
+}
+
+// B fragment taken column-wise with the transposing LDS read: element j of lane (g, i) is slab[k0 + 16 (j >> 2) + 4 g + (j & 3)][16 dt + i]
+__device__ __forceinline__ bf16x8_t col_frag_acc(const unsigned char* slab, int k0, int dt, int lane) {
+    const int gq = lane >> 4, i = lane & 15;
+    s16x4_t h[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = k0 + 16 * q + 4 * gq + (i >> 2);
+        const unsigned a = tile_off(r, 2 * dt + ((i & 3) >> 1)) + 8 * (i & 1);
+        h[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(slab + a));
+    }
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    const s16x8_t v = {h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+    return *reinterpret_cast<const bf16x8_t*>(&v);
+}
+
+__device__ __forceinline__ bf16x8_t acc_pair_frag(const f32x4_t& a, const f32x4_t& b) {
+    uint4 u;
+    u.x = pack2bf(a[0], a[1]); u.y = pack2bf(a[2], a[3]); u.z = pack2bf(b[0], b[1]); u.w = pack2bf(b[2], b[3]);
+    return *reinterpret_cast<const bf16x8_t*>(&u);
+}
+
+constexpr int BQ = 64;                  // rows of a block (queries or keys)
+constexpr int SLAB = BQ * 64;           // bytes of one [64][32] slab
+constexpr int TILE = 2 * SLAB;          // [64][64] bf16
+
+// rows [r0, r0 + 64) x 64 columns of a [B*N][ld] column slice -> two slabs; rows >= nrows (end of the sequence) are zero
+__device__ __forceinline__ void load_block(unsigned char* dst, const bf16_t* src, long ld, int r0, int nrows) {
+    for (int i = threadIdx.x; i < BQ * 8; i += 256) {
+        const int r = i >> 3, c = i & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)(r0 + r) * ld + c * 8);
+        *reinterpret_cast<uint4*>(dst + (c >> 2) * SLAB + tile_off(r, c & 3)) = v;
+    }
+}
+
+// fp32 accumulator tiles o[dt] (rows 4g + r, column 16 dt + (lane & 15)) of one wave's 16 rows -> bf16 rows through this wave's
+// 2 KiB staging piece -> 16-byte global stores (8 lanes per row)
+__device__ __forceinline__ void store_rows16(unsigned char* stage, const f32x4_t (&o)[4], bf16_t* dst, long ld, int r0, int nrows,
+                                             int lane) {
+    bf16_t* st = reinterpret_cast<bf16_t*>(stage);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(4 * (lane >> 4) + r) * 64 + 16 * dt + (lane & 15)] = f2bf(o[dt][r]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS accesses complete in order
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = 8 * p + (lane >> 3), c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + r * 128 + c * 16);
+        if (r0 + r < nrows) *reinterpret_cast<uint4*>(dst + (long)(r0 + r) * ld + c * 8) = v;
+    }
+}
+
+__device__ __forceinline__ int xcd_walk(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct Item { int b, h, blk; long row0; };   // row0 = first row of image b in the [B*N] matrices
+
+__device__ __forceinline__ Item item_of(const ga_attn_desc& d, int id, int nblk) {
+    Item it;
+    it.blk = id % nblk;
+    const int bh = id / nblk;
+    it.h = bh % d.H;
+    it.b = bh / d.H;
+    it.row0 = (long)it.b * d.N;
+    return it;
+}
+
+// =================================================================================================================
+// forward, bf16, head_dim 64
+// =================================================================================================================
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const int nblk, const int nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qs = smem;
+    unsigned char* Ks = Qs + TILE;
+    unsigned char* Vs = Ks + TILE;
+    unsigned char* Stage = Vs + TILE;            // 4 x 2 KiB
+    const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int C = d.H * 64, q0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
+    load_block(Qs, qkv, d.ldq, q0, d.N);
+    __syncthreads();
+    bf16x8_t qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) qf[s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t o[4] = {zero, zero, zero, zero};
+    float m = -3.0e38f, l = 0.f;
+    const float sc = d.scale * 1.44269504f;                    // exp2 domain
+    for (int k0 = 0; k0 < d.N; k0 += BQ) {
+        __syncthreads();                                       // everyone is done with the previous key block
+        load_block(Ks, qkv + C, d.ldq, k0, d.N);
+        load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+        __syncthreads();
+        f32x4_t st[4];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            st[kt] = zero;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks + s * SLAB, 16 * kt, lane), qf[s], st[kt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[kt][r] = (k0 + 16 * kt + 4 * g + r < d.N) ? st[kt][r] * sc : -3.0e38f;
+                mx = fmaxf(mx, st[kt][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __builtin_amdgcn_exp2f(st[kt][r] - mn);      // masked keys: exp2(-huge) = 0
+                st[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l = l * alpha + sum;
+        m = mn;
+        // the accumulator rows are queries 4g + r, the statistics live in the lanes whose (lane & 15) is that query
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float ar = __shfl(alpha, 4 * g + r, 64);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const bf16x8_t pf = acc_pair_frag(st[2 * kp], st[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Vs + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane), o[dt], 0, 0, 0);
+        }
+    }
+    const float linv = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float lr = __shfl(linv, 4 * g + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][r] *= lr;
+    }
+    const int qw = q0 + 16 * wave;
+    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(d.out) + it.row0 * d.ldo + it.h * 64, d.ldo, qw, d.N, lane);
+    if (lane < 16 && qw + lane < d.N) d.lse[((long)it.b * d.H + it.h) * d.N + qw + lane] = m * 0.69314718f + __logf(l);   // natural-log units
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]   (one thread per (b, h, q))
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const ga_attn_desc d, const void* dout_, float* delta) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x, n = (long)d.B * d.H * d.N;
+    if (i >= n) return;
+    const int q = (int)(i % d.N), h = (int)((i / d.N) % d.H), b = (int)(i / ((long)d.N * d.H));
+    const T* o = reinterpret_cast<const T*>(d.out) + ((long)b * d.N + q) * d.ldo + h * d.hd;
+    const T* go = reinterpret_cast<const T*>(dout_) + ((long)b * d.N + q) * d.ldo + h * d.hd;
+    float s = 0.f;
+    for (int c = 0; c < d.hd; ++c) s = fmaf(elt<T>::ld(o + c), elt<T>::ld(go + c), s);
+    delta[i] = s;
+}
+
+// =================================================================================================================
+// backward dQ, bf16, head_dim 64: one workgroup per 64 queries, keys / values streamed
+// =================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta,
+                                                        const int nblk, const int nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Qs = smem;
+    unsigned char* Gs = Qs + TILE;
+    unsigned char* Ks = Gs + TILE;
+    unsigned char* Vs = Ks + TILE;
+    unsigned char* Stage = Vs + TILE;
+    const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int C = d.H * 64, q0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
+    load_block(Qs, qkv, d.ldq, q0, d.N);
+    load_block(Gs, reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * 64, d.ldo, q0, d.N);
+    __syncthreads();
+    bf16x8_t qf[2], gf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qf[s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
+        gf[s] = row_frag(Gs + s * SLAB, 16 * wave, lane);
+    }
+    const int qi = q0 + 16 * wave + (lane & 15);
+    const long sidx = ((long)it.b * d.H + it.h) * d.N + qi;
+    const float lse = qi < d.N ? d.lse[sidx] : 0.f, dl = qi < d.N ? delta[sidx] : 0.f;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t o[4] = {zero, zero, zero, zero};
+    for (int k0 = 0; k0 < d.N; k0 += BQ) {
+        __syncthreads();
+        load_block(Ks, qkv + C, d.ldq, k0, d.N);
+        load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+        __syncthreads();
+        f32x4_t ds[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4_t st = zero, dp = zero;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks + s * SLAB, 16 * kt, lane), qf[s], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs + s * SLAB, 16 * kt, lane), gf[s], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = k0 + 16 * kt + 4 * g + r < d.N;
+                const float p = ok ? __expf(st[r] * d.scale - lse) : 0.f;
+                ds[kt][r] = p * (dp[r] - dl);
+            }
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            const bf16x8_t sf = acc_pair_frag(ds[2 * kp], ds[2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Ks + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane), o[dt], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= d.scale;
+    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * 64, d.ldq, q0 + 16 * wave, d.N, lane);
+}
+
+// =================================================================================================================
+// backward dK / dV, bf16, head_dim 64: one workgroup per 64 keys, queries / dO streamed
+// =================================================================================================================
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta,
+                                                         const int nblk, const int nwg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Ks = smem;
+    unsigned char* Vs = Ks + TILE;
+    unsigned char* Qs = Vs + TILE;
+    unsigned char* Gs = Qs + TILE;
+    unsigned char* Stage = Gs + TILE;                              // 4 x 2 KiB
+    float* lse_s = reinterpret_cast<float*>(Stage + 8192);         // [64]
+    float* dlt_s = lse_s + BQ;                                     // [64]
+    const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int C = d.H * 64, k0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
+    const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * 64;
+    bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * 64;
+    load_block(Ks, qkv + C, d.ldq, k0, d.N);
+    load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+    __syncthreads();
+    bf16x8_t kf[2], vf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        kf[s] = row_frag(Ks + s * SLAB, 16 * wave, lane);
+        vf[s] = row_frag(Vs + s * SLAB, 16 * wave, lane);
+    }
+    const bool key_ok = k0 + 16 * wave + (lane & 15) < d.N;
+    const long sbase = ((long)it.b * d.H + it.h) * d.N;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t dv[4] = {zero, zero, zero, zero}, dk[4] = {zero, zero, zero, zero};
+    for (int q0 = 0; q0 < d.N; q0 += BQ) {
+        __syncthreads();
+        load_block(Qs, qkv, d.ldq, q0, d.N);
+        load_block(Gs, dout, d.ldo, q0, d.N);
+        if (threadIdx.x < BQ) {
+            const int q = q0 + threadIdx.x;
+            lse_s[threadIdx.x] = q < d.N ? d.lse[sbase + q] : 0.f;
+            dlt_s[threadIdx.x] = q < d.N ? delta[sbase + q] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            f32x4_t p[2], ds[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qt = 32 * qs + 16 * h;              // rows of this 16-query tile inside the block
+                p[h] = zero;
+                ds[h] = zero;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    p[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs + s * SLAB, qt, lane), kf[s], p[h], 0, 0, 0);      // [query 4g+r][key lane&15]
+                    ds[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Gs + s * SLAB, qt, lane), vf[s], ds[h], 0, 0, 0);
+                }
+                const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(lse_s + qt + 4 * g);
+                const f32x4_t de = *reinterpret_cast<const f32x4_t*>(dlt_s + qt + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = key_ok && q0 + qt + 4 * g + r < d.N;
+                    const float pv = ok ? __expf(p[h][r] * d.scale - ls[r]) : 0.f;
+                    p[h][r] = pv;
+                    ds[h][r] = pv * (ds[h][r] - de[r]);
+                }
+            }
+            const bf16x8_t pf = acc_pair_frag(p[0], p[1]), sf = acc_pair_frag(ds[0], ds[1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Gs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane), dv[dt], 0, 0, 0);
+                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Qs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane), dk[dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dk[dt][r] *= d.scale;
+    store_rows16(Stage + wave * 2048, dk, dqkv + C, d.ldq, k0 + 16 * wave, d.N, lane);
+    store_rows16(Stage + wave * 2048, dv, dqkv + 2 * C, d.ldq, k0 + 16 * wave, d.N, lane);
+}
+
+// =================================================================================================================
+// generic fp32 forms (any dtype / head_dim <= 128): one thread per query (forward, dQ) or per key (dK, dV)
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(128) void attn_fwd_simple(const ga_attn_desc d) {
+    const long i = (long)blockIdx.x * 128 + threadIdx.x, n = (long)d.B * d.H * d.N;
+    if (i >= n) return;
+    const int q = (int)(i % d.N), h = (int)((i / d.N) % d.H), b = (int)(i / ((long)d.N * d.H));
+    const int C = d.H * d.hd, hd = d.hd;
+    const T* base = reinterpret_cast<const T*>(d.qkv) + (long)b * d.N * d.ldq + h * hd;
+    float qv[128], acc[128];
+    for (int c = 0; c < hd; ++c) {
+        qv[c] = elt<T>::ld(base + (long)q * d.ldq + c) * d.scale;
+        acc[c] = 0.f;
+    }
+    float m = -3.0e38f, l = 0.f;
+    for (int j = 0; j < d.N; ++j) {
+        const T* kr = base + (long)j * d.ldq + C;
+        float s = 0.f;
+        for (int c = 0; c < hd; ++c) s = fmaf(qv[c], elt<T>::ld(kr + c), s);
+        const float mn = fmaxf(m, s), a = __expf(m - mn), p = __expf(s - mn);
+        l = l * a + p;
+        const T* vr = base + (long)j * d.ldq + 2 * C;
+        for (int c = 0; c < hd; ++c) acc[c] = fmaf(p, elt<T>::ld(vr + c), acc[c] * a);
+        m = mn;
+    }
+    T* o = reinterpret_cast<T*>(d.out) + ((long)b * d.N + q) * d.ldo + h * hd;
+    const float inv = 1.f / l;
+    for (int c = 0; c < hd; ++c) elt<T>::st(o + c, acc[c] * inv);
+    d.lse[i] = m + __logf(l);
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_bwd_dq_simple(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta) {
+    const long i = (long)blockIdx.x * 128 + threadIdx.x, n = (long)d.B * d.H * d.N;
+    if (i >= n) return;
+    const int q = (int)(i % d.N), h = (int)((i / d.N) % d.H), b = (int)(i / ((long)d.N * d.H));
+    const int C = d.H * d.hd, hd = d.hd;
+    const T* base = reinterpret_cast<const T*>(d.qkv) + (long)b * d.N * d.ldq + h * hd;
+    const T* go = reinterpret_cast<const T*>(dout_) + ((long)b * d.N + q) * d.ldo + h * hd;
+    float qv[128], gv[128], acc[128];
+    for (int c = 0; c < hd; ++c) {
+        qv[c] = elt<T>::ld(base + (long)q * d.ldq + c);
+        gv[c] = elt<T>::ld(go + c);
+        acc[c] = 0.f;
+    }
+    const float lse = d.lse[i], dl = delta[i];
+    for (int j = 0; j < d.N; ++j) {
+        const T* kr = base + (long)j * d.ldq + C;
+        const T* vr = base + (long)j * d.ldq + 2 * C;
+        float s = 0.f, dp = 0.f;
+        for (int c = 0; c < hd; ++c) {
+            s = fmaf(qv[c], elt<T>::ld(kr + c), s);
+            dp = fmaf(gv[c], elt<T>::ld(vr + c), dp);
+        }
+        const float ds = __expf(s * d.scale - lse) * (dp - dl);
+        for (int c = 0; c < hd; ++c) acc[c] = fmaf(ds, elt<T>::ld(kr + c), acc[c]);
+    }
+    T* o = reinterpret_cast<T*>(dqkv_) + ((long)b * d.N + q) * d.ldq + h * hd;
+    for (int c = 0; c < hd; ++c) elt<T>::st(o + c, acc[c] * d.scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void attn_bwd_dkv_simple(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta) {
+    const long i = (long)blockIdx.x * 128 + threadIdx.x, n = (long)d.B * d.H * d.N;
+    if (i >= n) return;
+    const int j = (int)(i % d.N), h = (int)((i / d.N) % d.H), b = (int)(i / ((long)d.N * d.H));
+    const int C = d.H * d.hd, hd = d.hd;
+    const T* base = reinterpret_cast<const T*>(d.qkv) + (long)b * d.N * d.ldq + h * hd;
+    const T* gbase = reinterpret_cast<const T*>(dout_) + (long)b * d.N * d.ldo + h * hd;
+    float kv[128], vv[128], ak[128], av[128];
+    for (int c = 0; c < hd; ++c) {
+        kv[c] = elt<T>::ld(base + (long)j * d.ldq + C + c);
+        vv[c] = elt<T>::ld(base + (long)j * d.ldq + 2 * C + c);
+        ak[c] = av[c] = 0.f;
+    }
+    const long sbase = ((long)b * d.H + h) * d.N;
+    for (int q = 0; q < d.N; ++q) {
+        const T* qr = base + (long)q * d.ldq;
+        const T* gr = gbase + (long)q * d.ldo;
+        float s = 0.f, dp = 0.f;
+        for (int c = 0; c < hd; ++c) {
+            s = fmaf(elt<T>::ld(qr + c), kv[c], s);
+            dp = fmaf(elt<T>::ld(gr + c), vv[c], dp);
+        }
+        const float p = __expf(s * d.scale - d.lse[sbase + q]);
+        const float ds = p * (dp - delta[sbase + q]);
+        for (int c = 0; c < hd; ++c) {
+            av[c] = fmaf(p, elt<T>::ld(gr + c), av[c]);
+            ak[c] = fmaf(ds, elt<T>::ld(qr + c), ak[c]);
+        }
+    }
+    T* o = reinterpret_cast<T*>(dqkv_) + ((long)b * d.N + j) * d.ldq + h * hd;
+    for (int c = 0; c < hd; ++c) {
+        elt<T>::st(o + C + c, ak[c] * d.scale);
+        elt<T>::st(o + 2 * C + c, av[c]);
+    }
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_desc(const ga_attn_desc* d, const char* what) {
+    GA_REQUIRE(d && d->qkv && d->out && d->lse && d->B > 0 && d->N > 0 && d->H > 0 && d->hd > 0 && d->hd <= 128, "%s: null / empty descriptor", what);
+    GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "%s: bad dtype", what);
+    GA_REQUIRE(d->ldq >= 3L * d->H * d->hd && d->ldo >= (long)d->H * d->hd, "%s: leading dimensions", what);
+    return GA_OK;
+}
+
+bool use_mfma(const ga_attn_desc* d) {
+    const char* e = getenv("GAEXT_ATTN_MFMA");
+    return (!e || atoi(e)) && d->dtype == GA_BF16 && d->hd == 64 && d->ldq % 8 == 0 && d->ldo % 8 == 0 && aligned16(d->qkv) && aligned16(d->out);
+}
+
+}  // namespace
+
+extern "C" int ga_attn_fwd(const ga_attn_desc* d, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_attn_fwd")) return rc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (use_mfma(d)) {
+        const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
+        hipLaunchKernelGGL(attn_fwd_mfma, dim3(nwg), dim3(256), 3 * TILE + 8192, s, *d, nblk, nwg);
+        return ga_check_launch("ga_attn_fwd");
+    }
+    const long n = (long)d->B * d->H * d->N;
+    if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_fwd_simple<bf16_t>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, *d);
+    else hipLaunchKernelGGL(attn_fwd_simple<float>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, s, *d);
+    return ga_check_launch("ga_attn_fwd");
+}
+
+extern "C" size_t ga_attn_bwd_workspace(const ga_attn_desc* d) { return d ? (size_t)d->B * d->H * d->N * sizeof(float) : 0; }
+
+extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, void* workspace, size_t ws_bytes, ga_stream_t stream) {
+    if (int rc = check_desc(d, "ga_attn_bwd")) return rc;
+    GA_REQUIRE(dout && dqkv && workspace && ws_bytes >= ga_attn_bwd_workspace(d), "ga_attn_bwd: dout / dqkv / a workspace of %zu bytes",
+               ga_attn_bwd_workspace(d));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* delta = reinterpret_cast<float*>(workspace);
+    const long n = (long)d->B * d->H * d->N;
+    const unsigned g256 = (unsigned)((n + 255) / 256), g128 = (unsigned)((n + 127) / 128);
+    if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+    else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+    if (use_mfma(d) && aligned16(dout) && aligned16(dqkv)) {
+        const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
+        hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk, nwg);
+        hipLaunchKernelGGL(attn_bwd_dkv_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192 + 512, s, *d, dout, dqkv, delta, nblk, nwg);
+        return ga_check_launch("ga_attn_bwd");
+    }
+    if (d->dtype == GA_BF16) {
+        hipLaunchKernelGGL(attn_bwd_dq_simple<bf16_t>, dim3(g128), dim3(128), 0, s, *d, dout, dqkv, delta);
+        hipLaunchKernelGGL(attn_bwd_dkv_simple<bf16_t>, dim3(g128), dim3(128), 0, s, *d, dout, dqkv, delta);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_simple<float>, dim3(g128), dim3(128), 0, s, *d, dout, dqkv, delta);
+        hipLaunchKernelGGL(attn_bwd_dkv_simple<float>, dim3(g128), dim3(128), 0, s, *d, dout, dqkv, delta);
+    }
+    return ga_check_launch("ga_attn_bwd");
+}

@@ -337,6 +337,22 @@ class Plan:
         d.colsum, d.colsumsq, d.strideCol = _ptr(colsum), _ptr(colsumsq), strideCol
         self._add('ga_gemm', (C.byref(d),), label, keep=(d, A, B, Cout, bias, H, rowscale, R, colsum, colsumsq, C2))
 
+    # -- global attention (ViT blocks) ---------------------------------------------------------------
+    def attn_desc(self, qkv, out, lse, B, N, H, hd, scale, dtype, ldq=None, ldo=None):
+        d = L.AttnDesc()
+        d.B, d.N, d.H, d.hd, d.scale, d.dtype = B, N, H, hd, scale, dtype
+        d.qkv, d.ldq, d.out, d.ldo, d.lse = _ptr(qkv), (3 * H * hd if ldq is None else ldq), _ptr(out), (H * hd if ldo is None else ldo), _ptr(lse)
+        self.keep.extend([d, qkv, out, lse])
+        return d
+
+    def attn_fwd(self, d, label=None):
+        self._add('ga_attn_fwd', (C.byref(d),), label, keep=(d,))
+
+    def attn_bwd(self, d, dout, dqkv, ws, label=None):
+        """ws: fp32 tensor of B*H*N elements (delta)"""
+        self._add('ga_attn_bwd', (C.byref(d), _ptr(dout), _ptr(dqkv), _ptr(ws), ws.numel() * ws.element_size()), label,
+                  keep=(d, dout, dqkv, ws))
+
     # -- alignment-free forms (odd-width variants) -------------------------------------------------
     def small_linear_desc(self, A, W, Y, rows, groups, Ng, Kg, dtype, lda, a_gstride, ldy, bias=None, a_perm=None, col_scale=None,
                           rowscale=None, rows_per_scale=1, R=None, ldr=0, Yraw=None):

@@ -518,6 +518,25 @@ int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, in
 int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, int dtype,
                 ga_stream_t stream);
 
+/* Global multi-head self-attention (timm vision_transformer.Attention inside `Block`, MAP/models/map_pit.py:14,35-44):
+ *   qkv [B*N][ldq]: q | k | v column blocks of width C = H*hd (head h = columns h*hd.. of each block); out [B*N][ldo];
+ *   out = softmax(q k^T * scale) v per (image, head);  lse [B][H][N] fp32 = row log-sum-exp, kept for the backward pass.
+ * bf16 with hd = 64 runs flash-style on MFMA (64-query workgroups, 64-key blocks streamed through LDS, online softmax);
+ * everything else (fp32 parity mode, other hd <= 128) on a plain fp32 form meant for small batches.
+ * bwd: dqkv [B*N][ldq] = d(q | k | v) from dout [B*N][ldo]; needs `out` and `lse` of the forward pass and a caller-owned
+ * workspace of ga_attn_bwd_workspace(d) bytes (delta[b][h][q] = dout . out). */
+typedef struct {
+    int B, N, H, hd;
+    float scale;
+    int dtype;
+    const void* qkv; int64_t ldq;
+    void* out; int64_t ldo;
+    float* lse;
+} ga_attn_desc;
+int ga_attn_fwd(const ga_attn_desc* d, ga_stream_t stream);
+size_t ga_attn_bwd_workspace(const ga_attn_desc* d);
+int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, void* workspace, size_t ws_bytes, ga_stream_t stream);
+
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */
 int ga_transpose_f32(const float* in, float* out, int R, int C, int accumulate, ga_stream_t stream); /* out[c][r] (+)= in[r][c] */
