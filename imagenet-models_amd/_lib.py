@@ -175,6 +175,9 @@ _SIGS = {
     'ga_attn_fwd': ([C.POINTER(AttnDesc), vp], i32),
     'ga_attn_bwd_workspace': ([C.POINTER(AttnDesc)], C.c_size_t),
     'ga_attn_bwd': ([C.POINTER(AttnDesc), vp, vp, vp, C.c_size_t, vp], i32),
+    'ga_patchify': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_vit_embed_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_vit_embed_bwd': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

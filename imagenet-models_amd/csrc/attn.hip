@@ -441,6 +441,70 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_simple(const ga_attn_desc d,
     }
 }
 
+// =================================================================================================================
+// ViT stem helpers (timm PatchEmbed + cls_token / pos_embed): the P x P / stride P patch convolution is a GEMM over patches
+//   ga_patchify:  fp32 NCHW [B,3,H,W] -> [B*(H/P)*(W/P)][3*P*P] in T, k = (c, ky, kx) = the flattened conv weight's order
+//   ga_vit_embed_fwd:  x0[b][0] = cls + pos[0];  x0[b][1+p] = tok[b][p] + pos[1+p]
+//   ga_vit_embed_bwd:  dtok = dx0[b][1+p];  dcls += sum_b dx0[b][0];  dpos[t] += sum_b dx0[b][t]
+// =================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int CH, int H, int W, int P) {
+    const int gw = W / P, gh = H / P, K = CH * P * P, K8 = K / 8;
+    const long n = (long)B * gh * gw * K8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % K8) * 8;
+        const long row = i / K8;
+        const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long)gw * gh));
+        const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
+        const float* src = x + (((long)b * CH + c) * H + py * P + ky) * W + px * P + kx;
+        const float4 a = *reinterpret_cast<const float4*>(src), bq = *reinterpret_cast<const float4*>(src + 4);
+        float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        store8(out + row * K + k, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                            T* __restrict__ x0, int B, int Np, int C) {
+    const int C8 = C / 8;
+    const long n = (long)B * (Np + 1) * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long row = i / C8;
+        const int t = (int)(row % (Np + 1)), b = (int)(row / (Np + 1));
+        float v[8], pv[8];
+        load8(pos + (long)t * C + c, pv);
+        if (t == 0) load8(cls + c, v);
+        else load8(tok + ((long)b * Np + t - 1) * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += pv[j];
+        store8(x0 + row * C + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_embed_bwd_kernel(const T* __restrict__ dx0, T* __restrict__ dtok, float* __restrict__ dcls,
+                                                            float* __restrict__ dpos, int B, int Np, int C) {
+    const int C8 = C / 8;
+    const long n = (long)(Np + 1) * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8, t = (int)(i / C8);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            float v[8];
+            load8(dx0 + ((long)b * (Np + 1) + t) * C + c, v);
+            if (t > 0) store8(dtok + ((long)b * Np + t - 1) * C + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dpos[(long)t * C + c + j] += acc[j];
+            if (t == 0) dcls[c + j] += acc[j];
+        }
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int check_desc(const ga_attn_desc* d, const char* what) {
@@ -497,4 +561,38 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
         hipLaunchKernelGGL(attn_bwd_dkv_simple<float>, dim3(g128), dim3(128), 0, s, *d, dout, dqkv, delta);
     }
     return ga_check_launch("ga_attn_bwd");
+}
+
+extern "C" int ga_patchify(const float* x, void* out, int B, int CH, int H, int W, int P, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && out && B > 0 && CH > 0 && P > 0 && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0 && aligned16(x) && aligned16(out),
+               "ga_patchify: patch size must be a multiple of 8 and divide the 16-byte aligned image");
+    const long n = (long)B * (H / P) * (W / P) * (CH * P * P / 8);
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, (bf16_t*)out, B, CH, H, W, P);
+    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)out, B, CH, H, W, P);
+    return ga_check_launch("ga_patchify");
+}
+
+extern "C" int ga_vit_embed_fwd(const void* tok, const float* cls, const float* pos, void* x0, int B, int Np, int C, int dtype,
+                                ga_stream_t stream) {
+    GA_REQUIRE(tok && cls && pos && x0 && B > 0 && Np > 0 && C > 0 && C % 8 == 0 && aligned16(tok) && aligned16(x0) && aligned16(cls) && aligned16(pos),
+               "ga_vit_embed_fwd: bad args (C %% 8, 16-byte alignment)");
+    const long n = (long)B * (Np + 1) * (C / 8);
+    const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(vit_embed_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)tok, cls, pos, (bf16_t*)x0, B, Np, C);
+    else hipLaunchKernelGGL(vit_embed_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)tok, cls, pos, (float*)x0, B, Np, C);
+    return ga_check_launch("ga_vit_embed_fwd");
+}
+
+extern "C" int ga_vit_embed_bwd(const void* dx0, void* dtok, float* dcls, float* dpos, int B, int Np, int C, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dx0 && dtok && dcls && dpos && B > 0 && Np > 0 && C > 0 && C % 8 == 0 && aligned16(dx0) && aligned16(dtok),
+               "ga_vit_embed_bwd: bad args (C %% 8, 16-byte alignment)");
+    const long n = (long)(Np + 1) * (C / 8);
+    const int blocks = (int)std::max<long>(1, std::min<long>(4096, (n + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GA_BF16) hipLaunchKernelGGL(vit_embed_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dx0, (bf16_t*)dtok, dcls, dpos, B, Np, C);
+    else hipLaunchKernelGGL(vit_embed_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dx0, (float*)dtok, dcls, dpos, B, Np, C);
+    return ga_check_launch("ga_vit_embed_bwd");
 }

@@ -54,6 +54,18 @@ class MAPEngine(GAEngine):
             F.pool_concat_fwd(src, cat, B, hw, hw, c, Hc, Hc, ctot, off, mode, dt, label=f'agg.{off}')
             self.agg_segs.append((src, hw, c, mode, off))
             off += c
+        x = self._multi_scale_conv_fwd(cat, M4, ctot)
+        self._build_map_head(x, M4, Hc)
+        if T:
+            self._build_backward(feats, stage_in, x, M4)
+            if self.async_wgrad:
+                self.bwd.join_async()
+            self.bwd.flush('end.')
+        self.prep.flush('prep.')
+
+    def _multi_scale_conv_fwd(self, cat, M4, ctot):
+        """MultiScale.concat_conv (map.py:322-333): conv1x1 -> BN -> GELU on the concat of the resized maps"""
+        F, dt, T, L = self.fwd, self.dt, self.training, self.cfg['last_dim']
         mp = 'head.mmcap.multi_scale.concat_conv.'
         Wc = self._w_plain(mp + '0.weight', L, ctot, 1, 1)
         ms = self.ms = dict(cat=cat, ctot=ctot, c=self.act('ms.c', (M4, L)), bn=self._bn_bufs(mp + '1.', L), z=self.act('ms.z', (M4, L)))
@@ -63,13 +75,7 @@ class MAPEngine(GAEngine):
         F.affine_act(ms['c'], ms['bn']['scale'], ms['bn']['shift'], None, ms['z'], M4, L, False, dt, label=mp + 'bn')
         x = self.buf('ms.x', (M4, L))
         F.gelu_fwd(ms['z'], x, M4 * L, dt, label=mp + 'gelu')
-        self._build_map_head(x, M4, Hc)
-        if T:
-            self._build_backward(feats, stage_in, x, M4)
-            if self.async_wgrad:
-                self.bwd.join_async()
-            self.bwd.flush('end.')
-        self.prep.flush('prep.')
+        return x
 
     # ------------------------------------------------------------------------------------------
     def _build_map_head(self, x, M4, Hc):
@@ -341,9 +347,22 @@ class MAPEngine(GAEngine):
 
     # ------------------------------------------------------------------------------------------
     def _build_backward(self, feats, stage_in, x, M4):
+        """head backward, then the ConvNeXt trunk's"""
+        Bk, dt, B = self.bwd, self.dt, self.B
+        dcat = self._build_head_backward(x, M4)
+        ctot = self.ms['ctot']
+        seeds = []
+        for src, hw, c, mode, off in self.agg_segs:
+            ds = self.buf(f'agg.d{off}', (B * hw * hw, c))
+            Bk.pool_concat_bwd(dcat, None, ds, B, hw, hw, c, 14, 14, ctot, off, mode, dt, label=f'agg.b{off}')
+            seeds.append(ds)
+        self._build_trunk_backward({i: seeds[1 + i] for i in range(4)}, [], [], feats, stage_in, stem_seed=seeds[0])
+
+    def _build_head_backward(self, x, M4):
+        """classifiers, the groups, ch_reduction / k|v stacks, MultiScale conv: everything of head.* ; returns dcat [M4, ctot], the
+        gradient of the multi-scale concat (the trunk-specific part takes it from there)"""
         Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
         L, G, Tn, E, NC, bp = cfg['last_dim'], cfg['n_groups'], cfg['n_tokens'], cfg['ca_dim'], cfg['num_classes'], cfg['bp_dim']
-        d = cfg['dims']
         self.dlogits = self.buf('dlogits', (2 * G, B, NC))
         Bk.zero(self.arena, label='zero.arena')
         # classifiers: one batched wgrad + dgrad for the heads, one for the self_dt_heads
@@ -404,12 +423,7 @@ class MAPEngine(GAEngine):
             Bk.join_async()
         Bk.flush('heads.')
         Bk.mark('heads')      # every gradient of head.* is final here
-        seeds = []
-        for src, hw, c, mode, off in self.agg_segs:
-            ds = self.buf(f'agg.d{off}', (B * hw * hw, c))
-            Bk.pool_concat_bwd(dcat, None, ds, B, hw, hw, c, 14, 14, ctot, off, mode, dt, label=f'agg.b{off}')
-            seeds.append(ds)
-        self._build_trunk_backward({i: seeds[1 + i] for i in range(4)}, [], [], feats, stage_in, stem_seed=seeds[0])
+        return dcat
 
     # ------------------------------------------------------------------------------------------
     def forward(self, x):

@@ -353,6 +353,16 @@ class Plan:
         self._add('ga_attn_bwd', (C.byref(d), _ptr(dout), _ptr(dqkv), _ptr(ws), ws.numel() * ws.element_size()), label,
                   keep=(d, dout, dqkv, ws))
 
+    def patchify(self, x, out, P, dtype, label=None):
+        B, CH, H, W = x.shape
+        self._add('ga_patchify', (_ptr(x), _ptr(out), B, CH, H, W, P, dtype), label, keep=(x, out))
+
+    def vit_embed_fwd(self, tok, cls, pos, x0, B, Np, Cdim, dtype, label=None):
+        self._add('ga_vit_embed_fwd', (_ptr(tok), _ptr(cls), _ptr(pos), _ptr(x0), B, Np, Cdim, dtype), label, keep=(tok, cls, pos, x0))
+
+    def vit_embed_bwd(self, dx0, dtok, dcls, dpos, B, Np, Cdim, dtype, label=None):
+        self._add('ga_vit_embed_bwd', (_ptr(dx0), _ptr(dtok), _ptr(dcls), _ptr(dpos), B, Np, Cdim, dtype), label, keep=(dx0, dtok, dcls, dpos))
+
     # -- alignment-free forms (odd-width variants) -------------------------------------------------
     def small_linear_desc(self, A, W, Y, rows, groups, Ng, Kg, dtype, lda, a_gstride, ldy, bias=None, a_perm=None, col_scale=None,
                           rowscale=None, rows_per_scale=1, R=None, ldr=0, Yraw=None):

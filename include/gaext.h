@@ -536,6 +536,13 @@ typedef struct {
 int ga_attn_fwd(const ga_attn_desc* d, ga_stream_t stream);
 size_t ga_attn_bwd_workspace(const ga_attn_desc* d);
 int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, void* workspace, size_t ws_bytes, ga_stream_t stream);
+/* ViT stem (timm PatchEmbed + cls_token / pos_embed; the P x P stride-P patch convolution becomes a ga_gemm over patches):
+ *   ga_patchify:      fp32 NCHW [B,CH,H,W] -> [B*(H/P)*(W/P)][CH*P*P] in `dtype`, k = (c, ky, kx) (the conv weight's flattened order)
+ *   ga_vit_embed_fwd: x0[b][0] = cls + pos[0];  x0[b][1+p] = tok[b][p] + pos[1+p]      (cls [C], pos [Np+1][C] fp32)
+ *   ga_vit_embed_bwd: dtok = dx0[b][1+p];  dcls += sum_b dx0[b][0];  dpos[t] += sum_b dx0[b][t] */
+int ga_patchify(const float* x, void* out, int B, int CH, int H, int W, int P, int dtype, ga_stream_t stream);
+int ga_vit_embed_fwd(const void* tok, const float* cls, const float* pos, void* x0, int B, int Np, int C, int dtype, ga_stream_t stream);
+int ga_vit_embed_bwd(const void* dx0, void* dtok, float* dcls, float* dpos, int B, int Np, int C, int dtype, ga_stream_t stream);
 
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */

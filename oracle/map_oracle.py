@@ -226,10 +226,11 @@ def forward_features(sd, x, cfg, dp_masks=None):
     return feats
 
 
-def multi_scale(sd, pre, feats, level, training, new_stats):
+def multi_scale(sd, pre, feats, level, training, new_stats, size=None):
     """MultiScale.forward (map.py:322-333): smaller maps are ENLARGED by adaptive_avg_pool2d, larger ones REDUCED by
-    bilinear interpolation (align_corners=False, no antialias); then conv1x1 (no bias) + BN + GELU (non_linearity=nn.GELU)"""
-    h, w = feats[level].shape[2:]
+    bilinear interpolation (align_corners=False, no antialias); then conv1x1 (no bias) + BN + GELU (non_linearity=nn.GELU).
+    size: explicit target (the builder-defined MAP-ViT composition, whose maps all have one size, reduces to half of it)"""
+    h, w = size if size is not None else feats[level].shape[2:]
     ms = []
     for f in feats:
         if h > f.size(2):
@@ -322,7 +323,8 @@ def norm_head(sd, pre, x):
 def map_head(sd, pre, feats, cfg, training, new_stats=None, masks=None):
     """MAPHead.forward (map.py:514-539): train -> [[org_out, avg_out]] per group, eval -> [org_out] per group"""
     masks = masks or {}
-    x = multi_scale(sd, pre + 'mmcap.multi_scale.concat_conv.', feats, cfg['multi_scale_level'], training, new_stats)
+    x = multi_scale(sd, pre + 'mmcap.multi_scale.concat_conv.', feats, cfg['multi_scale_level'], training, new_stats,
+                    cfg.get('multi_scale_size'))
     out_ch = cfg['last_dim'] * cfg['n_tokens']
     outs = []
     for i in range(cfg['n_groups']):
