@@ -36,10 +36,14 @@ MODEL = 'ga_convnext_tiny_768'
 GFLOP_PER_IMG = {'ga_convnext_tiny_768': 34.52, 'ga_convnext_tiny': 34.52, 'ga_convnext_tiny_688': 32.73,
                  'ga_convnext_small_768': 60.76, 'ga_convnext_small': 60.76, 'ga_convnext_small_688': 58.87,
                  'ga_convnext_base_1024': 105.54, 'ga_convnext_base': 105.54, 'ga_convnext_base_976': 104.00,
-                 'ga_CSWin_64_12211_tiny_224': 36.5, 'map_convnext_tiny': 30.37, 'map_convnext_small': 55.85}
+                 'ga_CSWin_64_12211_tiny_224': 36.5, 'map_convnext_tiny': 30.37, 'map_convnext_small': 55.85,
+                 # MAP-ViT (builder-defined, configs[4]): 3 x forward, forward = 2 FLOP/MAC over patch embedding, qkv / proj / MLP linears and
+                 # the two attention products of every block (N = (img/16)^2 + 1 tokens) + the MAP head on (img/32)^2 tokens
+                 'map_vit_base_patch16_384': 336.1, 'map_vit_base_patch16_224': 106.6, 'map_vit_small_patch16_224': 28.6}
 LABEL = {'ga_convnext_tiny_768': 'GA-ConvNeXt-T', 'ga_convnext_small_768': 'GA-ConvNeXt-S', 'ga_convnext_base_1024': 'GA-ConvNeXt-B',
          'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)', 'map_convnext_tiny': 'MAP-ConvNeXt-T',
-         'map_convnext_small': 'MAP-ConvNeXt-S'}
+         'map_convnext_small': 'MAP-ConvNeXt-S', 'map_vit_base_patch16_384': 'MAP-ViT-B/16 @ 384 (builder-defined composition)',
+         'map_vit_base_patch16_224': 'MAP-ViT-B/16 @ 224', 'map_vit_small_patch16_224': 'MAP-ViT-S/16 @ 224'}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -150,6 +154,11 @@ def cpu_baseline(model_name, budget_s=10.0):
         from oracle import ga_cswin_oracle as O
         from oracle.ga_convnext_oracle import adamw_step
         mod = 'oracle/ga_cswin_oracle.py'
+    elif model_name.startswith('map_vit'):
+        from oracle import map_vit_oracle as O
+        from oracle.ga_convnext_oracle import adamw_step
+        mod = 'oracle/map_vit_oracle.py'
+        step_kw = dict(dec_lam=-0.8)
     elif model_name.startswith('map_'):
         from oracle import map_oracle as O
         from oracle.ga_convnext_oracle import adamw_step
@@ -166,7 +175,8 @@ def cpu_baseline(model_name, budget_s=10.0):
     sd = O.fill_state(cfg)
     B = 8
     g = torch.Generator().manual_seed(42)
-    x = torch.randn(B, 3, 224, 224, generator=g)
+    img = cfg.get('img_size', 224)
+    x = torch.randn(B, 3, img, img, generator=g)
     y = torch.randint(0, 1000, (B,), generator=g)
     m, v = {}, {}
     times = []
@@ -240,7 +250,8 @@ def main():
     opt = A.create_optimizer_v2(model, opt=a.opt, lr=1e-3, weight_decay=0.05, momentum=0.9)
     step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce', broadcast_buffers=not a.no_ddp_bb)
     g = torch.Generator().manual_seed(42 + rank)
-    x = torch.randn(a.batch, 3, 224, 224, generator=g).cuda()
+    img = getattr(model, 'cfg', {}).get('img_size', 224)
+    x = torch.randn(a.batch, 3, img, img, generator=g).cuda()
     y = torch.randint(0, model.num_classes, (a.batch,), generator=g).cuda()
 
     def barrier():
@@ -266,11 +277,11 @@ def main():
     gflop = GFLOP_PER_IMG.get(a.model)
     label = LABEL.get(a.model, a.model)
 
-    out = dict(metric=f'images/sec (whole node) {label} 3x224x224 {a.math} training step', value=round(value, 1),
+    out = dict(metric=f'images/sec (whole node) {label} 3x{img}x{img} {a.math} training step', value=round(value, 1),
                unit='images/sec', n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms_per_step, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.math, data='synthetic',
                config=dict(workload=f'{a.model} train step (fwd + GA loss lam=-0.8 + bwd + all-reduce + {a.opt}), '
-                                    f'batch {a.batch}/GPU, drop_path 0.2, synthetic 3x224x224',
+                                    f'batch {a.batch}/GPU, drop_path 0.2, synthetic 3x{img}x{img}',
                            global_batch=a.batch * world, parallelism=f'dp{world}', dist_backend=backend,
                            allreduce_buckets=len(step.buckets), gflop_per_img=gflop),
                loss=round(loss_val, 4))

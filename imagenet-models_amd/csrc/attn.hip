@@ -63,6 +63,24 @@ __device__ __forceinline__ void load_block(unsigned char* dst, const bf16_t* src
     }
 }
 
+// the same block in two steps: global -> registers (issued a whole block ahead of its use), registers -> LDS
+struct BlockRegs { u32x4_t v[2]; };
+__device__ __forceinline__ void fetch_block(BlockRegs& b, const bf16_t* src, long ld, int r0, int nrows) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = threadIdx.x + 256 * j, r = i >> 3, c = i & 7;
+        b.v[j] = u32x4_t{0, 0, 0, 0};
+        if (r0 + r < nrows) b.v[j] = *reinterpret_cast<const u32x4_t*>(src + (long)(r0 + r) * ld + c * 8);
+    }
+}
+__device__ __forceinline__ void put_block(unsigned char* dst, const BlockRegs& b) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i = threadIdx.x + 256 * j, r = i >> 3, c = i & 7;
+        *reinterpret_cast<u32x4_t*>(dst + (c >> 2) * SLAB + tile_off(r, c & 3)) = b.v[j];
+    }
+}
+
 // fp32 accumulator tiles o[dt] (rows 4g + r, column 16 dt + (lane & 15)) of one wave's 16 rows -> bf16 rows through this wave's
 // 2 KiB staging piece -> 16-byte global stores (8 lanes per row)
 __device__ __forceinline__ void store_rows16(unsigned char* stage, const f32x4_t (&o)[4], bf16_t* dst, long ld, int r0, int nrows,
@@ -121,11 +139,18 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
     f32x4_t o[4] = {zero, zero, zero, zero};
     float m = -3.0e38f, l = 0.f;
     const float sc = d.scale * 1.44269504f;                    // exp2 domain
+    BlockRegs kr, vr;                                          // the next key / value block travels in registers
+    fetch_block(kr, qkv + C, d.ldq, 0, d.N);
+    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N);
     for (int k0 = 0; k0 < d.N; k0 += BQ) {
         __syncthreads();                                       // everyone is done with the previous key block
-        load_block(Ks, qkv + C, d.ldq, k0, d.N);
-        load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+        put_block(Ks, kr);
+        put_block(Vs, vr);
         __syncthreads();
+        if (k0 + BQ < d.N) {
+            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N);
+            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N);
+        }
         f32x4_t st[4];
         float mx = -3.0e38f;
 #pragma unroll
@@ -196,6 +221,33 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const ga_attn_desc d, c
     delta[i] = s;
 }
 
+// the same with whole-row coalesced reads (hd / 8 a power of two): thread = 8 consecutive channels of one token row, the hd / 8
+// lanes of a head reduce by shuffles (the per-(b, h, q) form above reads 64 scattered 128-byte pieces per wave: 1.4 ms at
+// ViT-B / 384 / B = 128, more than the three MFMA kernels of the backward together)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_rows_kernel(const ga_attn_desc d, const void* dout_, float* delta) {
+    const int C8 = d.H * d.hd / 8, L = d.hd / 8;
+    const long n = (long)d.B * d.N * C8;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f;
+    long row = 0;
+    int c8 = 0;
+    if (i < n) {
+        row = i / C8;
+        c8 = (int)(i - row * C8);
+        float a[8], g[8];
+        load8(reinterpret_cast<const T*>(d.out) + row * d.ldo + c8 * 8, a);
+        load8(reinterpret_cast<const T*>(dout_) + row * d.ldo + c8 * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(a[j], g[j], s);
+    }
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o, 64);
+    if (i < n && (c8 & (L - 1)) == 0) {
+        const long b = row / d.N, q = row - b * d.N;
+        delta[(b * d.H + c8 / L) * d.N + q] = s;
+    }
+}
+
 // =================================================================================================================
 // backward dQ, bf16, head_dim 64: one workgroup per 64 queries, keys / values streamed
 // =================================================================================================================
@@ -225,11 +277,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
     const float lse = qi < d.N ? d.lse[sidx] : 0.f, dl = qi < d.N ? delta[sidx] : 0.f;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t o[4] = {zero, zero, zero, zero};
+    BlockRegs kr, vr;
+    fetch_block(kr, qkv + C, d.ldq, 0, d.N);
+    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N);
     for (int k0 = 0; k0 < d.N; k0 += BQ) {
         __syncthreads();
-        load_block(Ks, qkv + C, d.ldq, k0, d.N);
-        load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+        put_block(Ks, kr);
+        put_block(Vs, vr);
         __syncthreads();
+        if (k0 + BQ < d.N) {
+            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N);
+            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N);
+        }
         f32x4_t ds[4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
@@ -293,16 +352,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
     const long sbase = ((long)it.b * d.H + it.h) * d.N;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t dv[4] = {zero, zero, zero, zero}, dk[4] = {zero, zero, zero, zero};
-    for (int q0 = 0; q0 < d.N; q0 += BQ) {
-        __syncthreads();
-        load_block(Qs, qkv, d.ldq, q0, d.N);
-        load_block(Gs, dout, d.ldo, q0, d.N);
+    BlockRegs qr, gr;
+    float lr = 0.f, dr = 0.f;                                  // this thread's lse / delta entry of the next query block (threads < 64)
+    auto fetch_q = [&](int q0) {
+        fetch_block(qr, qkv, d.ldq, q0, d.N);
+        fetch_block(gr, dout, d.ldo, q0, d.N);
         if (threadIdx.x < BQ) {
             const int q = q0 + threadIdx.x;
-            lse_s[threadIdx.x] = q < d.N ? d.lse[sbase + q] : 0.f;
-            dlt_s[threadIdx.x] = q < d.N ? delta[sbase + q] : 0.f;
+            lr = q < d.N ? d.lse[sbase + q] : 0.f;
+            dr = q < d.N ? delta[sbase + q] : 0.f;
+        }
+    };
+    fetch_q(0);
+    for (int q0 = 0; q0 < d.N; q0 += BQ) {
+        __syncthreads();
+        put_block(Qs, qr);
+        put_block(Gs, gr);
+        if (threadIdx.x < BQ) {
+            lse_s[threadIdx.x] = lr;
+            dlt_s[threadIdx.x] = dr;
         }
         __syncthreads();
+        if (q0 + BQ < d.N) fetch_q(q0 + BQ);
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             f32x4_t p[2], ds[2];
@@ -545,8 +616,19 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
     float* delta = reinterpret_cast<float*>(workspace);
     const long n = (long)d->B * d->H * d->N;
     const unsigned g256 = (unsigned)((n + 255) / 256), g128 = (unsigned)((n + 127) / 128);
-    if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
-    else hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+    const int L8 = d->hd / 8;
+    const bool rows_form = d->hd % 8 == 0 && (L8 & (L8 - 1)) == 0 && L8 <= 64 && (d->H * L8) % L8 == 0 && aligned16(d->out) && aligned16(dout) &&
+                           d->ldo % (d->dtype == GA_BF16 ? 8 : 4) == 0 && (256 % L8) == 0;
+    if (rows_form) {
+        const long nt = (long)d->B * d->N * d->H * L8;
+        const unsigned gr = (unsigned)((nt + 255) / 256);
+        if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_delta_rows_kernel<bf16_t>, dim3(gr), dim3(256), 0, s, *d, dout, delta);
+        else hipLaunchKernelGGL(attn_delta_rows_kernel<float>, dim3(gr), dim3(256), 0, s, *d, dout, delta);
+    } else if (d->dtype == GA_BF16) {
+        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+    } else {
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+    }
     if (use_mfma(d) && aligned16(dout) && aligned16(dqkv)) {
         const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
         hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk, nwg);
