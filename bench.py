@@ -101,6 +101,10 @@ def time_plan_calls(plan, fams, per_call=None):
             fam, flops = 'gemm_tn(wgrad)', 2.0 * d.M * d.N * d.K * d.batch
         elif isinstance(d, L.GemmDesc):
             fam, flops = 'gemm_nt', 2.0 * d.M * d.N * d.K * d.batch
+        elif isinstance(d, L.AttnDesc):       # global attention: QK^T and PV forward; S, dP, dQ, dK, dV backward (2.5x)
+            bwd = 'attnb' in label
+            fam = 'global_attn_bwd' if bwd else 'global_attn_fwd'
+            flops = 4.0 * d.B * d.H * d.N * d.N * d.hd * (2.5 if bwd else 1.0)
         elif isinstance(d, L.MlpDesc):        # fc1 + fc2
             fam, flops = 'mlp_fused_fwd', 4.0 * d.M * d.C * d.H
         elif isinstance(d, L.MlpBwdDesc):     # re-computed fc1 + dgrad2 + dgrad1
@@ -108,7 +112,7 @@ def time_plan_calls(plan, fams, per_call=None):
         else:
             fam = kernel_family(label)
         if per_call is not None:
-            shape = (f'M{d.M} N{d.N} K{d.K} b{d.batch}' if hasattr(d, 'N') else f'M{d.M} C{d.C} H{d.H}') if d is not None and hasattr(d, 'M') else ''
+            shape = (f'M{d.M} N{d.N} K{d.K} b{d.batch}' if hasattr(d, 'K') else f'M{d.M} C{d.C} H{d.H}') if d is not None and hasattr(d, 'M') else (f'B{d.B} N{d.N} H{d.H} hd{d.hd}' if isinstance(d, L.AttnDesc) else '')
             per_call.append(dict(label=f'{plan.name}:{label}', fam=fam, ms=round(ms, 4), shape=shape,
                                  tflops=round(flops / ms / 1e9, 1) if flops and ms > 0 else None))
         f = fams.setdefault(fam, dict(ms=0.0, flops=0.0, launches=0))

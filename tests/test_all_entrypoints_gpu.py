@@ -14,7 +14,7 @@ def _names():
 
 @pytest.mark.parametrize('name', ['ga_convnext_small_768', 'ga_convnext_small_688', 'ga_convnext_base_1024', 'ga_convnext_base_976',
                                   'ga_CSWin_64_24322_small_224', 'map_convnext_small', 'ga_convnext_tiny', 'ga_convnext_small',
-                                  'ga_convnext_base'])
+                                  'ga_convnext_base', 'map_vit_small_patch16_224', 'map_vit_base_patch16_224'])
 def test_entry_point_trains_and_evaluates(name):
     import imagenet_models_amd as A
     assert name in _names()
@@ -22,7 +22,8 @@ def test_entry_point_trains_and_evaluates(name):
     m = A.create_model(name, pretrained=False, drop_path_rate=0.1).cuda().train()
     opt = A.create_optimizer_v2(m, opt='adamw', lr=1e-4, weight_decay=0.05)
     step = A.TrainStep(m, opt, 4, lam=-0.8)
-    x = torch.randn(4, 3, 224, 224, device='cuda')
+    img = m.cfg.get('img_size', 224)
+    x = torch.randn(4, 3, img, img, device='cuda')
     y = torch.randint(0, 1000, (4,), device='cuda')
     loss = step(x, y)
     loss = step(x, y)
@@ -37,8 +38,8 @@ def test_entry_point_trains_and_evaluates(name):
 
 def test_every_listed_model_is_covered_somewhere():
     """list_models() holds exactly the factories of the three families (ga_convnext.py:572-613 + README aliases, the two CSWin
-    candidates, map_convnext.py:173-240)"""
+    candidates, map_convnext.py:173-240, the builder-defined MAP-ViT compositions)"""
     assert set(_names()) == {'ga_convnext_tiny_688', 'ga_convnext_tiny_768', 'ga_convnext_small_688', 'ga_convnext_small_768',
                              'ga_convnext_base_976', 'ga_convnext_base_1024', 'ga_convnext_tiny', 'ga_convnext_small',
                              'ga_convnext_base', 'ga_CSWin_64_12211_tiny_224', 'ga_CSWin_64_24322_small_224', 'map_convnext_tiny',
-                             'map_convnext_small'}
+                             'map_convnext_small', 'map_vit_base_patch16_384', 'map_vit_base_patch16_224', 'map_vit_small_patch16_224'}

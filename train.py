@@ -79,8 +79,8 @@ parser.add_argument('--local_rank', default=0, type=int)
 class SyntheticLoader:
     """fixed-shape random batches generated on the device (seed = args.seed + rank, like timm random_seed)"""
 
-    def __init__(self, batch, steps, num_classes, seed, device):
-        self.batch, self.steps, self.nc = batch, steps, num_classes
+    def __init__(self, batch, steps, num_classes, seed, device, img=224):
+        self.batch, self.steps, self.nc, self.img = batch, steps, num_classes, img
         self.g = torch.Generator(device=device).manual_seed(seed)
         self.device = device
 
@@ -89,7 +89,7 @@ class SyntheticLoader:
 
     def __iter__(self):
         for _ in range(self.steps):
-            x = torch.randn(self.batch, 3, 224, 224, device=self.device, generator=self.g)
+            x = torch.randn(self.batch, 3, self.img, self.img, device=self.device, generator=self.g)
             y = torch.randint(0, self.nc, (self.batch,), device=self.device, generator=self.g)
             yield x, y
 
@@ -195,8 +195,9 @@ def main():
                           clip_grad=args.clip_grad, clip_mode=args.clip_mode, broadcast_buffers=not args.no_ddp_bb,
                           mixup_fn=mixup_fn, bce_target_thresh=args.bce_target_thresh)
     model_ema = A.ModelEma(model, args.model_ema_decay) if args.model_ema else None
-    loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda')
-    eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda')
+    img = getattr(model, 'cfg', {}).get('img_size', 224)
+    loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda', img)
+    eval_loader = SyntheticLoader(args.batch_size, max(1, args.steps_per_epoch // 10), model.num_classes, 7 + rank, 'cuda', img)
     model.train()
     for epoch in range(args.epochs):
         if sched is not None:

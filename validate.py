@@ -36,11 +36,12 @@ def main():
     g = torch.Generator(device='cuda').manual_seed(0)
     n = c1 = c5 = 0
     with torch.no_grad():
-        model(torch.randn(args.batch_size, 3, 224, 224, device='cuda', generator=g))  # warm-up (MAP/validate.py:240)
+        img = getattr(model, 'cfg', {}).get('img_size', 224)
+        model(torch.randn(args.batch_size, 3, img, img, device='cuda', generator=g))  # warm-up (MAP/validate.py:240)
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(args.batches):
-            x = torch.randn(args.batch_size, 3, 224, 224, device='cuda', generator=g)
+            x = torch.randn(args.batch_size, 3, img, img, device='cuda', generator=g)
             y = torch.randint(0, model.num_classes, (args.batch_size,), device='cuda', generator=g)
             _, idx = A.heads_topk(model(x), 5)
             a1, a5 = A.accuracy_from_topk(idx, y, (1, 5))
