@@ -1198,7 +1198,9 @@ bool want_dma2(const ga_gemm_desc* d, int epi) {
 // 256 x 256 tile, 8 waves (64 x 128 each), LDS-DMA into a 2-slot ring: wide-N launches
 bool want_t256(const ga_gemm_desc* d, int epi) {
     const char* e = getenv("GAEXT_NT_T256");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
-    const int mask = e ? atoi(e) : 0;
+    // unset: every epilogue, but only for the very tall launches (M >= 65536: the ViT trunk's 73,856 token rows, -4.8 % on the
+    // MAP-ViT-B/384 step); on the ConvNeXt / CSWin stage-2/3 shapes (M = 50,176) the form measured -12 .. +5 % and stays off
+    const int mask = e ? atoi(e) : ((d->M >= 65536 && d->N >= 768) ? 15 : 0);      // (N >= 768: the CSWin stem's N = 256 launches lose 2 %)
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC) return false;
     if (d->N % 256 != 0 || d->K < 256) return false;
     if ((long)cdiv(d->M, 256) * (d->N / 256) * d->batch < num_cus()) return false;
