@@ -178,6 +178,14 @@ _SIGS = {
     'ga_patchify': ([vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_vit_embed_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
     'ga_vit_embed_bwd': ([vp, vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_patchify_strided': ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_pos_add_fwd': ([vp, vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_pos_add_bwd': ([vp, vp, i32, i32, i32, i32, vp], i32),
+    'ga_dwpool_fwd': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwpool_bwd_data': ([vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_dwpool_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
+    'ga_resize_concat_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp], i32),
+    'ga_resize_concat_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

@@ -54,23 +54,24 @@ constexpr int SLAB = BQ * 64;           // bytes of one [64][32] slab
 constexpr int TILE = 2 * SLAB;          // [64][64] bf16
 
 // rows [r0, r0 + 64) x 64 columns of a [B*N][ld] column slice -> two slabs; rows >= nrows (end of the sequence) are zero
-__device__ __forceinline__ void load_block(unsigned char* dst, const bf16_t* src, long ld, int r0, int nrows) {
+// (hc = head_dim / 8 column chunks are real, the rest of the 64-wide tile is zero: head_dim 16 / 32 / 48 ride the same code)
+__device__ __forceinline__ void load_block(unsigned char* dst, const bf16_t* src, long ld, int r0, int nrows, int hc) {
     for (int i = threadIdx.x; i < BQ * 8; i += 256) {
         const int r = i >> 3, c = i & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (r0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)(r0 + r) * ld + c * 8);
+        if (r0 + r < nrows && c < hc) v = *reinterpret_cast<const uint4*>(src + (long)(r0 + r) * ld + c * 8);
         *reinterpret_cast<uint4*>(dst + (c >> 2) * SLAB + tile_off(r, c & 3)) = v;
     }
 }
 
 // the same block in two steps: global -> registers (issued a whole block ahead of its use), registers -> LDS
 struct BlockRegs { u32x4_t v[2]; };
-__device__ __forceinline__ void fetch_block(BlockRegs& b, const bf16_t* src, long ld, int r0, int nrows) {
+__device__ __forceinline__ void fetch_block(BlockRegs& b, const bf16_t* src, long ld, int r0, int nrows, int hc) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int i = threadIdx.x + 256 * j, r = i >> 3, c = i & 7;
         b.v[j] = u32x4_t{0, 0, 0, 0};
-        if (r0 + r < nrows) b.v[j] = *reinterpret_cast<const u32x4_t*>(src + (long)(r0 + r) * ld + c * 8);
+        if (r0 + r < nrows && c < hc) b.v[j] = *reinterpret_cast<const u32x4_t*>(src + (long)(r0 + r) * ld + c * 8);
     }
 }
 __device__ __forceinline__ void put_block(unsigned char* dst, const BlockRegs& b) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void put_block(unsigned char* dst, const BlockRegs& b
 // fp32 accumulator tiles o[dt] (rows 4g + r, column 16 dt + (lane & 15)) of one wave's 16 rows -> bf16 rows through this wave's
 // 2 KiB staging piece -> 16-byte global stores (8 lanes per row)
 __device__ __forceinline__ void store_rows16(unsigned char* stage, const f32x4_t (&o)[4], bf16_t* dst, long ld, int r0, int nrows,
-                                             int lane) {
+                                             int lane, int hc) {
     bf16_t* st = reinterpret_cast<bf16_t*>(stage);
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -96,7 +97,7 @@ __device__ __forceinline__ void store_rows16(unsigned char* stage, const f32x4_t
     for (int p = 0; p < 2; ++p) {
         const int r = 8 * p + (lane >> 3), c = lane & 7;
         const uint4 v = *reinterpret_cast<const uint4*>(stage + r * 128 + c * 16);
-        if (r0 + r < nrows) *reinterpret_cast<uint4*>(dst + (long)(r0 + r) * ld + c * 8) = v;
+        if (r0 + r < nrows && c < hc) *reinterpret_cast<uint4*>(dst + (long)(r0 + r) * ld + c * 8) = v;
     }
 }
 
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
     unsigned char* Stage = Vs + TILE;            // 4 x 2 KiB
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int C = d.H * 64, q0 = it.blk * BQ;
-    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
-    load_block(Qs, qkv, d.ldq, q0, d.N);
+    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
+    load_block(Qs, qkv, d.ldq, q0, d.N, hc);
     __syncthreads();
     bf16x8_t qf[2];
 #pragma unroll
@@ -140,16 +141,16 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
     float m = -3.0e38f, l = 0.f;
     const float sc = d.scale * 1.44269504f;                    // exp2 domain
     BlockRegs kr, vr;                                          // the next key / value block travels in registers
-    fetch_block(kr, qkv + C, d.ldq, 0, d.N);
-    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N);
+    fetch_block(kr, qkv + C, d.ldq, 0, d.N, hc);
+    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N, hc);
     for (int k0 = 0; k0 < d.N; k0 += BQ) {
         __syncthreads();                                       // everyone is done with the previous key block
         put_block(Ks, kr);
         put_block(Vs, vr);
         __syncthreads();
         if (k0 + BQ < d.N) {
-            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N);
-            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N);
+            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N, hc);
+            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N, hc);
         }
         f32x4_t st[4];
         float mx = -3.0e38f;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
         for (int dt = 0; dt < 4; ++dt) o[dt][r] *= lr;
     }
     const int qw = q0 + 16 * wave;
-    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(d.out) + it.row0 * d.ldo + it.h * 64, d.ldo, qw, d.N, lane);
+    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(d.out) + it.row0 * d.ldo + it.h * d.hd, d.ldo, qw, d.N, lane, hc);
     if (lane < 16 && qw + lane < d.N) d.lse[((long)it.b * d.H + it.h) * d.N + qw + lane] = m * 0.69314718f + __logf(l);   // natural-log units
 }
 
@@ -248,6 +249,29 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const ga_attn_desc
     }
 }
 
+// head dims whose chunk count is not a power of two (PiT: 48): thread = one (row, head), hd / 8 16-byte loads each; the lanes of a
+// wave cover consecutive heads of a row, so the wave's reads are one contiguous span when ldo = H * hd
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_heads_kernel(const ga_attn_desc d, const void* dout_, float* delta) {
+    const long n = (long)d.B * d.N * d.H;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long row = i / d.H;
+    const int h = (int)(i - row * d.H);
+    const T* o = reinterpret_cast<const T*>(d.out) + row * d.ldo + h * d.hd;
+    const T* go = reinterpret_cast<const T*>(dout_) + row * d.ldo + h * d.hd;
+    float s = 0.f;
+    for (int c = 0; c < d.hd; c += 8) {
+        float a[8], g[8];
+        load8(o + c, a);
+        load8(go + c, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = fmaf(a[j], g[j], s);
+    }
+    const long b = row / d.N, q = row - b * d.N;
+    delta[(b * d.H + h) * d.N + q] = s;
+}
+
 // =================================================================================================================
 // backward dQ, bf16, head_dim 64: one workgroup per 64 queries, keys / values streamed
 // =================================================================================================================
@@ -261,10 +285,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
     unsigned char* Stage = Vs + TILE;
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int C = d.H * 64, q0 = it.blk * BQ;
-    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
-    load_block(Qs, qkv, d.ldq, q0, d.N);
-    load_block(Gs, reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * 64, d.ldo, q0, d.N);
+    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
+    load_block(Qs, qkv, d.ldq, q0, d.N, hc);
+    load_block(Gs, reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * d.hd, d.ldo, q0, d.N, hc);
     __syncthreads();
     bf16x8_t qf[2], gf[2];
 #pragma unroll
@@ -278,16 +302,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
     f32x4_t o[4] = {zero, zero, zero, zero};
     BlockRegs kr, vr;
-    fetch_block(kr, qkv + C, d.ldq, 0, d.N);
-    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N);
+    fetch_block(kr, qkv + C, d.ldq, 0, d.N, hc);
+    fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N, hc);
     for (int k0 = 0; k0 < d.N; k0 += BQ) {
         __syncthreads();
         put_block(Ks, kr);
         put_block(Vs, vr);
         __syncthreads();
         if (k0 + BQ < d.N) {
-            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N);
-            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N);
+            fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N, hc);
+            fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N, hc);
         }
         f32x4_t ds[4];
 #pragma unroll
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][r] *= d.scale;
-    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * 64, d.ldq, q0 + 16 * wave, d.N, lane);
+    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * d.hd, d.ldq, q0 + 16 * wave, d.N, lane, hc);
 }
 
 // =================================================================================================================
@@ -335,12 +359,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
     float* dlt_s = lse_s + BQ;                                     // [64]
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int C = d.H * 64, k0 = it.blk * BQ;
-    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * 64;
-    const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * 64;
-    bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * 64;
-    load_block(Ks, qkv + C, d.ldq, k0, d.N);
-    load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N);
+    const int hc = d.hd >> 3, C = d.H * d.hd, k0 = it.blk * BQ;
+    const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
+    const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * d.hd;
+    bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * d.hd;
+    load_block(Ks, qkv + C, d.ldq, k0, d.N, hc);
+    load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N, hc);
     __syncthreads();
     bf16x8_t kf[2], vf[2];
 #pragma unroll
@@ -355,8 +379,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
     BlockRegs qr, gr;
     float lr = 0.f, dr = 0.f;                                  // this thread's lse / delta entry of the next query block (threads < 64)
     auto fetch_q = [&](int q0) {
-        fetch_block(qr, qkv, d.ldq, q0, d.N);
-        fetch_block(gr, dout, d.ldo, q0, d.N);
+        fetch_block(qr, qkv, d.ldq, q0, d.N, hc);
+        fetch_block(gr, dout, d.ldo, q0, d.N, hc);
         if (threadIdx.x < BQ) {
             const int q = q0 + threadIdx.x;
             lr = q < d.N ? d.lse[sbase + q] : 0.f;
@@ -409,8 +433,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dk[dt][r] *= d.scale;
-    store_rows16(Stage + wave * 2048, dk, dqkv + C, d.ldq, k0 + 16 * wave, d.N, lane);
-    store_rows16(Stage + wave * 2048, dv, dqkv + 2 * C, d.ldq, k0 + 16 * wave, d.N, lane);
+    store_rows16(Stage + wave * 2048, dk, dqkv + C, d.ldq, k0 + 16 * wave, d.N, lane, hc);
+    store_rows16(Stage + wave * 2048, dv, dqkv + 2 * C, d.ldq, k0 + 16 * wave, d.N, lane, hc);
 }
 
 // =================================================================================================================
@@ -515,19 +539,21 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_simple(const ga_attn_desc d,
 // =================================================================================================================
 // ViT stem helpers (timm PatchEmbed + cls_token / pos_embed): the P x P / stride P patch convolution is a GEMM over patches
 //   ga_patchify:  fp32 NCHW [B,3,H,W] -> [B*(H/P)*(W/P)][3*P*P] in T, k = (c, ky, kx) = the flattened conv weight's order
+//   ga_patchify_strided: the same for a patch convolution whose stride S differs from P (PiT conv_embedding: 16 / 8, overlapping)
 //   ga_vit_embed_fwd:  x0[b][0] = cls + pos[0];  x0[b][1+p] = tok[b][p] + pos[1+p]
 //   ga_vit_embed_bwd:  dtok = dx0[b][1+p];  dcls += sum_b dx0[b][0];  dpos[t] += sum_b dx0[b][t]
 // =================================================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int CH, int H, int W, int P) {
-    const int gw = W / P, gh = H / P, K = CH * P * P, K8 = K / 8;
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, T* __restrict__ out, int B, int CH, int H, int W, int P,
+                                                       int S) {
+    const int gw = (W - P) / S + 1, gh = (H - P) / S + 1, K = CH * P * P, K8 = K / 8;
     const long n = (long)B * gh * gw * K8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int k = (int)(i % K8) * 8;
         const long row = i / K8;
         const int px = (int)(row % gw), py = (int)((row / gw) % gh), b = (int)(row / ((long)gw * gh));
         const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
-        const float* src = x + (((long)b * CH + c) * H + py * P + ky) * W + px * P + kx;
+        const float* src = x + (((long)b * CH + c) * H + py * S + ky) * W + px * S + kx;
         const float4 a = *reinterpret_cast<const float4*>(src), bq = *reinterpret_cast<const float4*>(src + 4);
         float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
         store8(out + row * K + k, v);
@@ -587,7 +613,7 @@ int check_desc(const ga_attn_desc* d, const char* what) {
 
 bool use_mfma(const ga_attn_desc* d) {
     const char* e = getenv("GAEXT_ATTN_MFMA");
-    return (!e || atoi(e)) && d->dtype == GA_BF16 && d->hd == 64 && d->ldq % 8 == 0 && d->ldo % 8 == 0 && aligned16(d->qkv) && aligned16(d->out);
+    return (!e || atoi(e)) && d->dtype == GA_BF16 && d->hd % 16 == 0 && d->hd <= 64 && d->ldq % 8 == 0 && d->ldo % 8 == 0 && aligned16(d->qkv) && aligned16(d->out);
 }
 
 }  // namespace
@@ -624,6 +650,9 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
         const unsigned gr = (unsigned)((nt + 255) / 256);
         if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_delta_rows_kernel<bf16_t>, dim3(gr), dim3(256), 0, s, *d, dout, delta);
         else hipLaunchKernelGGL(attn_delta_rows_kernel<float>, dim3(gr), dim3(256), 0, s, *d, dout, delta);
+    } else if (d->hd % 8 == 0 && aligned16(d->out) && aligned16(dout) && d->ldo % 8 == 0) {
+        if (d->dtype == GA_BF16) hipLaunchKernelGGL(attn_delta_heads_kernel<bf16_t>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
+        else hipLaunchKernelGGL(attn_delta_heads_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
     } else if (d->dtype == GA_BF16) {
         hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
     } else {
@@ -645,15 +674,21 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
     return ga_check_launch("ga_attn_bwd");
 }
 
-extern "C" int ga_patchify(const float* x, void* out, int B, int CH, int H, int W, int P, int dtype, ga_stream_t stream) {
-    GA_REQUIRE(x && out && B > 0 && CH > 0 && P > 0 && P % 8 == 0 && H % P == 0 && W % P == 0 && W % 4 == 0 && aligned16(x) && aligned16(out),
-               "ga_patchify: patch size must be a multiple of 8 and divide the 16-byte aligned image");
-    const long n = (long)B * (H / P) * (W / P) * (CH * P * P / 8);
+extern "C" int ga_patchify_strided(const float* x, void* out, int B, int CH, int H, int W, int P, int S, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(x && out && B > 0 && CH > 0 && P > 0 && P % 8 == 0 && S > 0 && S % 4 == 0 && H >= P && W >= P && W % 4 == 0 && aligned16(x) &&
+                   aligned16(out),
+               "ga_patchify_strided: patch size %% 8, stride %% 4, a 16-byte aligned image at least one patch large");
+    const long n = (long)B * ((H - P) / S + 1) * ((W - P) / S + 1) * (CH * P * P / 8);
     const int blocks = (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == GA_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, (bf16_t*)out, B, CH, H, W, P);
-    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)out, B, CH, H, W, P);
-    return ga_check_launch("ga_patchify");
+    if (dtype == GA_BF16) hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, x, (bf16_t*)out, B, CH, H, W, P, S);
+    else hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, s, x, (float*)out, B, CH, H, W, P, S);
+    return ga_check_launch("ga_patchify_strided");
+}
+
+extern "C" int ga_patchify(const float* x, void* out, int B, int CH, int H, int W, int P, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(P > 0 && H % P == 0 && W % P == 0, "ga_patchify: the patch size must divide the image");
+    return ga_patchify_strided(x, out, B, CH, H, W, P, P, dtype, stream);
 }
 
 extern "C" int ga_vit_embed_fwd(const void* tok, const float* cls, const float* pos, void* x0, int B, int Np, int C, int dtype,

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(256) void map_tokens_bwd_kernel(const T* __restrict
 //   P [B][T][heads][N] fp32 = a (saved for backward)
 // One workgroup of 16 waves per sample; a WAVE per k | v row, lane c = the row's 8-channel chunk c (whole 16-byte lines).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kW = 16, kThr = 64 * kW, kMaxT = 4;
+constexpr int kW = 16, kThr = 64 * kW, kMaxT = 8;   // kernels are built for MT = 4 (T <= 4, the ConvNeXt / ViT heads), 6 (map_pit_s: T = 5) and 8
 
-template <typename T>
+template <typename T, int MT>
 __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv_cls,
                                                            const T* __restrict__ kv_tok, long tok_ld, T* __restrict__ out,
                                                            float* __restrict__ P, const float* __restrict__ mask, int Tn, int N,
@@ -117,9 +117,9 @@ __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__
         }
     }
     __syncthreads();
-    float acc[kMaxT][8];
+    float acc[MT][8];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
     const int hl = live ? lane / cph : 0;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__
             float v[8];
             load8(row(n) + E + lane * 8, v);
 #pragma unroll
-            for (int t = 0; t < kMaxT; ++t) {
+            for (int t = 0; t < MT; ++t) {
                 if (t < Tn) {
                     const float p = pl[(t * heads + hl) * N + n];
 #pragma unroll
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t < Tn) {
             __syncthreads();
             if (live) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__
 }
 
 // backward: dout [B][T][E] -> dq [B][T][E], dkv_cls [B][T][2E], dkv_tok rows (overwritten)
-template <typename T>
+template <typename T, int MT>
 __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
                                                            const T* __restrict__ kv_cls, const T* __restrict__ kv_tok, long tok_ld,
                                                            const float* __restrict__ P, const float* __restrict__ mask,
@@ -177,9 +177,9 @@ __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__
     T* dkc = dkv_cls + b * Tn * 2 * E;
     T* dkt = dkv_tok + b * (N - Tn) * dtok_ld - (long)Tn * dtok_ld;
     auto row = [&](int n) { return n < Tn ? kvc + (long)n * 2 * E : kvt + (long)n * tok_ld; };
-    float dov[kMaxT][8], qv[kMaxT][8];
+    float dov[MT][8], qv[MT][8];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t < Tn && live) {
             load8(dout + (b * Tn + t) * E + lane * 8, dov[t]);
             load8(q + (b * Tn + t) * E + lane * 8, qv[t]);
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t >= Tn) break;
         __syncthreads();
         for (int n = wave; n < N; n += kW) {
@@ -224,9 +224,9 @@ __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__
         }
     }
     __syncthreads();
-    float acc[kMaxT][8];
+    float acc[MT][8];
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t)
+    for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[t][e] = 0.f;
     const int hl = live ? lane / cph : 0;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__
 #pragma unroll
             for (int e = 0; e < 8; ++e) dk[e] = dv[e] = 0.f;
 #pragma unroll
-            for (int t = 0; t < kMaxT; ++t) {
+            for (int t = 0; t < MT; ++t) {
                 if (t < Tn) {
                     const float ds = dsl[(t * heads + hl) * N + n], p = pl[(t * heads + hl) * N + n];
 #pragma unroll
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kThr) void mt_attn_bwd_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int t = 0; t < kMaxT; ++t) {
+    for (int t = 0; t < MT; ++t) {
         if (t < Tn) {
             __syncthreads();
             if (live) {
@@ -397,13 +397,15 @@ extern "C" int ga_class_attn_mt_fwd(const void* q, const void* kv_cls, const voi
     const size_t lds = mt_lds(T_, N, heads, hd, false);
     GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_fwd: %zu B of LDS needed", lds);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_fwd_kernel<bf16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_fwd_kernel<float>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    auto reserve = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    static const bool ok = reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<bf16_t, 4>)) && reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<float, 4>)) &&
+                           reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<bf16_t, 6>)) && reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<float, 6>)) &&
+                           reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<bf16_t, 8>)) && reserve(reinterpret_cast<const void*>(mt_attn_fwd_kernel<float, 8>));
     GA_REQUIRE(ok, "ga_class_attn_mt_fwd: cannot reserve LDS");
-    MAP_DISPATCH(dtype, mt_attn_fwd_kernel, dim3(B), dim3(kThr), lds, s, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld,
-                 (T*)out, P, mask, T_, N, heads, hd, scale);
+#define MT_LAUNCH(TT, MTT) hipLaunchKernelGGL((mt_attn_fwd_kernel<TT, MTT>), dim3(B), dim3(kThr), lds, s, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld, (T*)out, P, mask, T_, N, heads, hd, scale)
+    if (dtype == GA_BF16) { using T = bf16_t; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
+    else { using T = float; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
+#undef MT_LAUNCH
     return ga_check_launch("ga_class_attn_mt_fwd");
 }
 
@@ -418,13 +420,15 @@ extern "C" int ga_class_attn_mt_bwd(const void* dout, const void* q, const void*
     const size_t lds = mt_lds(T_, N, heads, hd, true);
     GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_bwd: %zu B of LDS needed", lds);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
-                           hipFuncSetAttribute(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    auto reserve = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    static const bool ok = reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t, 4>)) && reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float, 4>)) &&
+                           reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t, 6>)) && reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float, 6>)) &&
+                           reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t, 8>)) && reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float, 8>));
     GA_REQUIRE(ok, "ga_class_attn_mt_bwd: cannot reserve LDS");
-    MAP_DISPATCH(dtype, mt_attn_bwd_kernel, dim3(B), dim3(kThr), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok,
-                 (long)tok_ld, P, mask, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, T_, N, heads, hd, scale);
+#define MT_LAUNCH(TT, MTT) hipLaunchKernelGGL((mt_attn_bwd_kernel<TT, MTT>), dim3(B), dim3(kThr), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld, P, mask, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, T_, N, heads, hd, scale)
+    if (dtype == GA_BF16) { using T = bf16_t; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
+    else { using T = float; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
+#undef MT_LAUNCH
     return ga_check_launch("ga_class_attn_mt_bwd");
 }
 

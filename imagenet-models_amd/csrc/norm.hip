@@ -21,6 +21,7 @@ int pick_group(int C, int epc) {
     }
     for (int g = 4; g <= 64; g <<= 1)
         if (kMaxChunks * g >= nch) return g;
+    if (nch <= 8 * 64) return 64;      // very wide rows (fp32 NormHead of map_pit_s: 4 x 384 channels): 8 chunks per lane
     return 0;
 }
 
@@ -425,6 +426,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #define LN_DISPATCH_(G, AFF, nch3, KERNEL, ...)                                                                  \
     do {                                                                                                         \
         if ((nch3) == 1 && (G) == 16) { hipLaunchKernelGGL((KERNEL<T, 16, AFF, 1>), __VA_ARGS__); }             \
+        else if ((nch3) == 8) { hipLaunchKernelGGL((KERNEL<T, 64, AFF, 8>), __VA_ARGS__); }                      \
         else if (nch3) { LN_DISPATCH__(G, AFF, 3, KERNEL, __VA_ARGS__) }                                          \
         else { LN_DISPATCH__(G, AFF, 4, KERNEL, __VA_ARGS__) }                                                   \
     } while (0)
@@ -442,7 +444,7 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
     dim3 grid(grid_blocks(rows, rpb, 4096)), block(256);
     // 1: one chunk per lane (the 12 chunks of C = 96 on 16 lanes: a third of the registers of the 3-chunk form, which
     // matters for the affine variants -- stem / downsample norms), 2: up to 3 chunks, 0: up to 4
-    const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : 0);
+    const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : (C / elt<T>::EPC <= 4 * G ? 0 : 8));
     LN_DISPATCH(G, w != nullptr, nch3, ln_fwd_kernel, grid, block, 0, s, (const T*)x, w, b, (T*)y, mean, rstd, (long)rows, C, eps);
     return ga_check_launch("ga_layernorm_fwd");
 }
@@ -455,7 +457,7 @@ static int ln_bwd_t(const void* g, const void* x, const float* mean, const float
     // persistent when parameter gradients are reduced (bounds the number of atomics)
     dim3 grid(grid_blocks(rows, rpb, dw ? 1024 : 4096)), block(256);
     const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
-    const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : 0);
+    const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : (C / elt<T>::EPC <= 4 * G ? 0 : 8));
     LN_DISPATCH(G, (w != nullptr || dw != nullptr), nch3, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
                 dw, db, (long)rows, C, xnorm);
     return ga_check_launch("ga_layernorm_bwd");

@@ -85,7 +85,7 @@ class MAPEngine(GAEngine):
         Tq = Tn + 1                      # gram tokens + the self-distillation (mean) token
         HW = Hc * Hc
         hd = E // nh
-        assert E % nh == 0 and hd % 8 == 0 and E <= 512 and L % 8 == 0 and bp % 8 == 0 and NC % 8 == 0 and Tq <= 4
+        assert E % nh == 0 and hd % 8 == 0 and E <= 512 and L % 8 == 0 and bp % 8 == 0 and NC % 8 == 0 and Tq <= 8
         self.G, self.Tq = G, Tq
         H = self.mh = dict(x=x)
         nlog = 2 * G if T else G

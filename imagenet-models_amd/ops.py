@@ -357,6 +357,32 @@ class Plan:
         B, CH, H, W = x.shape
         self._add('ga_patchify', (_ptr(x), _ptr(out), B, CH, H, W, P, dtype), label, keep=(x, out))
 
+    def patchify_strided(self, x, out, P, S, dtype, label=None):
+        B, CH, H, W = x.shape
+        self._add('ga_patchify_strided', (_ptr(x), _ptr(out), B, CH, H, W, P, S, dtype), label, keep=(x, out))
+
+    # -- pooling transformer (PiT) pieces ----------------------------------------------------------
+    def pos_add_fwd(self, tok, pos, x0, B, Np, Cdim, dtype, label=None):
+        self._add('ga_pos_add_fwd', (_ptr(tok), _ptr(pos), _ptr(x0), B, Np, Cdim, dtype), label, keep=(tok, pos, x0))
+
+    def pos_add_bwd(self, dx0, dpos, B, Np, Cdim, dtype, label=None):
+        self._add('ga_pos_add_bwd', (_ptr(dx0), _ptr(dpos), B, Np, Cdim, dtype), label, keep=(dx0, dpos))
+
+    def dwpool_fwd(self, x, w, bias, y, B, H, W_, Cin, mult, dtype, label=None):
+        self._add('ga_dwpool_fwd', (_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, H, W_, Cin, mult, dtype), label, keep=(x, w, bias, y))
+
+    def dwpool_bwd_data(self, dy, w, dx, B, H, W_, Cin, mult, dtype, label=None):
+        self._add('ga_dwpool_bwd_data', (_ptr(dy), _ptr(w), _ptr(dx), B, H, W_, Cin, mult, dtype), label, keep=(dy, w, dx))
+
+    def dwpool_bwd_weight(self, dy, x, dw, db, B, H, W_, Cin, mult, dtype, label=None):
+        self._add('ga_dwpool_bwd_weight', (_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), B, H, W_, Cin, mult, dtype), label, keep=(dy, x, dw, db))
+
+    def resize_concat_fwd(self, src, dst, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype, label=None):
+        self._add('ga_resize_concat_fwd', (_ptr(src), _ptr(dst), B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype), label, keep=(src, dst))
+
+    def resize_concat_bwd(self, dcat, dsrc, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype, label=None):
+        self._add('ga_resize_concat_bwd', (_ptr(dcat), _ptr(dsrc), B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype), label, keep=(dcat, dsrc))
+
     def vit_embed_fwd(self, tok, cls, pos, x0, B, Np, Cdim, dtype, label=None):
         self._add('ga_vit_embed_fwd', (_ptr(tok), _ptr(cls), _ptr(pos), _ptr(x0), B, Np, Cdim, dtype), label, keep=(tok, cls, pos, x0))
 

@@ -521,7 +521,7 @@ int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t cols, int64_t 
 /* Global multi-head self-attention (timm vision_transformer.Attention inside `Block`, MAP/models/map_pit.py:14,35-44):
  *   qkv [B*N][ldq]: q | k | v column blocks of width C = H*hd (head h = columns h*hd.. of each block); out [B*N][ldo];
  *   out = softmax(q k^T * scale) v per (image, head);  lse [B][H][N] fp32 = row log-sum-exp, kept for the backward pass.
- * bf16 with hd = 64 runs flash-style on MFMA (64-query workgroups, 64-key blocks streamed through LDS, online softmax);
+ * bf16 with hd in {16, 32, 48, 64} runs flash-style on MFMA (64-query workgroups, 64-key blocks streamed through LDS, online softmax);
  * everything else (fp32 parity mode, other hd <= 128) on a plain fp32 form meant for small batches.
  * bwd: dqkv [B*N][ldq] = d(q | k | v) from dout [B*N][ldo]; needs `out` and `lse` of the forward pass and a caller-owned
  * workspace of ga_attn_bwd_workspace(d) bytes (delta[b][h][q] = dout . out). */
@@ -543,6 +543,30 @@ int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, void* works
 int ga_patchify(const float* x, void* out, int B, int CH, int H, int W, int P, int dtype, ga_stream_t stream);
 int ga_vit_embed_fwd(const void* tok, const float* cls, const float* pos, void* x0, int B, int Np, int C, int dtype, ga_stream_t stream);
 int ga_vit_embed_bwd(const void* dx0, void* dtok, float* dcls, float* dpos, int B, int Np, int C, int dtype, ga_stream_t stream);
+
+/* Pooling transformer (PiT) pieces around the ViT blocks -- /root/reference/MAP/models/map_pit.py
+ *   ga_patchify_strided: conv_embedding (:71-81) as im2col for a patch convolution whose stride S differs from the patch size P
+ *                        (16 / 8 in map_pit_s: overlapping patches): [B*gh*gw][CH*P*P], gh = (H - P) / S + 1; P % 8 == 0, S % 4 == 0
+ *   ga_pos_add_fwd/bwd:  x0[b][p] = tok[b][p] + pos[p]  (:190-191; pos fp32 [Np][C], the NCHW parameter transposed);
+ *                        dpos[p] = sum_b dx0[b][p]  (overwrites)
+ *   ga_dwpool_*:         conv_head_pooling (:58-68): depthwise 3 x 3 / stride 2 / pad 1 convolution with a channel multiplier
+ *                        (groups = Cin, Cout = mult * Cin) on NHWC maps [B][H][W][Cin] -> [B][Ho][Wo][Cout], Ho = (H - 1) / 2 + 1;
+ *                        w fp32 [Cout][9] (the (Cout, 1, 3, 3) parameter), bias fp32 [Cout].  bwd_weight ACCUMULATES into dw / db.
+ *   ga_resize_concat_*:  bilinear resize (align_corners = False, no antialias; any Hin x Win -> Hout x Wout) of an NHWC map into
+ *                        columns [c_off, c_off + C) of the MultiScale concat buffer (row stride ldd); map.py:322-333 reduces
+ *                        PiT's 27 x 27 maps to 14 x 14 this way.  bwd writes dsrc (gather form, no atomics). */
+int ga_patchify_strided(const float* x, void* out, int B, int CH, int H, int W, int P, int S, int dtype, ga_stream_t stream);
+int ga_pos_add_fwd(const void* tok, const float* pos, void* x0, int B, int Np, int C, int dtype, ga_stream_t stream);
+int ga_pos_add_bwd(const void* dx0, float* dpos, int B, int Np, int C, int dtype, ga_stream_t stream);
+int ga_dwpool_fwd(const void* x, const float* w, const float* bias, void* y, int B, int H, int W, int Cin, int mult, int dtype,
+                  ga_stream_t stream);
+int ga_dwpool_bwd_data(const void* dy, const float* w, void* dx, int B, int H, int W, int Cin, int mult, int dtype, ga_stream_t stream);
+int ga_dwpool_bwd_weight(const void* dy, const void* x, float* dw, float* db, int B, int H, int W, int Cin, int mult, int dtype,
+                         ga_stream_t stream);
+int ga_resize_concat_fwd(const void* src, void* dst, int B, int Hin, int Win, int C, int Hout, int Wout, int64_t ldd, int c_off,
+                         int dtype, ga_stream_t stream);
+int ga_resize_concat_bwd(const void* dcat, void* dsrc, int B, int Hin, int Win, int C, int Hout, int Wout, int64_t ldd, int c_off,
+                         int dtype, ga_stream_t stream);
 
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */

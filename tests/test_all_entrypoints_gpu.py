@@ -14,7 +14,7 @@ def _names():
 
 @pytest.mark.parametrize('name', ['ga_convnext_small_768', 'ga_convnext_small_688', 'ga_convnext_base_1024', 'ga_convnext_base_976',
                                   'ga_CSWin_64_24322_small_224', 'map_convnext_small', 'ga_convnext_tiny', 'ga_convnext_small',
-                                  'ga_convnext_base', 'map_vit_small_patch16_224', 'map_vit_base_patch16_224'])
+                                  'ga_convnext_base', 'map_vit_small_patch16_224', 'map_vit_base_patch16_224', 'map_pit_s'])
 def test_entry_point_trains_and_evaluates(name):
     import imagenet_models_amd as A
     assert name in _names()
@@ -38,8 +38,9 @@ def test_entry_point_trains_and_evaluates(name):
 
 def test_every_listed_model_is_covered_somewhere():
     """list_models() holds exactly the factories of the three families (ga_convnext.py:572-613 + README aliases, the two CSWin
-    candidates, map_convnext.py:173-240, the builder-defined MAP-ViT compositions)"""
+    candidates, map_convnext.py:173-240, map_pit.py:224-251, the builder-defined MAP-ViT compositions)"""
     assert set(_names()) == {'ga_convnext_tiny_688', 'ga_convnext_tiny_768', 'ga_convnext_small_688', 'ga_convnext_small_768',
                              'ga_convnext_base_976', 'ga_convnext_base_1024', 'ga_convnext_tiny', 'ga_convnext_small',
                              'ga_convnext_base', 'ga_CSWin_64_12211_tiny_224', 'ga_CSWin_64_24322_small_224', 'map_convnext_tiny',
-                             'map_convnext_small', 'map_vit_base_patch16_384', 'map_vit_base_patch16_224', 'map_vit_small_patch16_224'}
+                             'map_convnext_small', 'map_vit_base_patch16_384', 'map_vit_base_patch16_224', 'map_vit_small_patch16_224',
+                             'map_pit_s'}

@@ -50,7 +50,8 @@ def _case(dt, B, N, H, hd, tol, force_simple=False):
     assert e_o < tol and e_l < max(tol, 1e-3) and max(e) < 2 * tol, (e_o, e_l, e)
 
 
-@pytest.mark.parametrize('B,N,H,hd', [(2, 577, 3, 64), (1, 64, 2, 64), (2, 197, 2, 64), (1, 130, 1, 64)])
+@pytest.mark.parametrize('B,N,H,hd', [(2, 577, 3, 64), (1, 64, 2, 64), (2, 197, 2, 64), (1, 130, 1, 64),
+                                      (2, 729, 3, 48), (2, 196, 6, 48), (3, 49, 12, 48), (1, 70, 2, 32), (2, 100, 5, 16)])   # PiT: head_dim 48
 def test_attention_bf16_mfma(B, N, H, hd):
     _case(torch.bfloat16, B, N, H, hd, 2e-2)
 
