@@ -39,11 +39,13 @@ GFLOP_PER_IMG = {'ga_convnext_tiny_768': 34.52, 'ga_convnext_tiny': 34.52, 'ga_c
                  'ga_CSWin_64_12211_tiny_224': 36.5, 'map_convnext_tiny': 30.37, 'map_convnext_small': 55.85,
                  # MAP-ViT (builder-defined, configs[4]): 3 x forward, forward = 2 FLOP/MAC over patch embedding, qkv / proj / MLP linears and
                  # the two attention products of every block (N = (img/16)^2 + 1 tokens) + the MAP head on (img/32)^2 tokens
-                 'map_vit_base_patch16_384': 336.1, 'map_vit_base_patch16_224': 106.6, 'map_vit_small_patch16_224': 28.6}
+                 'map_vit_base_patch16_384': 336.1, 'map_vit_base_patch16_224': 106.6, 'map_vit_small_patch16_224': 28.6,
+                 # map_pit_s (map_pit.py:224-251): trunk 2.85 GMAC (conv_embedding 0.08, stages 0.67 / 1.30 / 0.79) + MAP head 0.28 GMAC
+                 'map_pit_s': 18.8}
 LABEL = {'ga_convnext_tiny_768': 'GA-ConvNeXt-T', 'ga_convnext_small_768': 'GA-ConvNeXt-S', 'ga_convnext_base_1024': 'GA-ConvNeXt-B',
          'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)', 'map_convnext_tiny': 'MAP-ConvNeXt-T',
          'map_convnext_small': 'MAP-ConvNeXt-S', 'map_vit_base_patch16_384': 'MAP-ViT-B/16 @ 384 (builder-defined composition)',
-         'map_vit_base_patch16_224': 'MAP-ViT-B/16 @ 224', 'map_vit_small_patch16_224': 'MAP-ViT-S/16 @ 224'}
+         'map_vit_base_patch16_224': 'MAP-ViT-B/16 @ 224', 'map_vit_small_patch16_224': 'MAP-ViT-S/16 @ 224', 'map_pit_s': 'MAP-PiT-S'}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -163,6 +165,11 @@ def cpu_baseline(model_name, budget_s=10.0):
         from oracle.ga_convnext_oracle import adamw_step
         mod = 'oracle/map_vit_oracle.py'
         step_kw = dict(dec_lam=-0.8)
+    elif model_name.startswith('map_pit'):
+        from oracle import map_pit_oracle as O
+        from oracle.ga_convnext_oracle import adamw_step
+        mod = 'oracle/map_pit_oracle.py'
+        step_kw = dict(dec_lam=-0.8)
     elif model_name.startswith('map_'):
         from oracle import map_oracle as O
         from oracle.ga_convnext_oracle import adamw_step
@@ -179,7 +186,7 @@ def cpu_baseline(model_name, budget_s=10.0):
     sd = O.fill_state(cfg)
     B = 8
     g = torch.Generator().manual_seed(42)
-    img = cfg.get('img_size', 224)
+    img = cfg.get('img_size', cfg.get('image_size', 224))
     x = torch.randn(B, 3, img, img, generator=g)
     y = torch.randint(0, 1000, (B,), generator=g)
     m, v = {}, {}

@@ -5,6 +5,7 @@
 //     buffer (map.py:322-333: 27 x 27 -> 14 x 14 is not an integer factor) and its backward.
 // The maps are small (<= 27 x 27 x 576 per image): plain HBM-bound kernels, 8 channels per thread.
 #include <algorithm>
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -112,6 +113,154 @@ __global__ __launch_bounds__(256) void dwpool_bwd_weight_kernel(const T* __restr
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(dw + (co + j) * 9 + k, acc[k][j]);
         atomicAdd(db + co + j, acc[9][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// channel multiplier 1 / 2 (PiT: 2): weights staged once per workgroup in LDS as [tap][Cout] (+ bias row), 16-byte / 8-byte
+// vector loads of the input channels an 8-channel output chunk needs
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stage_w(float* wl, const float* __restrict__ w, const float* __restrict__ bias, int Co) {
+    for (int i = threadIdx.x; i < Co * 9; i += 256) wl[(i % 9) * Co + i / 9] = w[i];
+    if (bias)
+        for (int i = threadIdx.x; i < Co; i += 256) wl[9 * Co + i] = bias[i];
+    __syncthreads();
+}
+
+// the 8 output channels co .. co+7 read input channels co/MULT .. : xv[j] = x[(co + j) / MULT]
+template <typename T, int MULT>
+__device__ __forceinline__ void load_in8(const T* xp, int co, float xv[8]) {
+    if constexpr (MULT == 1) {
+        load8(xp + co, xv);
+    } else {
+        float h[4];
+        load4(xp + co / 2, h);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv[j] = h[j >> 1];
+    }
+}
+
+template <typename T, int MULT>
+__global__ __launch_bounds__(256) void dwpool_fwd_v(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                    T* __restrict__ y, int B, int H, int W, int Cin, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int Co = Cin * MULT, C8 = Co / 8;
+    stage_w(wl, w, bias, Co);
+    const long n = (long)B * Ho * Wo * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int co = (int)(i % C8) * 8;
+        const long pix = i / C8;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+        float acc[8];
+        load8(wl + 9 * Co + co, acc);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    float xv[8], wv[8];
+                    load_in8<T, MULT>(x + (((long)b * H + iy) * W + ix) * Cin, co, xv);
+                    load8(wl + (ky * 3 + kx) * Co + co, wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(wv[j], xv[j], acc[j]);
+                }
+            }
+        }
+        store8(y + pix * Co + co, acc);
+    }
+}
+
+template <typename T, int MULT>
+__global__ __launch_bounds__(256) void dwpool_bwd_data_v(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int B, int H,
+                                                         int W, int Cin, int Ho, int Wo) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];
+    const int Co = Cin * MULT, C8 = Cin / 8;
+    stage_w(wl, w, nullptr, Co);
+    const long n = (long)B * H * W * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int ci = (int)(i % C8) * 8;
+        const long pix = i / C8;
+        const int ix = (int)(pix % W), iy = (int)((pix / W) % H), b = (int)(pix / ((long)W * H));
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int t = iy + 1 - ky, oy = t >> 1;
+            if (t < 0 || (t & 1) || oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int u = ix + 1 - kx, ox = u >> 1;
+                if (u < 0 || (u & 1) || ox >= Wo) continue;
+                const T* gp = dy + (((long)b * Ho + oy) * Wo + ox) * Co + ci * MULT;
+                const float* wp = wl + (ky * 3 + kx) * Co + ci * MULT;
+#pragma unroll
+                for (int m = 0; m < MULT; ++m) {
+                    float g[8], wv[8];
+                    load8(gp + 8 * m, g);
+                    load8(wp + 8 * m, wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[(8 * m + j) / MULT] = fmaf(wv[j], g[j], acc[(8 * m + j) / MULT]);
+                }
+            }
+        }
+        store8(dx + pix * Cin + ci, acc);
+    }
+}
+
+// a WAVE per (8-channel output chunk, pixel group): lanes = 64 output pixels, per-lane partial sums, one shuffle reduction and 80
+// atomics per wave
+template <typename T, int MULT>
+__global__ __launch_bounds__(256) void dwpool_bwd_weight_v(const T* __restrict__ dy, const T* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ db, int B, int H, int W, int Cin, int Ho, int Wo, int npg) {
+    const int Co = Cin * MULT, C8 = Co / 8;
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int chunk = gw % C8, pg = gw / C8;
+    if (pg >= npg) return;
+    const int co = chunk * 8;
+    float acc[10][8];
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    const long npix = (long)B * Ho * Wo;
+    for (long pix = (long)pg * 64 + lane; pix < npix; pix += (long)npg * 64) {
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((long)Wo * Ho));
+        float g[8];
+        load8(dy + pix * Co + co, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[9][j] += g[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    float xv[8];
+                    load_in8<T, MULT>(x + (((long)b * H + iy) * W + ix) * Cin, co, xv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] = fmaf(g[j], xv[j], acc[ky * 3 + kx][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[k][j];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            acc[k][j] = v;
+        }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) atomicAdd(dw + (co + j) * 9 + k, acc[k][j]);
+            atomicAdd(db + co + j, acc[9][j]);
+        }
     }
 }
 
@@ -223,9 +372,19 @@ __global__ __launch_bounds__(256) void pos_add_bwd_kernel(const T* __restrict__ 
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+bool fast_path() {       // GAEXT_DWPOOL_SIMPLE=1: the plain any-multiplier kernels (diagnostics / tests)
+    const char* e = getenv("GAEXT_DWPOOL_SIMPLE");
+    return !(e && atoi(e));
+}
 int grid_for(long n) { return (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256)); }
 
 }  // namespace
+
+#define PIT_DISPATCH_V(dtype, KERNEL, MULT, grid, lds, s, ...)                                                   \
+    do {                                                                                                         \
+        if ((dtype) == GA_BF16) { using T = bf16_t; hipLaunchKernelGGL((KERNEL<T, MULT>), dim3(grid), dim3(256), lds, s, __VA_ARGS__); } \
+        else { using T = float; hipLaunchKernelGGL((KERNEL<T, MULT>), dim3(grid), dim3(256), lds, s, __VA_ARGS__); }                     \
+    } while (0)
 
 #define PIT_DISPATCH(dtype, KERNEL, grid, s, ...)                                                              \
     do {                                                                                                       \
@@ -239,7 +398,15 @@ extern "C" int ga_dwpool_fwd(const void* x, const float* w, const float* bias, v
                "ga_dwpool_fwd: bad args (Cout must be a multiple of 8)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    PIT_DISPATCH(dtype, dwpool_fwd_kernel, grid_for((long)B * Ho * Wo * Cin * mult / 8), s, (const T*)x, w, bias, (T*)y, B, H, W, Cin, mult, Ho, Wo);
+    const long n8 = (long)B * Ho * Wo * Cin * mult / 8;
+    const size_t lds = (size_t)Cin * mult * 10 * sizeof(float);
+    if ((mult == 1 || mult == 2) && Cin % 8 == 0 && lds <= 64 * 1024 && aligned16(x) && fast_path()) {
+        const int grid = (int)std::max<long>(1, std::min<long>(2048, (n8 + 255) / 256));
+        if (mult == 1) PIT_DISPATCH_V(dtype, dwpool_fwd_v, 1, grid, lds, s, (const T*)x, w, bias, (T*)y, B, H, W, Cin, Ho, Wo);
+        else PIT_DISPATCH_V(dtype, dwpool_fwd_v, 2, grid, lds, s, (const T*)x, w, bias, (T*)y, B, H, W, Cin, Ho, Wo);
+        return ga_check_launch("ga_dwpool_fwd");
+    }
+    PIT_DISPATCH(dtype, dwpool_fwd_kernel, grid_for(n8), s, (const T*)x, w, bias, (T*)y, B, H, W, Cin, mult, Ho, Wo);
     return ga_check_launch("ga_dwpool_fwd");
 }
 
@@ -247,7 +414,15 @@ extern "C" int ga_dwpool_bwd_data(const void* dy, const float* w, void* dx, int 
     GA_REQUIRE(dy && w && dx && B > 0 && Cin % 8 == 0 && mult >= 1 && aligned16(dx), "ga_dwpool_bwd_data: bad args (Cin %% 8)");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    PIT_DISPATCH(dtype, dwpool_bwd_data_kernel, grid_for((long)B * H * W * Cin / 8), s, (const T*)dy, w, (T*)dx, B, H, W, Cin, mult, Ho, Wo);
+    const long n8 = (long)B * H * W * Cin / 8;
+    const size_t lds = (size_t)Cin * mult * 9 * sizeof(float);
+    if ((mult == 1 || mult == 2) && lds <= 64 * 1024 && aligned16(dy) && fast_path()) {
+        const int grid = (int)std::max<long>(1, std::min<long>(2048, (n8 + 255) / 256));
+        if (mult == 1) PIT_DISPATCH_V(dtype, dwpool_bwd_data_v, 1, grid, lds, s, (const T*)dy, w, (T*)dx, B, H, W, Cin, Ho, Wo);
+        else PIT_DISPATCH_V(dtype, dwpool_bwd_data_v, 2, grid, lds, s, (const T*)dy, w, (T*)dx, B, H, W, Cin, Ho, Wo);
+        return ga_check_launch("ga_dwpool_bwd_data");
+    }
+    PIT_DISPATCH(dtype, dwpool_bwd_data_kernel, grid_for(n8), s, (const T*)dy, w, (T*)dx, B, H, W, Cin, mult, Ho, Wo);
     return ga_check_launch("ga_dwpool_bwd_data");
 }
 
@@ -258,6 +433,14 @@ extern "C" int ga_dwpool_bwd_weight(const void* dy, const void* x, float* dw, fl
     // about 128 pixel groups per channel chunk, whole workgroups
     const int blocks = std::max(1, (C8 * 128 + 255) / 256);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if ((mult == 1 || mult == 2) && Cin % 8 == 0 && aligned16(x) && fast_path()) {
+        const long npix = (long)B * Ho * Wo;
+        const int npg = (int)std::max<long>(1, std::min<long>((npix + 63) / 64, std::max(1, 4096 / C8)));
+        const int grid = (C8 * npg + 3) / 4;
+        if (mult == 1) PIT_DISPATCH_V(dtype, dwpool_bwd_weight_v, 1, grid, 0, s, (const T*)dy, (const T*)x, dw, db, B, H, W, Cin, Ho, Wo, npg);
+        else PIT_DISPATCH_V(dtype, dwpool_bwd_weight_v, 2, grid, 0, s, (const T*)dy, (const T*)x, dw, db, B, H, W, Cin, Ho, Wo, npg);
+        return ga_check_launch("ga_dwpool_bwd_weight");
+    }
     PIT_DISPATCH(dtype, dwpool_bwd_weight_kernel, blocks, s, (const T*)dy, (const T*)x, dw, db, B, H, W, Cin, mult, Ho, Wo);
     return ga_check_launch("ga_dwpool_bwd_weight");
 }
