@@ -70,7 +70,7 @@ def parse():
 def kernel_family(label):
     for key, fam in (('.wg', 'gemm_tn(wgrad)'), ('wgrad', 'gemm_tn(wgrad)'), ('gram.', 'gemm/gram'),
                      ('.dww', 'dwconv7_wgrad'), ('.dwd', 'dwconv7'), ('.dw', 'dwconv7'),
-                     ('attnb', 'stripe_attn_bwd'), ('.attn', 'stripe_attn_fwd' if 'stage' in label or 'gram_layer' in label else 'class_attn'),
+                     ('attnb', 'stripe_attn_bwd' if 'stage' in label or 'gram_layer' in label else 'class_attn_bwd'), ('.attn', 'stripe_attn_fwd' if 'stage' in label or 'gram_layer' in label else 'class_attn'),
                      ('.lnb', 'layernorm_bwd'), ('ln0b', 'layernorm_bwd'), ('ln1b', 'layernorm_bwd'), ('ln2b', 'layernorm_bwd'),
                      ('.ln', 'layernorm_fwd'), ('prep.', 'weight_prep'), ('unf', 'weight_unfold'), ('bn', 'batchnorm'),
                      ('agg.', 'aggregate'), ('se.', 'squeeze_excite'), ('attn', 'class_attn'), ('zero', 'memset'), ('.dp', 'rowscale'),
