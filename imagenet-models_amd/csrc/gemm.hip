@@ -183,6 +183,19 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
+// two pieces with one M0 set-up: the instruction offset is added to the global address AND to the LDS address, so the second
+// piece (LDS dst + 1024) takes its global address minus 1024
+__device__ __forceinline__ void glds16x2(const void* g0, const void* g1, unsigned lds_dst) {
+    unsigned keep;
+    const char* g1m = static_cast<const char*>(g1) - 1024;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+        "global_load_lds_dwordx4 %2, off offset:1024\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g0), "v"(g1m), "s"(lds_dst)
+        : "memory");
+}
+
 // lanes whose source row / k chunk is out of range fetch zeros from here
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -723,6 +736,307 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
 }
 
 // ================================================================================================
+// NT kernel, 8-wave ping-pong form (bf16, plain operands, one of the compile-time epilogues).
+// 256 x 256 output tile, 512 threads = 2 (m) x 4 (n) waves of 128 x 64 (acc: 8 x 4 MFMA tiles = 128 registers), K tiles of
+// 64 in a ring of two 64 KiB buffers, each four 16 KiB half-tiles {A rows 0-127, A rows 128-255, B rows 0-127, B rows
+// 128-255} in the [row][128 B] XOR layout of the other NT forms, filled by LDS-DMA (every wave brings 16 rows of each).
+// A K tile is multiplied in four PHASES of 16 MFMAs (one 64 x 32 quadrant of the wave's tile over K = 64); each phase is
+//     L: ds_read the fragments the phase needs | issue LDS-DMA | s_waitcnt | barrier      M: 16 MFMA | barrier
+// and the two wave groups (m halves; one wave of each group per SIMD) run ONE barrier apart, so that in every barrier
+// interval one group multiplies while the other reads / issues DMA.  Fragment reads: A(rows 0-63) 8 in L of phase 1,
+// A(rows 64-127) 8 in L of phase 3; the 4 B reads of phase 2 and the 4 of the NEXT K tile's phase 1 are issued at the head of
+// the M steps of phases 1 / 3, under MFMAs that do not use those registers.  All reads of a phase are retired BEFORE its first barrier, so a half-tile
+// may be refilled from the phase after its last read.  Issue schedule (an LDS-DMA piece costs 60-180 clocks of issue, so they
+// are spread, one half-tile = 2 pieces per wave and phase): phases 3, 4 of tile g: the B halves of tile g+2; phases 1, 2 of
+// tile g+1: the A halves of g+2 -- 2 to 5 phases ahead of their first use; counted waits (vmcnt(6) / vmcnt(4)) in phases 3 / 4
+// retire the B / A halves of tile g+1 one phase before they are read.  The K-tile stream runs across the workgroup's output tiles
+// (persistent), so the first two K tiles of the next output tile land while this tile's epilogue runs.
+// Epilogue: per wave, 16 rows at a time through a private 4 KiB fp32 staging piece -> 8 columns per lane, 16-byte stores.
+// ================================================================================================
+constexpr int kPPThreads = 512, kPPHalf = 16384, kPPBuf = 4 * kPPHalf, kPPSmem = 2 * kPPBuf + 8 * 4096;
+
+template <int EPI>
+__global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_desc d, const int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = (d.N + 255) / 256, tiles_m = (d.M + 255) / 256;
+    const int nwg = tiles_n * tiles_m;
+    const int z = blockIdx.z;
+    const int za = d.a_batch_mod > 0 ? z % d.a_batch_mod : z;
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(d.A) + (long)za * d.strideA;
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(d.B) + (long)z * d.strideB;
+    const int nk = (d.K + 63) / 64;
+    const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * nk;                               // K tiles in this workgroup's stream
+
+    // ---- fragment addresses (bytes from the buffer start): lane reads row (lane & 15) of a 16-row fragment, 16-byte chunk
+    // ks*4 + (lane >> 4); the chunk sits at chunk ^ (row & 7), and ks = 1 is the same address with bit 6 flipped
+    const int fa = (lane & 15) * 128 + ((((lane >> 4) ^ (lane & 7))) << 4);
+    const unsigned char* aF[2] = {smem + wr * kPPHalf + fa, smem + wr * kPPHalf + (fa ^ 64)};
+    const unsigned char* bF[2] = {smem + (2 + (wc >> 1)) * kPPHalf + (wc & 1) * 8192 + fa,
+                                  smem + (2 + (wc >> 1)) * kPPHalf + (wc & 1) * 8192 + (fa ^ 64)};
+
+    // ---- LDS-DMA roles: of every half-tile this wave brings pieces 2w and 2w+1 (a piece = 8 rows x 128 B = one glds16).
+    // Rows beyond M / N are clamped to the last row (their products are never stored); the K tail fetches the zero page.
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int dchunk = ((lane & 7) ^ (lane >> 3)) * 8;
+    // two issue-side cursors: the A rows 128-255 half of a K tile is issued one phase-group later than its other three halves
+    struct Cursor { int vt, kt; };
+    Cursor cm = {(int)blockIdx.x, 0}, cl = {(int)blockIdx.x, 0};
+    int off_a0[2], off_b[2][2], off_a1[2];                     // element offsets of this lane's rows in the cursor's output tile
+    auto rows_of = [&](int t, int h, bool is_a, int (&o)[2]) {
+        const int bid = xcd_remap(t, nwg);
+        const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = h * 128 + 16 * wave + 8 * i + (lane >> 3);
+            o[i] = is_a ? min(tm * 256 + r, d.M - 1) * (int)d.lda : min(tn * 256 + r, d.N - 1) * (int)d.ldb;
+        }
+    };
+    auto set_main = [&]() {
+        rows_of(cm.vt, 0, false, off_b[0]);
+        rows_of(cm.vt, 1, false, off_b[1]);
+    };
+    auto set_lag = [&]() {
+        rows_of(cl.vt, 0, true, off_a0);
+        rows_of(cl.vt, 1, true, off_a1);
+    };
+    auto glds_half = [&](const bf16_t* base, const int (&o)[2], int kt_, int half, int buf) {
+        if (dbg & 2) return;                                    // timing experiment: no operand traffic
+        const int k = kt_ * 64 + dchunk;
+        const bool kv = k < d.K && !(dbg & 8);                  // (dbg 8: every piece comes from the zero page -- no operand traffic, same issue)
+        glds16x2(kv ? static_cast<const void*>(base + o[0] + k) : static_cast<const void*>(g_zero_page),
+                 kv ? static_cast<const void*>(base + o[1] + k) : static_cast<const void*>(g_zero_page),
+                 lds0 + buf * kPPBuf + half * kPPHalf + 2 * wave * 1024);
+    };
+    auto issue_B0 = [&](int buf) { glds_half(Bb, off_b[0], cm.kt, 2, buf); };
+    auto issue_B1 = [&](int buf) {
+        glds_half(Bb, off_b[1], cm.kt, 3, buf);
+        if (++cm.kt == nk) {
+            cm.kt = 0;
+            cm.vt += gridDim.x;
+            if (cm.vt < nwg) set_main();
+        }
+    };
+    auto issue_A0 = [&](int buf) { glds_half(Ab, off_a0, cl.kt, 0, buf); };
+    auto issue_A1 = [&](int buf) {
+        glds_half(Ab, off_a1, cl.kt, 1, buf);
+        if (++cl.kt == nk) {
+            cl.kt = 0;
+            cl.vt += gridDim.x;
+            if (cl.vt < nwg) set_lag();
+        }
+    };
+
+    f32x4_t acc[4][8];                                         // [tn][tm]: C[m = tm*16 + (lane&15)][n = tn*16 + (lane>>4)*4 + r]
+    bf16x8_t af[4][2], bc0[2][2], b1[2][2], bn0[2][2];
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = zero4;
+
+#define PP_READ_A(mh, bufp)                                                                                         \
+    _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)               \
+        af[tm][ks] = *reinterpret_cast<const bf16x8_t*>(aF[ks] + (bufp) + ((mh) * 4 + tm) * 2048);
+#define PP_READ_B(dst, nh, bufp)                                                                                    \
+    _Pragma("unroll") for (int tn = 0; tn < 2; ++tn) _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)               \
+        dst[tn][ks] = *reinterpret_cast<const bf16x8_t*>(bF[ks] + (bufp) + ((nh) * 2 + tn) * 2048);
+#define PP_MMA(bq, mh, nh)                                                                                          \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)               \
+        _Pragma("unroll") for (int tm = 0; tm < 4; ++tm)                                                            \
+            acc[(nh) * 2 + tn][(mh) * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[tn][ks], af[tm][ks],     \
+                                                                                      acc[(nh) * 2 + tn][(mh) * 4 + tm], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+// the same, 4 MFMAs per A fragment pair, which is then re-read (rows of quadrant row `mh2`) while the remaining MFMAs run
+#define PP_MMA_RELOAD(bq, mh, nh, mh2, bufp)                                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                                  \
+    _Pragma("unroll") for (int tm = 0; tm < 4; ++tm) {                                                              \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int tn = 0; tn < 2; ++tn)           \
+            acc[(nh) * 2 + tn][(mh) * 4 + tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[tn][ks], af[tm][ks],     \
+                                                                                      acc[(nh) * 2 + tn][(mh) * 4 + tm], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                            \
+            af[tm][ks] = *reinterpret_cast<const bf16x8_t*>(aF[ks] + (bufp) + ((mh2) * 4 + tm) * 2048);             \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    }                                                                                                               \
+    __builtin_amdgcn_s_setprio(0);
+#define PP_LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PP_BAR                            \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0)
+
+    // ---- prologue: K tiles 0 and 1 of the stream
+    set_main();
+    set_lag();
+    issue_B0(0);
+    issue_B1(0);
+    issue_A0(0);
+    issue_A1(0);
+    if (S > 1) {
+        issue_B0(1);
+        issue_B1(1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    PP_BAR;
+    PP_READ_B(bn0, 0, 0);
+    PP_LGKM0;
+
+    const bf16_t* Hb = d.H ? reinterpret_cast<const bf16_t*>(d.H) + (long)z * d.strideH : nullptr;
+    const bf16_t* Rb = d.R ? reinterpret_cast<const bf16_t*>(d.R) + (long)z * d.strideR : nullptr;
+    float* stage = reinterpret_cast<float*>(smem + 2 * kPPBuf + wave * 4096);
+    int vt = blockIdx.x, kt = 0;
+#pragma unroll 1
+    for (int g = 0; g < S; ++g) {
+        const int bufp = (g & 1) * kPPBuf, nbufp = kPPBuf - bufp;
+        const bool more1 = g + 1 < S, more2 = g + 2 < S;
+        // the second wave group runs one barrier behind the first through the K loop of an output tile; the groups re-align for
+        // the epilogue (run side by side, it is paid once, not once per group)
+        if (kt == 0 && wr == 1) { PP_BAR; }
+        // ---- phase 1: quadrant (rows 0-63, cols 0-31).  L: A rows 0-63 + DMA;  M: the B fragments of phase 2 ride under the MFMAs
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bc0[i][j] = bn0[i][j];
+        PP_READ_A(0, bufp);
+        if (more1) issue_A0((g + 1) & 1);                       // A halves of K tile g+1 (free since phase 4 of tile g-1)
+        PP_LGKM0;
+        PP_BAR;
+        PP_READ_B(b1, 1, bufp);
+        PP_MMA(bc0, 0, 0);
+        PP_BAR;
+        // ---- phase 2: (rows 0-63, cols 32-63).  L: DMA only
+        if (more1) {
+            issue_A1((g + 1) & 1);
+            if (!(dbg & 4)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B halves of K tile g+1 have landed (this wave's share)
+        }
+        PP_LGKM0;
+        PP_BAR;
+        PP_MMA_RELOAD(b1, 0, 1, 1, bufp);                       // ... and A rows 64-127 replace rows 0-63 as their registers die
+        PP_BAR;
+        // ---- phase 3: (rows 64-127, cols 32-63); the B halves of this buffer are free: K tile g+2
+        if (more2) issue_B0(g & 1);
+        PP_LGKM0;
+        PP_BAR;
+        if (more1) { PP_READ_B(bn0, 0, nbufp); }               // first B fragments of K tile g+1, under the MFMAs
+        PP_MMA(b1, 1, 1);
+        PP_BAR;
+        // ---- phase 4: (rows 64-127, cols 0-31).  L: DMA only
+        if (more2) issue_B1(g & 1);
+        if (more1 && !(dbg & 4)) {
+            if (more2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // A halves of K tile g+1
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PP_LGKM0;
+        PP_BAR;
+        PP_MMA(bc0, 1, 0);
+        PP_BAR;
+        if (++kt < nk) continue;
+        kt = 0;
+        if (wr == 0) { PP_BAR; }
+        if (dbg & 1) {                                          // timing experiment: no epilogue
+            vt += gridDim.x;
+            continue;
+        }
+        // ================= epilogue of output tile vt (no workgroup barrier in here: the staging piece is private) =================
+        {
+            const int bid = xcd_remap(vt, nwg);
+            const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+            const int q = lane & 7, rr = lane >> 3;
+            const int n = tile_n * 256 + wc * 64 + q * 8;
+            const bool n_ok = n < d.N;                          // N % 8 == 0: a piece is wholly in or out
+            float bias[8], csum[8], csq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bias[j] = (d.bias && n_ok) ? d.bias[(long)z * d.strideBias + n + j] : 0.f;
+                csum[j] = csq[j] = 0.f;
+            }
+            const bool do_csum = (EPI == EPI_PLAIN || EPI == EPI_DG2) && d.colsum != nullptr;
+#pragma unroll
+            for (int tm = 0; tm < 8; ++tm) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the previous piece has been read
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const int row = lane & 15, u = tn * 4 + (lane >> 4);
+                    *reinterpret_cast<f32x4_t*>(stage + row * 64 + ((u ^ row) << 2)) = acc[tn][tm];
+                    acc[tn][tm] = zero4;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int row = 8 * p + rr;
+                    const long m = (long)tile_m * 256 + wr * 128 + tm * 16 + row;
+                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(stage + row * 64 + (((2 * q) ^ row) << 2));
+                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(stage + row * 64 + (((2 * q + 1) ^ row) << 2));
+                    if (!n_ok || m >= d.M) continue;
+                    float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
+                                  hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
+                    if constexpr (EPI == EPI_FC1) {
+                        float w[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gelu_both_fast(v[j], v[j], w[j]);
+                        if (d.C2) store8_nt(reinterpret_cast<bf16_t*>(d.C2) + (long)z * d.strideC + m * d.ldc + n, w);
+                    }
+                    if constexpr (EPI == EPI_DG2) {
+                        float h[8];
+                        load8_nt(Hb + m * d.ldh + n, h);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= h[j];
+                    }
+                    if constexpr (EPI == EPI_FC2) {
+                        if (d.rowscale) {
+                            const float sc = d.rowscale[(unsigned)m / (unsigned)d.rows_per_scale];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] *= sc;
+                        }
+                        float r[8];
+                        load8_nt(Rb + m * d.ldr + n, r);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += r[j];
+                    }
+                    if (do_csum) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            csum[j] += v[j];
+                            csq[j] += v[j] * v[j];
+                        }
+                    }
+                    store8_nt(reinterpret_cast<bf16_t*>(d.C) + (long)z * d.strideC + m * d.ldc + n, v);
+                }
+            }
+            if (do_csum) {                                      // lanes q, q+8, .. hold the same 8 columns over different rows
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float a = csum[j], b = csq[j];
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        a += __shfl_xor(a, o, 64);
+                        b += __shfl_xor(b, o, 64);
+                    }
+                    if (rr == 0 && n_ok) {
+                        atomicAdd(d.colsum + (long)z * d.strideCol + n + j, a);
+                        if (d.colsumsq) atomicAdd(d.colsumsq + (long)z * d.strideCol + n + j, b);
+                    }
+                }
+            }
+        }
+        vt += gridDim.x;
+    }
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MMA
+#undef PP_MMA_RELOAD
+#undef PP_LGKM0
+#undef PP_BAR
+}
+
+// ================================================================================================
 // TN (wgrad) kernel: dW[n][k] = sum_m Y[m][n] X[m][k]
 // LDS images are [rows = m][128 columns]; bf16: 64 rows x 256 B, fp32: 32 rows x 512 B (16 KiB each)
 // ================================================================================================
@@ -1147,6 +1461,40 @@ void launch_nt_(const ga_gemm_desc* d, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, smem, s, *d);
 }
 
+template <int EPI>
+void launch_nt_pp(const ga_gemm_desc* d, hipStream_t s) {
+    auto kern = gemm_nt_pp_kernel<EPI>;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kPPSmem) == hipSuccess;
+    if (!ok) {
+        ga_set_error("ga_gemm: cannot reserve %d bytes of LDS", kPPSmem);
+        return;
+    }
+    const int tiles = cdiv(d->M, 256) * cdiv(d->N, 256);
+    const int cap = std::max(8, (num_cus() / d->batch) / 8 * 8);
+    dim3 grid(std::min(tiles, cap), 1, d->batch), block(kPPThreads);
+    const char* e = getenv("GAEXT_PP_DBG");
+    hipLaunchKernelGGL(kern, grid, block, kPPSmem, s, *d, e ? atoi(e) : 0);
+}
+
+// 8-wave ping-pong form: GAEXT_NT_PP = bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); unset: plain / fc1 / fc2, for
+// launches whose K loop is long enough to carry the un-overlapped epilogue (K >= GAEXT_NT_PP_MINK, default 512) and whose
+// last column tile is not mostly empty
+bool want_pp(const ga_gemm_desc* d, int epi) {
+    const char* e = getenv("GAEXT_NT_PP");
+    const int mask = e ? atoi(e) : 7;       // (dgrad2: its stored-GELU' operand is read inside the un-overlapped epilogue: measured slower)
+    static const int mink = [] { const char* m = getenv("GAEXT_NT_PP_MINK"); return m ? atoi(m) : 512; }();
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
+    if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < (e ? 256 : mink) || d->lda % 8 != 0 || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
+    if ((long)d->M * d->lda >= (1L << 31) || (long)d->N * d->ldb >= (1L << 31)) return false;
+    if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) & 15) return false;
+    if (epi == EPI_FC1 && d->C2 && (reinterpret_cast<uintptr_t>(d->C2) & 15)) return false;
+    if (epi == EPI_DG2 && (d->ldh % 8 != 0 || (reinterpret_cast<uintptr_t>(d->H) & 15))) return false;
+    if (epi == EPI_FC2 && (d->ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(d->R) & 15))) return false;
+    const int tn = cdiv(d->N, 256);
+    if (!e && tn * 256 - d->N > tn * 256 / 8) return false;        // > 12.5 % of the column tiles' MFMA work on columns that do not exist
+    return (long)cdiv(d->M, 256) * tn * d->batch >= num_cus() / 2;
+}
+
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
 int classify_epilogue(const ga_gemm_desc* d) {
     if (d->a_kind != GA_A_PLAIN || d->a_act != GA_ACT_NONE || d->alpha != 1.0f || d->c_kind != GA_C_PLAIN || d->c_f32 ||
@@ -1301,6 +1649,13 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
                 case EPI_FC2: launch_nt_<bf16_t, 3, 4, true, true, EPI_FC2, true>(d, s); break;
                 default: launch_nt_<bf16_t, 3, 4, true, true, EPI_DG2, true>(d, s); break;
             }
+        }
+    } else if (want_pp(d, epi)) {
+        switch (epi) {
+            case EPI_PLAIN: launch_nt_pp<EPI_PLAIN>(d, s); break;
+            case EPI_FC1: launch_nt_pp<EPI_FC1>(d, s); break;
+            case EPI_FC2: launch_nt_pp<EPI_FC2>(d, s); break;
+            default: launch_nt_pp<EPI_DG2>(d, s); break;
         }
     } else if (want_t256(d, epi)) {
         switch (epi) {

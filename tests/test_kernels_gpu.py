@@ -197,8 +197,9 @@ def test_gemm_stem(dt):
     assert_close(dW, ww.grad.reshape(N, 48), tol(dt, 2), 'stem wgrad')
 
 
-@pytest.mark.parametrize('form', ['dma256', 'dma128', 't256'])
-@pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384), (66000, 512, 328)])
+@pytest.mark.parametrize('form', ['dma256', 'dma128', 't256', 'pp'])
+@pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384), (66000, 512, 328),
+                                   (33000, 1536, 768), (40100, 264, 520), (12500, 3072, 768), (50200, 384, 1536)])
 def test_gemm_lds_dma_form_bf16(shape, form, monkeypatch):
     """large-M bf16 launches take the 256-row LDS-DMA form (ragged M, ragged K slab, 96- and 128-wide column tiles):
     plain + column sums, fc1 (GELU and GELU' outputs), fc2 (row scale + residual), dgrad2 (x stored GELU' + sums)"""
@@ -208,6 +209,8 @@ def test_gemm_lds_dma_form_bf16(shape, form, monkeypatch):
     elif form == 't256':                             # 256 x 256 tile, 8 waves (N % 256 == 0 and K >= 256 only)
         monkeypatch.setenv('GAEXT_NT_DMA', '0')
         monkeypatch.setenv('GAEXT_NT_T256', '15')
+    elif form == 'pp':                               # 8-wave ping-pong form (K >= 256)
+        monkeypatch.setenv('GAEXT_NT_PP', '15')
     else:                                            # 128 x 128 tile, 4 waves, 2-slot ring, two workgroups per CU
         monkeypatch.setenv('GAEXT_NT_DMA', '0')
         monkeypatch.setenv('GAEXT_NT_DMA2', '15')

@@ -86,5 +86,11 @@ p = ops.Plan(); p.gemm(a, b, c, M, N, K, dt)
 report('square 4096^3', timeit(p), 2.0 * M * N * K, 2 * 3 * M * N)
 p = ops.Plan(); p.wgrad(a, b, torch.zeros(N, K, device='cuda'), M, N, K, dt)
 report('wgrad 4096^3', timeit(p), 2.0 * M * N * K, 2 * 2 * M * N)
+del a, b, c
+for (M, N, K) in [(8192, 8192, 8192), (73856, 2304, 768), (73856, 768, 768), (73856, 3072, 768), (73856, 768, 3072), (50176, 768, 1920)]:
+    a, b, c = rnd(M, K), rnd(N, K), rnd(M, N)
+    p = ops.Plan(); p.gemm(a, b, c, M, N, K, dt)
+    report(f'plain M{M} N{N} K{K}', timeit(p), 2.0 * M * N * K, 2 * (M * N + M * K + N * K))
+    del a, b, c
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], 'w'), indent=1)
