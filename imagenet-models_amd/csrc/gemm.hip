@@ -958,6 +958,22 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
                 csum[j] = csq[j] = 0.f;
             }
             const bool do_csum = (EPI == EPI_PLAIN || EPI == EPI_DG2) && d.colsum != nullptr;
+            // the epilogue operand (dgrad2: stored GELU'; fc2: shortcut) of row piece tm+1 is requested while piece tm is staged
+            constexpr bool kOp = EPI == EPI_DG2 || EPI == EPI_FC2;
+            const bf16_t* Pb = EPI == EPI_DG2 ? Hb : Rb;
+            const long ldp = EPI == EPI_DG2 ? d.ldh : d.ldr;
+            const long mrow0 = (long)tile_m * 256 + wr * 128 + rr;
+            uint4 opn[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            auto fetch_op = [&](int tm) {
+                if constexpr (kOp) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const long m = mrow0 + tm * 16 + 8 * p;
+                        if (n_ok && m < d.M) opn[p] = load16_nt(Pb + m * ldp + n);
+                    }
+                }
+            };
+            fetch_op(0);
 #pragma unroll
             for (int tm = 0; tm < 8; ++tm) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the previous piece has been read
@@ -967,6 +983,8 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
                     *reinterpret_cast<f32x4_t*>(stage + row * 64 + ((u ^ row) << 2)) = acc[tn][tm];
                     acc[tn][tm] = zero4;
                 }
+                const uint4 opc[2] = {opn[0], opn[1]};
+                if (tm + 1 < 8) fetch_op(tm + 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
@@ -985,7 +1003,7 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
                     }
                     if constexpr (EPI == EPI_DG2) {
                         float h[8];
-                        load8_nt(Hb + m * d.ldh + n, h);
+                        unpack8(opc[p], h);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] *= h[j];
                     }
@@ -996,7 +1014,7 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
                             for (int j = 0; j < 8; ++j) v[j] *= sc;
                         }
                         float r[8];
-                        load8_nt(Rb + m * d.ldr + n, r);
+                        unpack8(opc[p], r);
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += r[j];
                     }
