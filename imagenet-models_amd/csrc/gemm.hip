@@ -196,6 +196,29 @@ __device__ __forceinline__ void glds16x2(const void* g0, const void* g1, unsigne
         : "memory");
 }
 
+// the same through a raw buffer resource: a 32-bit byte offset per lane + a scalar offset (the K advance) instead of a 64-bit
+// address per lane -- half the address traffic of the DMA issue.  Offsets >= the resource's num_records read as zeros.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_s;
+__device__ __forceinline__ void blds16x2(u32x4_s rsrc, unsigned voff0, unsigned voff1, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned v1m = voff1 - 1024;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, %5 offen lds\n\t"
+        "buffer_load_dwordx4 %2, %3, %5 offen offset:1024 lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff0), "v"(v1m), "s"(rsrc), "s"(lds_dst), "s"(soff)
+        : "memory");
+}
+__device__ __forceinline__ u32x4_s make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    u32x4_s r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+
 // lanes whose source row / k chunk is out of range fetch zeros from here
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
 
@@ -803,13 +826,21 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
         rows_of(cl.vt, 0, true, off_a0);
         rows_of(cl.vt, 1, true, off_a1);
     };
+    const u32x4_s rsA = make_rsrc(Ab, 0x80000000u), rsB = make_rsrc(Bb, 0x80000000u);
+    const int ktail = d.K & 63;                                 // > 0: the last K tile is ragged; its chunks beyond K read as zeros
     auto glds_half = [&](const bf16_t* base, const int (&o)[2], int kt_, int half, int buf) {
         if (dbg & 2) return;                                    // timing experiment: no operand traffic
-        const int k = kt_ * 64 + dchunk;
-        const bool kv = k < d.K && !(dbg & 8);                  // (dbg 8: every piece comes from the zero page -- no operand traffic, same issue)
-        glds16x2(kv ? static_cast<const void*>(base + o[0] + k) : static_cast<const void*>(g_zero_page),
-                 kv ? static_cast<const void*>(base + o[1] + k) : static_cast<const void*>(g_zero_page),
-                 lds0 + buf * kPPBuf + half * kPPHalf + 2 * wave * 1024);
+        const unsigned dst = lds0 + buf * kPPBuf + half * kPPHalf + 2 * wave * 1024;
+        if (dbg & 16) {                                         // the 64-bit-address form (A/B experiments: 7-11 % slower)
+            const int k = kt_ * 64 + dchunk;
+            const bool kv = k < d.K && !(dbg & 8);              // (dbg 8: every piece comes from the zero page -- no operand traffic, same issue)
+            glds16x2(kv ? static_cast<const void*>(base + o[0] + k) : static_cast<const void*>(g_zero_page),
+                     kv ? static_cast<const void*>(base + o[1] + k) : static_cast<const void*>(g_zero_page), dst);
+            return;
+        }
+        unsigned v0 = (unsigned)(o[0] + dchunk) * 2u, v1 = (unsigned)(o[1] + dchunk) * 2u;
+        if (ktail && kt_ == nk - 1 && dchunk >= ktail) v0 = v1 = 0x80000400u;   // out of the resource's range: zeros
+        blds16x2(base == Ab ? rsA : rsB, v0, v1, (unsigned)kt_ * 128u, dst);
     };
     auto issue_B0 = [&](int buf) { glds_half(Bb, off_b[0], cm.kt, 2, buf); };
     auto issue_B1 = [&](int buf) {
@@ -1503,7 +1534,7 @@ bool want_pp(const ga_gemm_desc* d, int epi) {
     static const int mink = [] { const char* m = getenv("GAEXT_NT_PP_MINK"); return m ? atoi(m) : 512; }();
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
     if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < (e ? 256 : mink) || d->lda % 8 != 0 || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
-    if ((long)d->M * d->lda >= (1L << 31) || (long)d->N * d->ldb >= (1L << 31)) return false;
+    if ((long)d->M * d->lda >= (1L << 30) || (long)d->N * d->ldb >= (1L << 30) || d->lda < 64 || d->ldb < 64) return false;   // 32-bit byte offsets
     if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) & 15) return false;
     if (epi == EPI_FC1 && d->C2 && (reinterpret_cast<uintptr_t>(d->C2) & 15)) return false;
     if (epi == EPI_DG2 && (d->ldh % 8 != 0 || (reinterpret_cast<uintptr_t>(d->H) & 15))) return false;

@@ -14,6 +14,8 @@ echo serial done
 python3 bench.py --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r02/ktable_convnext.json > gpurun_out/r02/bench_convnext.log 2>&1 || exit 1
 python3 bench.py --model ga_CSWin_64_12211_tiny_224 --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r02/ktable_cswin.json > gpurun_out/r02/bench_cswin.log 2>&1 || exit 1
 python3 bench.py --model map_convnext_tiny --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r02/ktable_map.json > gpurun_out/r02/bench_map.log 2>&1 || exit 1
+python3 bench.py --model map_vit_base_patch16_384 --batch 128 --steps 30 --warmup 8 --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r02/ktable_mapvit.json > gpurun_out/r02/bench_mapvit.log 2>&1 || exit 1
+python3 bench.py --model map_pit_s --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r02/ktable_mappit.json > gpurun_out/r02/bench_mappit.log 2>&1 || exit 1
 echo tables done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/r02/pmcF -o f -- python3 bench.py --steps 2 --warmup 1 $B > gpurun_out/r02/pmcF.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/r02/pmcW -o w -- python3 bench.py --steps 2 --warmup 1 $B > gpurun_out/r02/pmcW.log 2>&1 || exit 1
