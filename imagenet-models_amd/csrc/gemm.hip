@@ -209,6 +209,13 @@ __device__ __forceinline__ void blds16x2(u32x4_s rsrc, unsigned voff0, unsigned 
         : "v"(voff0), "v"(v1m), "s"(rsrc), "s"(lds_dst), "s"(soff)
         : "memory");
 }
+__device__ __forceinline__ void blds16(u32x4_s rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff)
+                 : "memory");
+}
 __device__ __forceinline__ u32x4_s make_rsrc(const void* base, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(base);
     u32x4_s r;
@@ -366,40 +373,39 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
 
     // ---- LDS-DMA roles: wave w brings A pieces 4w..4w+3 and B pieces w, w+NW, ... (a piece = 8 rows x 128 B);
     // lane: row lane>>3 of the piece, LDS chunk lane&7, which holds SOURCE chunk (lane&7) ^ (lane>>3)
-    long aoff[DMA ? 4 : 1], boff[DMA ? CF::NBP : 1];           // element offset of the row start, < 0: row out of range
+    // (through buffer resources: a 32-bit byte offset per lane, fixed for the tile, + the slab's K offset as the scalar offset;
+    // rows beyond M / N and chunks beyond K carry an offset outside the resource and read as zeros)
+    unsigned aoff[DMA ? 4 : 1], boff[DMA ? CF::NBP : 1];
+    constexpr unsigned kOob = 0x80000000u;
     const int dchunk = ((lane & 7) ^ (lane >> 3)) * 8;
     const unsigned lds_ring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + RING0;
+    const u32x4_s rsA = make_rsrc(Ab, kOob), rsB = make_rsrc(Bb, kOob);
+    const int ktail = d.K % BK;                                  // > 0: the last slab is ragged
     auto dma_rows = [&](int tm0, int tn0) {
         if constexpr (DMA) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long m = (long)tm0 + (wave * 4 + i) * 8 + (lane >> 3);
-                aoff[i] = m < d.M ? m * d.lda : -1;
+                aoff[i] = m < d.M ? (unsigned)(m * d.lda + dchunk) * 2u : kOob;
             }
 #pragma unroll
             for (int i = 0; i < CF::NBP; ++i) {
                 const long n = (long)tn0 + (i * CF::NW + wave) * 8 + (lane >> 3);
-                boff[i] = n < d.N ? n * d.ldb : -1;
+                boff[i] = n < d.N ? (unsigned)(n * d.ldb + dchunk) * 2u : kOob;
             }
         }
     };
     auto dma_issue = [&](int kt, int slot) {
         if constexpr (DMA) {
-            const int k = kt * BK + dchunk;
-            const bool kv = k < d.K;
-            const T* Ap = reinterpret_cast<const T*>(Ab) + k;
+            const bool kdead = ktail && kt == nk - 1 && dchunk >= ktail;      // this lane's chunk of the ragged last slab
+            const unsigned soff = (unsigned)kt * (unsigned)kRowBytes;
             const unsigned dst = lds_ring + slot * CF::SMEM_AB;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                glds16((kv && aoff[i] >= 0) ? static_cast<const void*>(Ap + aoff[i]) : static_cast<const void*>(g_zero_page),
-                       dst + (wave * 4 + i) * 1024);
+            for (int i = 0; i < 4; ++i) blds16(rsA, kdead ? kOob : aoff[i], soff, dst + (wave * 4 + i) * 1024);
 #pragma unroll
             for (int i = 0; i < CF::NBP; ++i) {
                 const int p = i * CF::NW + wave;
-                if (p < 4 * TNW)
-                    glds16((kv && boff[i] >= 0) ? static_cast<const void*>(Bb + boff[i] + k)
-                                               : static_cast<const void*>(g_zero_page),
-                           dst + CF::A_BYTES + p * 1024);
+                if (p < 4 * TNW) blds16(rsB, kdead ? kOob : boff[i], soff, dst + CF::A_BYTES + p * 1024);
             }
         }
     };
@@ -1317,12 +1323,17 @@ __global__ __launch_bounds__(kTn2Threads) void gemm_tn2_kernel(const ga_wgrad_de
         goff[b] = (long)lrow * ld + c;
     }
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // LDS-DMA through a buffer resource: 32-bit lane offsets (constant over the launch) + the stage's row offset as scalar
+    const u32x4_s rs = make_rsrc(gsrc, 0xffffffffu);
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) voff[i] = (unsigned)(goff[(i >> 1) & 1] + (long)(4 * i) * ld) * 2u;
     auto stage_load = [&](int s, int buf) {
         if (!sub_live) return;
-        const bf16_t* g = gsrc + (long)s * 32 * ld;
+        const unsigned soff = (unsigned)s * 64u * (unsigned)ld;                    // bytes of 32 rows
         const unsigned dst = lds0 + buf * kTn2Stage + sub * 8192 + (wave & 1) * 4096;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(g + goff[(i >> 1) & 1] + (long)(4 * i) * ld, dst + i * 1024);
+        for (int i = 0; i < 4; ++i) blds16(rs, voff[i], soff, dst + i * 1024);
     };
 
     // ---- MFMA role
@@ -1464,7 +1475,7 @@ bool tn2_eligible(const ga_wgrad_desc* d) {
         return e ? atoi(e) : 1;
     }();
     return force && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 32 == 0 &&
-           d->M >= 8192 && (d->accumulate || d->split_m > 1) && d->ldw % 1 == 0;
+           d->M >= 8192 && (d->accumulate || d->split_m > 1) && (long)d->M * d->ldy < (1L << 31) && (long)d->M * d->ldx < (1L << 31);   // 32-bit byte offsets
 }
 
 // row split of the wide form and the bytes of partial-tile workspace it wants (0: combine with atomics)
@@ -1572,10 +1583,13 @@ bool want_big_tile(const ga_gemm_desc* d, int epi) {
 }
 
 // LDS-DMA form: 256-row tiles, plain bf16 operands, one of the compile-time epilogues
+// the LDS-DMA forms address their operands with 32-bit byte offsets from the matrix base
+bool dma_offsets_fit(const ga_gemm_desc* d) { return (long)d->M * d->lda < (1L << 30) && (long)d->N * d->ldb < (1L << 30); }
+
 bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
     const char* e = getenv("GAEXT_NT_DMA");       // 0 off, 1 heuristic (default), 2 every eligible launch; read per call
     const int mode = e ? atoi(e) : 1;             // so that a test can switch it
-    if (!mode || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || (tnw != 4 && tnw != 3)) return false;
+    if (!mode || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || (tnw != 4 && tnw != 3) || !dma_offsets_fit(d)) return false;
     if ((long)cdiv(d->M, 256) * cdiv(d->N, 32 * tnw) * d->batch < num_cus()) return false;
     // measured (tools/gemm_bench.py): ahead only for the fc2 epilogue with a long reduction (K >= 1024, +8..20 %);
     // mode 2 forces it on every eligible launch (tests, experiments)
@@ -1586,7 +1600,7 @@ bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
 bool want_dma2(const ga_gemm_desc* d, int epi) {
     const char* e = getenv("GAEXT_NT_DMA2");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
     const int mask = e ? atoi(e) : 0;
-    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC) return false;
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !dma_offsets_fit(d)) return false;
     const char* k = getenv("GAEXT_NT_DMA2_MINK");
     if (d->K < (k ? atoi(k) : 256)) return false;
     return (mask >> epi) & 1;
@@ -1598,7 +1612,7 @@ bool want_t256(const ga_gemm_desc* d, int epi) {
     // unset: every epilogue, but only for the very tall launches (M >= 65536: the ViT trunk's 73,856 token rows, -4.8 % on the
     // MAP-ViT-B/384 step); on the ConvNeXt / CSWin stage-2/3 shapes (M = 50,176) the form measured -12 .. +5 % and stays off
     const int mask = e ? atoi(e) : ((d->M >= 65536 && d->N >= 768) ? 15 : 0);      // (N >= 768: the CSWin stem's N = 256 launches lose 2 %)
-    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC) return false;
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !dma_offsets_fit(d)) return false;
     if (d->N % 256 != 0 || d->K < 256) return false;
     if ((long)cdiv(d->M, 256) * (d->N / 256) * d->batch < num_cus()) return false;
     return (mask >> epi) & 1;
