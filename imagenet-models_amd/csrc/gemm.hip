@@ -1599,7 +1599,9 @@ bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
 // 128 x 128 tile, 4 waves, LDS-DMA into a 2-slot ring, 80 KiB: two workgroups per CU without the ds_write staging pass
 bool want_dma2(const ga_gemm_desc* d, int epi) {
     const char* e = getenv("GAEXT_NT_DMA2");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
-    const int mask = e ? atoi(e) : 0;
+    // unset: fc1 and dgrad2 (stage-2 shapes, same box, after the DMA went through buffer resources: fc1 0.126 -> 0.119 ms,
+    // dgrad2 0.137 -> 0.118; fc2 / dgrad1 are 3-5 % slower with it and keep the register-staged form)
+    const int mask = e ? atoi(e) : 10;
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !dma_offsets_fit(d)) return false;
     const char* k = getenv("GAEXT_NT_DMA2_MINK");
     if (d->K < (k ? atoi(k) : 256)) return false;
