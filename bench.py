@@ -41,11 +41,13 @@ GFLOP_PER_IMG = {'ga_convnext_tiny_768': 34.52, 'ga_convnext_tiny': 34.52, 'ga_c
                  # the two attention products of every block (N = (img/16)^2 + 1 tokens) + the MAP head on (img/32)^2 tokens
                  'map_vit_base_patch16_384': 336.1, 'map_vit_base_patch16_224': 106.6, 'map_vit_small_patch16_224': 28.6,
                  # map_pit_s (map_pit.py:224-251): trunk 2.85 GMAC (conv_embedding 0.08, stages 0.67 / 1.30 / 0.79) + MAP head 0.28 GMAC
-                 'map_pit_s': 18.8}
+                 'map_pit_s': 18.8,
+                 # plain ConvNeXt (global_pool='avg' branch of map_convnext.py): 4.47 / 8.70 GMAC forward
+                 'convnext_tiny': 26.8, 'convnext_small': 52.2}
 LABEL = {'ga_convnext_tiny_768': 'GA-ConvNeXt-T', 'ga_convnext_small_768': 'GA-ConvNeXt-S', 'ga_convnext_base_1024': 'GA-ConvNeXt-B',
          'ga_CSWin_64_12211_tiny_224': 'GA-CSWin-T (candidate config, SURVEY F3)', 'map_convnext_tiny': 'MAP-ConvNeXt-T',
          'map_convnext_small': 'MAP-ConvNeXt-S', 'map_vit_base_patch16_384': 'MAP-ViT-B/16 @ 384 (builder-defined composition)',
-         'map_vit_base_patch16_224': 'MAP-ViT-B/16 @ 224', 'map_vit_small_patch16_224': 'MAP-ViT-S/16 @ 224', 'map_pit_s': 'MAP-PiT-S'}
+         'map_vit_base_patch16_224': 'MAP-ViT-B/16 @ 224', 'map_vit_small_patch16_224': 'MAP-ViT-S/16 @ 224', 'map_pit_s': 'MAP-PiT-S', 'convnext_tiny': 'ConvNeXt-T (plain head)', 'convnext_small': 'ConvNeXt-S (plain head)'}
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -165,6 +167,11 @@ def cpu_baseline(model_name, budget_s=10.0):
         from oracle.ga_convnext_oracle import adamw_step
         mod = 'oracle/map_vit_oracle.py'
         step_kw = dict(dec_lam=-0.8)
+    elif model_name.startswith('convnext'):
+        from oracle import convnext_oracle as O
+        from oracle.ga_convnext_oracle import adamw_step
+        mod = 'oracle/convnext_oracle.py'
+        step_kw = dict()
     elif model_name.startswith('map_pit'):
         from oracle import map_pit_oracle as O
         from oracle.ga_convnext_oracle import adamw_step
@@ -195,7 +202,8 @@ def cpu_baseline(model_name, budget_s=10.0):
     step = 0
     while True:
         t0 = time.time()
-        loss, outs, grads, stats = O.train_step_grads(sd, x, y, cfg, **step_kw)
+        res = O.train_step_grads(sd, x, y, cfg, **step_kw)
+        loss, outs, grads, stats = res if len(res) == 4 else (res[0], res[1], res[2], {})
         params = {n: sd[n] for n in grads}
         newp, m, v = adamw_step(params, grads, m, v, step + 1, 1e-3, (0.9, 0.999), 1e-8, 0.05)
         sd.update(newp)

@@ -19,6 +19,8 @@ from .map_convnext import MAP_ConvNeXt  # noqa: E402,F401
 from . import map_vit  # noqa: E402,F401  (registers the map_vit_* entry points)
 from .map_vit import MAP_ViT  # noqa: E402,F401
 from . import map_pit  # noqa: E402,F401  (registers map_pit_s)
+from . import convnext  # noqa: E402,F401  (registers the plain convnext_tiny / convnext_small of map_convnext.py)
+from .convnext import ConvNeXt  # noqa: E402,F401
 from .map_pit import MAP_PiT  # noqa: E402,F401
 from .loss import ga_loss, heads_topk, accuracy_from_topk, map_loss, heads_mean_topk  # noqa: E402,F401
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401

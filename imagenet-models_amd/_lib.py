@@ -186,6 +186,7 @@ _SIGS = {
     'ga_dwpool_bwd_weight': ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_resize_concat_fwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp], i32),
     'ga_resize_concat_bwd': ([vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, i32, vp], i32),
+    'ga_rows_bcast': ([vp, vp, i32, i32, i32, f32, i32, vp], i32),
     'ga_mlp_supported': ([i32, i32, i32], i32),
     'ga_mlp_fwd': ([C.POINTER(MlpDesc), vp], i32),
     'ga_mlp_bwd': ([C.POINTER(MlpBwdDesc), vp], i32),

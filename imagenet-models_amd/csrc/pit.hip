@@ -371,6 +371,22 @@ __global__ __launch_bounds__(256) void pos_add_bwd_kernel(const T* __restrict__ 
     }
 }
 
+// dst[b][p][:] = scale * src[b][:]   (gradient of x.mean([-2, -1]): every pixel of image b receives dsrc[b] / HW)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_bcast_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int HW, int C, float scale) {
+    const int C8 = C / 8;
+    const long n = (long)B * HW * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        const long row = i / C8;
+        float v[8];
+        load8(src + (row / HW) * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= scale;
+        store8(dst + row * C + c, v);
+    }
+}
+
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool fast_path() {       // GAEXT_DWPOOL_SIMPLE=1: the plain any-multiplier kernels (diagnostics / tests)
     const char* e = getenv("GAEXT_DWPOOL_SIMPLE");
@@ -477,4 +493,11 @@ extern "C" int ga_pos_add_bwd(const void* dx0, float* dpos, int B, int Np, int C
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PIT_DISPATCH(dtype, pos_add_bwd_kernel, grid_for((long)Np * C / 8), s, (const T*)dx0, dpos, B, Np, C);
     return ga_check_launch("ga_pos_add_bwd");
+}
+
+extern "C" int ga_rows_bcast(const void* src, void* dst, int B, int HW, int C, float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(src && dst && B > 0 && HW > 0 && C > 0 && C % 8 == 0 && aligned16(src) && aligned16(dst), "ga_rows_bcast: bad args (C %% 8, 16-byte alignment)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PIT_DISPATCH(dtype, rows_bcast_kernel, grid_for((long)B * HW * C / 8), s, (const T*)src, (T*)dst, B, HW, C, scale);
+    return ga_check_launch("ga_rows_bcast");
 }

@@ -383,6 +383,9 @@ class Plan:
     def resize_concat_bwd(self, dcat, dsrc, B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype, label=None):
         self._add('ga_resize_concat_bwd', (_ptr(dcat), _ptr(dsrc), B, Hin, Win, Cdim, Hout, Wout, ldd, c_off, dtype), label, keep=(dcat, dsrc))
 
+    def rows_bcast(self, src, dst, B, HW, Cdim, scale, dtype, label=None):
+        self._add('ga_rows_bcast', (_ptr(src), _ptr(dst), B, HW, Cdim, scale, dtype), label, keep=(src, dst))
+
     def vit_embed_fwd(self, tok, cls, pos, x0, B, Np, Cdim, dtype, label=None):
         self._add('ga_vit_embed_fwd', (_ptr(tok), _ptr(cls), _ptr(pos), _ptr(x0), B, Np, Cdim, dtype), label, keep=(tok, cls, pos, x0))
 

@@ -567,6 +567,9 @@ int ga_resize_concat_fwd(const void* src, void* dst, int B, int Hin, int Win, in
                          int dtype, ga_stream_t stream);
 int ga_resize_concat_bwd(const void* dcat, void* dsrc, int B, int Hin, int Win, int C, int Hout, int Wout, int64_t ldd, int c_off,
                          int dtype, ga_stream_t stream);
+/* dst[b][p][:] = scale * src[b][:], p < HW: the gradient of the global average pool of the plain ConvNeXt head
+ * (MAP/models/map_convnext.py:134-135, `x.mean([-2, -1])`; scale = 1 / HW) */
+int ga_rows_bcast(const void* src, void* dst, int B, int HW, int C, float scale, int dtype, ga_stream_t stream);
 
 /* small fp32 / elementwise utilities */
 int ga_memset(void* p, int value, size_t bytes, ga_stream_t stream); /* hipMemsetAsync on `stream` */

@@ -14,7 +14,7 @@ def _names():
 
 @pytest.mark.parametrize('name', ['ga_convnext_small_768', 'ga_convnext_small_688', 'ga_convnext_base_1024', 'ga_convnext_base_976',
                                   'ga_CSWin_64_24322_small_224', 'map_convnext_small', 'ga_convnext_tiny', 'ga_convnext_small',
-                                  'ga_convnext_base', 'map_vit_small_patch16_224', 'map_vit_base_patch16_224', 'map_pit_s'])
+                                  'ga_convnext_base', 'map_vit_small_patch16_224', 'map_vit_base_patch16_224', 'map_pit_s', 'convnext_tiny'])
 def test_entry_point_trains_and_evaluates(name):
     import imagenet_models_amd as A
     assert name in _names()
@@ -32,6 +32,8 @@ def test_entry_point_trains_and_evaluates(name):
     m.eval()
     with torch.no_grad():
         outs = m(x)
+    if isinstance(outs, torch.Tensor):          # the plain ConvNeXt returns one tensor, as the reference class does
+        outs = [outs]
     assert all(o.shape == (4, 1000) and torch.isfinite(o).all() for o in outs), name
     assert all(torch.isfinite(p).all() for p in m.parameters()), name
 
@@ -43,4 +45,4 @@ def test_every_listed_model_is_covered_somewhere():
                              'ga_convnext_base_976', 'ga_convnext_base_1024', 'ga_convnext_tiny', 'ga_convnext_small',
                              'ga_convnext_base', 'ga_CSWin_64_12211_tiny_224', 'ga_CSWin_64_24322_small_224', 'map_convnext_tiny',
                              'map_convnext_small', 'map_vit_base_patch16_384', 'map_vit_base_patch16_224', 'map_vit_small_patch16_224',
-                             'map_pit_s'}
+                             'map_pit_s', 'convnext_tiny', 'convnext_small'}

@@ -80,3 +80,35 @@ def test_multi_group_loss_matches_torch_formula():
     for y, ym in outs:
         want = want + (-0.8) * F.kl_div(F.log_softmax(y, 1), F.log_softmax(agg / 4, 1), reduction='mean', log_target=True)
     assert abs(float(O.multi_group_loss(outs, tgt, -0.8)) - float(want)) < 1e-6
+
+
+# ---- plain ConvNeXt (global_pool='avg' branch of map_convnext.py; oracle/convnext_oracle.py vs fixtures from the reference class)
+@pytest.mark.parametrize('tag', ['cnx_v9', 'cnx_tiny'])
+def test_plain_convnext_eval_fixture(tag):
+    from oracle import convnext_oracle as CO
+    z = np.load(os.path.join(GOLDEN, f'{tag}_eval.npz'))
+    c = json.loads(str(z['cfg']))
+    cfg = CO.make_cfg(dims=tuple(c['dims']), depths=tuple(c['depths']), num_classes=c['num_classes'])
+    sd = CO.fill_state(cfg)
+    assert sum(v.numel() for v in sd.values()) == int(z['param_count'])
+    with torch.no_grad():
+        out = CO.forward(sd, CO.gen_input(int(z['batch']), seed=0), cfg)
+    assert _rel(out[:, :40].numpy(), z['logits']) < 1e-4
+    assert np.array_equal(out.topk(5, 1, True, True)[1].numpy(), z['top5'])
+
+
+def test_plain_convnext_train_fixture():
+    from oracle import convnext_oracle as CO
+    z = np.load(os.path.join(GOLDEN, 'cnx_v9_train_b4.npz'))
+    c = json.loads(str(z['cfg']))
+    cfg = CO.make_cfg(dims=tuple(c['dims']), depths=tuple(c['depths']), num_classes=c['num_classes'])
+    sd = CO.fill_state(cfg)
+    loss, out, grads = CO.train_step_grads(sd, CO.gen_input(int(z['batch']), seed=1), torch.from_numpy(z['target']), cfg)
+    assert abs(float(loss) - float(z['loss'])) / abs(float(z['loss'])) < 1e-4
+    assert _rel(out[:, :40].numpy(), z['logits']) < 1e-4
+    gmax = float(z['grad_norm'].max())
+    for n, w in zip(z['grad_names'].tolist(), z['grad_norm'].tolist()):
+        if w > 1e-3 * gmax:
+            assert abs(float(grads[n].double().norm()) - w) / w < 1e-2, n
+    # README known answers of the architecture: ConvNeXt-T / -S parameter counts
+    assert sum(int(np.prod(s)) for s in CO.state_shapes(CO.make_cfg('convnext_tiny')).values()) == 28589128
