@@ -92,5 +92,11 @@ for (M, N, K) in [(8192, 8192, 8192), (73856, 2304, 768), (73856, 768, 768), (73
     p = ops.Plan(); p.gemm(a, b, c, M, N, K, dt)
     report(f'plain M{M} N{N} K{K}', timeit(p), 2.0 * M * N * K, 2 * (M * N + M * K + N * K))
     del a, b, c
+for (M, N, K) in [(73856, 2304, 768), (73856, 768, 768), (73856, 3072, 768), (73856, 768, 3072)]:
+    y, x = rnd(M, N), rnd(M, K)
+    G = torch.zeros(N, K, device='cuda')
+    p = ops.Plan(); p.wgrad(y, x, G, M, N, K, dt)
+    report(f'wgrad M{M} N{N} K{K}', timeit(p), 2.0 * M * N * K, 2 * (M * N + M * K))
+    del y, x, G
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], 'w'), indent=1)
