@@ -61,7 +61,10 @@ def ga_loss(outputs, target, lam=0.0, kind='ce', smoothing=0.0, bce_target_thres
 
 
 def heads_topk(outputs, k=5):
-    """validate(): output = sum_k out_k.float(); returns (summed logits (B,NC), top-k indices (B,k) int64)"""
+    """validate(): output = sum_k out_k.float(); returns (summed logits (B,NC), top-k indices (B,k) int64).  A single (B,NC)
+    tensor (the plain-head models) counts as one head, as the reference's validate does for non-list outputs"""
+    if isinstance(outputs, torch.Tensor):
+        outputs = [outputs]
     logits = stack_heads(outputs).float().contiguous()
     K, B, NC = logits.shape
     s = torch.empty(B, NC, device=logits.device)

@@ -22,7 +22,9 @@ def _run(cmd, env=None, timeout=900):
                                          ('ga_CSWin_64_12211_tiny_224', ['--GA_lam', '-0.8', '--opt', 'adamw', '--lr', '1e-3', '--mixup', '0', '--cutmix', '0']),
                                          ('ga_convnext_tiny_768', ['--GA_lam', '-0.8', '--clip-mode', 'agc', '--clip-grad', '0.02', '--mixup-off-epoch', '1']),
                                          ('map_convnext_tiny', ['--dec-lam', '-0.8', '--opt', 'adamw', '--lr', '1e-3']),
-                                         ('map_vit_small_patch16_224', ['--dec-lam', '-0.8', '--opt', 'adamw', '--lr', '1e-3'])])
+                                         ('map_vit_small_patch16_224', ['--dec-lam', '-0.8', '--opt', 'adamw', '--lr', '1e-3']),
+                                         ('map_pit_s', ['--dec-lam', '-0.8', '--opt', 'adamw', '--lr', '1e-3']),
+                                         ('convnext_tiny', ['--opt', 'adamw', '--lr', '1e-3', '--smoothing', '0.1'])])
 def test_train_cli_runs_every_family(model, extra):
     out = _run([sys.executable, 'train.py', '--synthetic', '--model', model, '-b', '8', '--epochs', '1', '--steps-per-epoch', '3',
                 '--drop-path', '0.1', '--log-interval', '1', '--clip-grad', '5.0'] + extra)
