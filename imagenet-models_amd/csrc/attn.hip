@@ -49,6 +49,21 @@ __device__ __forceinline__ bf16x8_t acc_pair_frag(const f32x4_t& a, const f32x4_
     return *reinterpret_cast<const bf16x8_t*>(&u);
 }
 
+// max / sum over the four lane rows (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap(x, x) leaves the lane's own value in
+// one result and its l^16 partner's in the other (which is which depends on the row, the combination does not); likewise 32
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 constexpr int BQ = 64;                  // rows of a block (queries or keys)
 constexpr int SLAB = BQ * 64;           // bytes of one [64][32] slab
 constexpr int TILE = 2 * SLAB;          // [64][64] bf16
@@ -101,6 +116,26 @@ __device__ __forceinline__ void store_rows16(unsigned char* stage, const f32x4_t
     }
 }
 
+// the same for TRANSPOSED accumulator tiles o[dt] (row = channel 16 dt + 4 g + r, column = the wave's row lane & 15)
+__device__ __forceinline__ void store_rows16_t(unsigned char* stage, const f32x4_t (&o)[4], bf16_t* dst, long ld, int r0, int nrows,
+                                               int lane, int hc) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        uint2 u;
+        u.x = pack2bf(o[dt][0], o[dt][1]);
+        u.y = pack2bf(o[dt][2], o[dt][3]);
+        *reinterpret_cast<uint2*>(stage + (lane & 15) * 128 + (16 * dt + 4 * (lane >> 4)) * 2) = u;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // a wave's LDS accesses complete in order
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = 8 * p + (lane >> 3), c = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + r * 128 + c * 16);
+        if (r0 + r < nrows && c < hc) *reinterpret_cast<uint4*>(dst + (long)(r0 + r) * ld + c * 8) = v;
+    }
+}
+
 __device__ __forceinline__ int xcd_walk(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -121,6 +156,9 @@ __device__ __forceinline__ Item item_of(const ga_attn_desc& d, int id, int nblk)
 // =================================================================================================================
 // forward, bf16, head_dim 64
 // =================================================================================================================
+// QT = 16-query tiles per wave: a workgroup owns 64 * QT queries.  With QT = 2 every K / V fragment read from LDS feeds two MFMAs
+// (one wave's 16 queries alone make the loop LDS-bound: 8 ds_read_b128 + 16 transposing reads per 16 MFMAs)
+template <int QT>
 __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const int nblk, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* Qs = smem;
@@ -129,16 +167,27 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
     unsigned char* Stage = Vs + TILE;            // 4 x 2 KiB
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * BQ;
+    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * (BQ * QT);
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
-    load_block(Qs, qkv, d.ldq, q0, d.N, hc);
-    __syncthreads();
-    bf16x8_t qf[2];
+    bf16x8_t qf[QT][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) qf[s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
+    for (int t = 0; t < QT; ++t) {
+        if (t) __syncthreads();
+        load_block(Qs, qkv, d.ldq, q0 + BQ * t, d.N, hc);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[t][s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
+    }
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t o[4] = {zero, zero, zero, zero};
-    float m = -3.0e38f, l = 0.f;
+    f32x4_t o[QT][4];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -3.0e38f;
+        l[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = zero;
+    }
     const float sc = d.scale * 1.44269504f;                    // exp2 domain
     BlockRegs kr, vr;                                          // the next key / value block travels in registers
     fetch_block(kr, qkv + C, d.ldq, 0, d.N, hc);
@@ -152,61 +201,72 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const ga_attn_desc d, const
             fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N, hc);
             fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N, hc);
         }
-        f32x4_t st[4];
-        float mx = -3.0e38f;
+        f32x4_t st[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            st[kt] = zero;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) st[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks + s * SLAB, 16 * kt, lane), qf[s], st[kt], 0, 0, 0);
+            for (int t = 0; t < QT; ++t) st[t][kt] = zero;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                st[kt][r] = (k0 + 16 * kt + 4 * g + r < d.N) ? st[kt][r] * sc : -3.0e38f;
-                mx = fmaxf(mx, st[kt][r]);
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8_t kf = row_frag(Ks + s * SLAB, 16 * kt, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[t][s], st[t][kt], 0, 0, 0);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m - mn);
-        float sum = 0.f;
+        bf16x8_t pf[QT][2];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int t = 0; t < QT; ++t) {
+            float mx = -3.0e38f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(st[kt][r] - mn);      // masked keys: exp2(-huge) = 0
-                st[kt][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        l = l * alpha + sum;
-        m = mn;
-        // the accumulator rows are queries 4g + r, the statistics live in the lanes whose (lane & 15) is that query
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float ar = __shfl(alpha, 4 * g + r, 64);
+                for (int r = 0; r < 4; ++r) {
+                    st[t][kt][r] = (k0 + 16 * kt + 4 * g + r < d.N) ? st[t][kt][r] * sc : -3.0e38f;
+                    mx = fmaxf(mx, st[t][kt][r]);
+                }
+            mx = rows_max(mx);
+            const float mn = fmaxf(m[t], mx);
+            const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+            float sum = 0.f;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[dt][r] *= ar;
-        }
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            const bf16x8_t pf = acc_pair_frag(st[2 * kp], st[2 * kp + 1]);
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(st[t][kt][r] - mn);      // masked keys: exp2(-huge) = 0
+                    st[t][kt][r] = p;
+                    sum += p;
+                }
+            sum = rows_sum(sum);
+            l[t] = l[t] * alpha + sum;
+            m[t] = mn;
+            // O is accumulated TRANSPOSED (rows = channels, column = the query lane & 15): the statistics of a lane's query are its own
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Vs + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane), o[dt], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][dt][r] *= alpha;
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) pf[t][kp] = acc_pair_frag(st[t][2 * kp], st[t][2 * kp + 1]);
         }
-    }
-    const float linv = 1.f / l;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float lr = __shfl(linv, 4 * g + r, 64);
+        for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt][r] *= lr;
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t vf = col_frag_acc(Vs + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[t][kp], o[t][dt], 0, 0, 0);   // (V^T P^T)
+            }
     }
-    const int qw = q0 + 16 * wave;
-    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(d.out) + it.row0 * d.ldo + it.h * d.hd, d.ldo, qw, d.N, lane, hc);
-    if (lane < 16 && qw + lane < d.N) d.lse[((long)it.b * d.H + it.h) * d.N + qw + lane] = m * 0.69314718f + __logf(l);   // natural-log units
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const float linv = 1.f / l[t];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][dt][r] *= linv;
+        const int qw = q0 + BQ * t + 16 * wave;
+        store_rows16_t(Stage + wave * 2048, o[t], reinterpret_cast<bf16_t*>(d.out) + it.row0 * d.ldo + it.h * d.hd, d.ldo, qw, d.N, lane, hc);
+        if (lane < 16 && qw + lane < d.N) d.lse[((long)it.b * d.H + it.h) * d.N + qw + lane] = m[t] * 0.69314718f + __logf(l[t]);   // natural-log units
+    }
 }
 
 // delta[b][h][q] = sum_d dO[q][d] * O[q][d]   (one thread per (b, h, q))
@@ -622,8 +682,11 @@ extern "C" int ga_attn_fwd(const ga_attn_desc* d, ga_stream_t stream) {
     if (int rc = check_desc(d, "ga_attn_fwd")) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (use_mfma(d)) {
-        const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
-        hipLaunchKernelGGL(attn_fwd_mfma, dim3(nwg), dim3(256), 3 * TILE + 8192, s, *d, nblk, nwg);
+        static const int qt_env = [] { const char* e = getenv("GAEXT_ATTN_QT"); return e ? atoi(e) : 0; }();
+        const int qt = qt_env ? qt_env : (d->N >= 128 ? 2 : 1);
+        const int nblk = (d->N + BQ * qt - 1) / (BQ * qt), nwg = nblk * d->B * d->H;
+        if (qt == 2) hipLaunchKernelGGL(attn_fwd_mfma<2>, dim3(nwg), dim3(256), 3 * TILE + 8192, s, *d, nblk, nwg);
+        else hipLaunchKernelGGL(attn_fwd_mfma<1>, dim3(nwg), dim3(256), 3 * TILE + 8192, s, *d, nblk, nwg);
         return ga_check_launch("ga_attn_fwd");
     }
     const long n = (long)d->B * d->H * d->N;
