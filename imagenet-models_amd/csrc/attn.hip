@@ -407,6 +407,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
 // =================================================================================================================
 // backward dK / dV, bf16, head_dim 64: one workgroup per 64 keys, queries / dO streamed
 // =================================================================================================================
+// KT = 16-key tiles per wave (a workgroup owns 64 * KT keys): with KT = 2 every Q / dO fragment read from LDS (16 row reads + 32
+// transposing reads per query block) feeds two MFMAs
+template <int KT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta,
                                                          const int nblk, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -419,23 +422,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
     float* dlt_s = lse_s + BQ;                                     // [64]
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int hc = d.hd >> 3, C = d.H * d.hd, k0 = it.blk * BQ;
+    const int hc = d.hd >> 3, C = d.H * d.hd, k0 = it.blk * (BQ * KT);
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
     const bf16_t* dout = reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * d.hd;
     bf16_t* dqkv = reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * d.hd;
-    load_block(Ks, qkv + C, d.ldq, k0, d.N, hc);
-    load_block(Vs, qkv + 2 * C, d.ldq, k0, d.N, hc);
-    __syncthreads();
-    bf16x8_t kf[2], vf[2];
+    bf16x8_t kf[KT][2], vf[KT][2];
+    bool key_ok[KT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        kf[s] = row_frag(Ks + s * SLAB, 16 * wave, lane);
-        vf[s] = row_frag(Vs + s * SLAB, 16 * wave, lane);
+    for (int t = 0; t < KT; ++t) {
+        if (t) __syncthreads();
+        load_block(Ks, qkv + C, d.ldq, k0 + BQ * t, d.N, hc);
+        load_block(Vs, qkv + 2 * C, d.ldq, k0 + BQ * t, d.N, hc);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            kf[t][s] = row_frag(Ks + s * SLAB, 16 * wave, lane);
+            vf[t][s] = row_frag(Vs + s * SLAB, 16 * wave, lane);
+        }
+        key_ok[t] = k0 + BQ * t + 16 * wave + (lane & 15) < d.N;
     }
-    const bool key_ok = k0 + 16 * wave + (lane & 15) < d.N;
     const long sbase = ((long)it.b * d.H + it.h) * d.N;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t dv[4] = {zero, zero, zero, zero}, dk[4] = {zero, zero, zero, zero};
+    f32x4_t dv[KT][4], dk[KT][4];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[t][dt] = dk[t][dt] = zero;
     BlockRegs qr, gr;
     float lr = 0.f, dr = 0.f;                                  // this thread's lse / delta entry of the next query block (threads < 64)
     auto fetch_q = [&](int q0) {
@@ -460,41 +472,59 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma(const ga_attn_desc d, c
         if (q0 + BQ < d.N) fetch_q(q0 + BQ);
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
-            f32x4_t p[2], ds[2];
+            f32x4_t p[KT][2], ds[KT][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int qt = 32 * qs + 16 * h;              // rows of this 16-query tile inside the block
-                p[h] = zero;
-                ds[h] = zero;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) p[t][h] = ds[t][h] = zero;
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    p[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Qs + s * SLAB, qt, lane), kf[s], p[h], 0, 0, 0);      // [query 4g+r][key lane&15]
-                    ds[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Gs + s * SLAB, qt, lane), vf[s], ds[h], 0, 0, 0);
+                    const bf16x8_t qfr = row_frag(Qs + s * SLAB, qt, lane), gfr = row_frag(Gs + s * SLAB, qt, lane);
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        p[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfr, kf[t][s], p[t][h], 0, 0, 0);      // [query 4g+r][key lane&15]
+                        ds[t][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gfr, vf[t][s], ds[t][h], 0, 0, 0);
+                    }
                 }
                 const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(lse_s + qt + 4 * g);
                 const f32x4_t de = *reinterpret_cast<const f32x4_t*>(dlt_s + qt + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = key_ok && q0 + qt + 4 * g + r < d.N;
-                    const float pv = ok ? __expf(p[h][r] * d.scale - ls[r]) : 0.f;
-                    p[h][r] = pv;
-                    ds[h][r] = pv * (ds[h][r] - de[r]);
-                }
+                for (int t = 0; t < KT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool ok = key_ok[t] && q0 + qt + 4 * g + r < d.N;
+                        const float pv = ok ? __expf(p[t][h][r] * d.scale - ls[r]) : 0.f;
+                        p[t][h][r] = pv;
+                        ds[t][h][r] = pv * (ds[t][h][r] - de[r]);
+                    }
             }
-            const bf16x8_t pf = acc_pair_frag(p[0], p[1]), sf = acc_pair_frag(ds[0], ds[1]);
+            bf16x8_t pf[KT], sf[KT];
+#pragma unroll
+            for (int t = 0; t < KT; ++t) {
+                pf[t] = acc_pair_frag(p[t][0], p[t][1]);
+                sf[t] = acc_pair_frag(ds[t][0], ds[t][1]);
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, col_frag_acc(Gs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane), dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Qs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane), dk[dt], 0, 0, 0);
+                const bf16x8_t gc = col_frag_acc(Gs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane), qc = col_frag_acc(Qs + (dt >> 1) * SLAB, 32 * qs, dt & 1, lane);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    dv[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[t], gc, dv[t][dt], 0, 0, 0);
+                    dk[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[t], qc, dk[t][dt], 0, 0, 0);
+                }
             }
         }
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int t = 0; t < KT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dk[dt][r] *= d.scale;
-    store_rows16(Stage + wave * 2048, dk, dqkv + C, d.ldq, k0 + 16 * wave, d.N, lane, hc);
-    store_rows16(Stage + wave * 2048, dv, dqkv + 2 * C, d.ldq, k0 + 16 * wave, d.N, lane, hc);
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dk[t][dt][r] *= d.scale;
+        store_rows16(Stage + wave * 2048, dk[t], dqkv + C, d.ldq, k0 + BQ * t + 16 * wave, d.N, lane, hc);
+        store_rows16(Stage + wave * 2048, dv[t], dqkv + 2 * C, d.ldq, k0 + BQ * t + 16 * wave, d.N, lane, hc);
+    }
 }
 
 // =================================================================================================================
@@ -724,7 +754,11 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
     if (use_mfma(d) && aligned16(dout) && aligned16(dqkv)) {
         const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
         hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk, nwg);
-        hipLaunchKernelGGL(attn_bwd_dkv_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192 + 512, s, *d, dout, dqkv, delta, nblk, nwg);
+        static const int kt_env = [] { const char* e = getenv("GAEXT_ATTN_KT"); return e ? atoi(e) : 0; }();
+        const int kt = kt_env ? kt_env : (d->N >= 128 ? 2 : 1);
+        const int nblk2 = (d->N + BQ * kt - 1) / (BQ * kt), nwg2 = nblk2 * d->B * d->H;
+        if (kt == 2) hipLaunchKernelGGL(attn_bwd_dkv_mfma<2>, dim3(nwg2), dim3(256), 4 * TILE + 8192 + 512, s, *d, dout, dqkv, delta, nblk2, nwg2);
+        else hipLaunchKernelGGL(attn_bwd_dkv_mfma<1>, dim3(nwg2), dim3(256), 4 * TILE + 8192 + 512, s, *d, dout, dqkv, delta, nblk2, nwg2);
         return ga_check_launch("ga_attn_bwd");
     }
     if (d->dtype == GA_BF16) {
