@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256) void attn_delta_heads_kernel(const ga_attn_des
 // =================================================================================================================
 // backward dQ, bf16, head_dim 64: one workgroup per 64 queries, keys / values streamed
 // =================================================================================================================
+template <int QT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, const void* dout_, void* dqkv_, const float* delta,
                                                         const int nblk, const int nwg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -345,22 +346,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
     unsigned char* Stage = Vs + TILE;
     const Item it = item_of(d, xcd_walk(blockIdx.x, nwg), nblk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * BQ;
+    const int hc = d.hd >> 3, C = d.H * d.hd, q0 = it.blk * (BQ * QT);
     const bf16_t* qkv = reinterpret_cast<const bf16_t*>(d.qkv) + it.row0 * d.ldq + it.h * d.hd;
-    load_block(Qs, qkv, d.ldq, q0, d.N, hc);
-    load_block(Gs, reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * d.hd, d.ldo, q0, d.N, hc);
-    __syncthreads();
-    bf16x8_t qf[2], gf[2];
+    bf16x8_t qf[QT][2], gf[QT][2];
+    float lse[QT], dl[QT];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        qf[s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
-        gf[s] = row_frag(Gs + s * SLAB, 16 * wave, lane);
+    for (int t = 0; t < QT; ++t) {
+        if (t) __syncthreads();
+        load_block(Qs, qkv, d.ldq, q0 + BQ * t, d.N, hc);
+        load_block(Gs, reinterpret_cast<const bf16_t*>(dout_) + it.row0 * d.ldo + it.h * d.hd, d.ldo, q0 + BQ * t, d.N, hc);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[t][s] = row_frag(Qs + s * SLAB, 16 * wave, lane);
+            gf[t][s] = row_frag(Gs + s * SLAB, 16 * wave, lane);
+        }
+        const int qi = q0 + BQ * t + 16 * wave + (lane & 15);
+        const long sidx = ((long)it.b * d.H + it.h) * d.N + qi;
+        lse[t] = qi < d.N ? d.lse[sidx] : 0.f;
+        dl[t] = qi < d.N ? delta[sidx] : 0.f;
     }
-    const int qi = q0 + 16 * wave + (lane & 15);
-    const long sidx = ((long)it.b * d.H + it.h) * d.N + qi;
-    const float lse = qi < d.N ? d.lse[sidx] : 0.f, dl = qi < d.N ? delta[sidx] : 0.f;
     const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t o[4] = {zero, zero, zero, zero};
+    f32x4_t o[QT][4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = zero;
     BlockRegs kr, vr;
     fetch_block(kr, qkv + C, d.ldq, 0, d.N, hc);
     fetch_block(vr, qkv + 2 * C, d.ldq, 0, d.N, hc);
@@ -373,35 +384,51 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma(const ga_attn_desc d, co
             fetch_block(kr, qkv + C, d.ldq, k0 + BQ, d.N, hc);
             fetch_block(vr, qkv + 2 * C, d.ldq, k0 + BQ, d.N, hc);
         }
-        f32x4_t ds[4];
+        f32x4_t ds[QT][4];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            f32x4_t st = zero, dp = zero;
+            f32x4_t st[QT], dp[QT];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) st[t] = dp[t] = zero;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Ks + s * SLAB, 16 * kt, lane), qf[s], st, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag(Vs + s * SLAB, 16 * kt, lane), gf[s], dp, 0, 0, 0);
+                const bf16x8_t kfr = row_frag(Ks + s * SLAB, 16 * kt, lane), vfr = row_frag(Vs + s * SLAB, 16 * kt, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    st[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[t][s], st[t], 0, 0, 0);
+                    dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr, gf[t][s], dp[t], 0, 0, 0);
+                }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool ok = k0 + 16 * kt + 4 * g + r < d.N;
-                const float p = ok ? __expf(st[r] * d.scale - lse) : 0.f;
-                ds[kt][r] = p * (dp[r] - dl);
-            }
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = k0 + 16 * kt + 4 * g + r < d.N;
+                    const float p = ok ? __expf(st[t][r] * d.scale - lse[t]) : 0.f;
+                    ds[t][kt][r] = p * (dp[t][r] - dl[t]);
+                }
         }
 #pragma unroll
         for (int kp = 0; kp < 2; ++kp) {
-            const bf16x8_t sf = acc_pair_frag(ds[2 * kp], ds[2 * kp + 1]);
+            bf16x8_t sf[QT];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf, col_frag_acc(Ks + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane), o[dt], 0, 0, 0);
+            for (int t = 0; t < QT; ++t) sf[t] = acc_pair_frag(ds[t][2 * kp], ds[t][2 * kp + 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const bf16x8_t kc = col_frag_acc(Ks + (dt >> 1) * SLAB, 32 * kp, dt & 1, lane);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[t], kc, o[t][dt], 0, 0, 0);
+            }
         }
     }
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int t = 0; t < QT; ++t) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[dt][r] *= d.scale;
-    store_rows16(Stage + wave * 2048, o, reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * d.hd, d.ldq, q0 + 16 * wave, d.N, lane, hc);
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[t][dt][r] *= d.scale;
+        store_rows16(Stage + wave * 2048, o[t], reinterpret_cast<bf16_t*>(dqkv_) + it.row0 * d.ldq + it.h * d.hd, d.ldq, q0 + BQ * t + 16 * wave, d.N, lane, hc);
+    }
 }
 
 // =================================================================================================================
@@ -752,8 +779,11 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
     }
     if (use_mfma(d) && aligned16(dout) && aligned16(dqkv)) {
-        const int nblk = (d->N + BQ - 1) / BQ, nwg = nblk * d->B * d->H;
-        hipLaunchKernelGGL(attn_bwd_dq_mfma, dim3(nwg), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk, nwg);
+        static const int qt_env = [] { const char* e = getenv("GAEXT_ATTN_QT"); return e ? atoi(e) : 0; }();
+        const int qt = qt_env ? qt_env : (d->N >= 256 ? 2 : 1);      // (N = 197: 0.381 vs 0.393 ms per backward with 2)
+        const int nblk1 = (d->N + BQ * qt - 1) / (BQ * qt), nwg1 = nblk1 * d->B * d->H;
+        if (qt == 2) hipLaunchKernelGGL(attn_bwd_dq_mfma<2>, dim3(nwg1), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk1, nwg1);
+        else hipLaunchKernelGGL(attn_bwd_dq_mfma<1>, dim3(nwg1), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk1, nwg1);
         static const int kt_env = [] { const char* e = getenv("GAEXT_ATTN_KT"); return e ? atoi(e) : 0; }();
         const int kt = kt_env ? kt_env : (d->N >= 128 ? 2 : 1);
         const int nblk2 = (d->N + BQ * kt - 1) / (BQ * kt), nwg2 = nblk2 * d->B * d->H;
