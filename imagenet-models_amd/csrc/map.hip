@@ -158,12 +158,12 @@ __global__ __launch_bounds__(kThr) void mt_attn_fwd_kernel(const T* __restrict__
 
 // backward: dout [B][T][E] -> dq [B][T][E], dkv_cls [B][T][2E], dkv_tok rows (overwritten)
 template <typename T, int MT>
-__global__ __launch_bounds__(MT > 4 ? 512 : kThr) void mt_attn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
+__global__ __launch_bounds__(512) void mt_attn_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q,
                                                            const T* __restrict__ kv_cls, const T* __restrict__ kv_tok, long tok_ld,
                                                            const float* __restrict__ P, const float* __restrict__ mask,
                                                            T* __restrict__ dq, T* __restrict__ dkv_cls, T* __restrict__ dkv_tok,
                                                            long dtok_ld, int Tn, int N, int heads, int hd, float scale) {
-    constexpr int kW = MT > 4 ? 8 : 16, kThr = 64 * kW;      // > 4 query tokens: 8 waves, so that the per-token registers fit without spills
+    constexpr int kW = 8, kThr = 64 * kW;      // 8 waves (not the 16 of the forward): the per-token registers fit without spills
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int E = heads * hd, NCH = E >> 3, cph = hd >> 3;
     float* part = sm;                       // [N][NCH]
@@ -426,7 +426,7 @@ extern "C" int ga_class_attn_mt_bwd(const void* dout, const void* q, const void*
                            reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t, 6>)) && reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float, 6>)) &&
                            reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<bf16_t, 8>)) && reserve(reinterpret_cast<const void*>(mt_attn_bwd_kernel<float, 8>));
     GA_REQUIRE(ok, "ga_class_attn_mt_bwd: cannot reserve LDS");
-#define MT_LAUNCH(TT, MTT) hipLaunchKernelGGL((mt_attn_bwd_kernel<TT, MTT>), dim3(B), dim3(MTT > 4 ? 512 : kThr), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld, P, mask, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, T_, N, heads, hd, scale)
+#define MT_LAUNCH(TT, MTT) hipLaunchKernelGGL((mt_attn_bwd_kernel<TT, MTT>), dim3(B), dim3(512), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld, P, mask, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, T_, N, heads, hd, scale)
     if (dtype == GA_BF16) { using T = bf16_t; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
     else { using T = float; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
 #undef MT_LAUNCH
