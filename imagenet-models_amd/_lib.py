@@ -112,6 +112,7 @@ _SIGS = {
     'ga_wgrad_workspace': ([C.POINTER(WgradDesc)], C.c_size_t),
     'ga_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, i64, i32, f32, i32, vp], i32),
     'ga_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp], i32),
+    'ga_layernorm_bwd_dp': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp, i64, i32, vp], i32),
     'ga_bn_finalize': ([vp, vp, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
     'ga_affine_act': ([vp, vp, vp, vp, vp, i64, vp, i64, i32, i32, i32, i64, vp], i32),
     'ga_bn_bwd_reduce': ([vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, i32, i64, vp], i32),

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ w, const T* __restrict__ dres,
                                                      T* __restrict__ dx, float* __restrict__ dw,
-                                                     float* __restrict__ db, long rows, int C, int xnorm) {
+                                                     float* __restrict__ db, long rows, int C, int xnorm,
+                                                     T* __restrict__ dx2, const float* __restrict__ scale2, long rows_per_scale) {
     constexpr int E = elt<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) float red[];  // [2][rpb][C] when dw != null
     const int lg = threadIdx.x % G, rib = threadIdx.x / G, rpb = 256 / G;
@@ -182,6 +183,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
 #pragma unroll
                 for (int e = 0; e < E; ++e) o[e] += rs * (gv[j][e] - s1 - xh[j][e] * s2);
                 st_chunk(dx + row * C + ci * E, o);
+                if (dx2) {      // second output: the stored value times a per-sample scale (the consumer block's DropPath factor)
+                    const float sc2 = scale2[row / rows_per_scale];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] = elt<T>::round(o[e]) * sc2;
+                    st_chunk(dx2 + row * C + ci * E, o);
+                }
             }
         }
     }
@@ -451,7 +458,8 @@ static int ln_fwd_t(const void* x, const float* w, const float* b, void* y, floa
 
 template <typename T>
 static int ln_bwd_t(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
-                    const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int xnorm, hipStream_t s) {
+                    const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int xnorm, hipStream_t s,
+                    void* dx2 = nullptr, const float* scale2 = nullptr, int64_t rows_per_scale = 1) {
     const int G = pick_group(C, elt<T>::EPC);
     const int rpb = 256 / G;
     // persistent when parameter gradients are reduced (bounds the number of atomics)
@@ -459,7 +467,7 @@ static int ln_bwd_t(const void* g, const void* x, const float* mean, const float
     const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
     const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : (C / elt<T>::EPC <= 4 * G ? 0 : 8));
     LN_DISPATCH(G, (w != nullptr || dw != nullptr), nch3, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
-                dw, db, (long)rows, C, xnorm);
+                dw, db, (long)rows, C, xnorm, (T*)dx2, scale2, (long)rows_per_scale);
     return ga_check_launch("ga_layernorm_bwd");
 }
 
@@ -482,6 +490,19 @@ extern "C" int ga_layernorm_bwd(const void* g, const void* x, const float* mean,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == GA_BF16 ? ln_bwd_t<bf16_t>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s)
                             : ln_bwd_t<float>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s);
+}
+
+extern "C" int ga_layernorm_bwd_dp(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
+                                   const void* dres, void* dx, float* dw, float* db, int64_t rows, int C,
+                                   int x_is_normalized, void* dx2, const float* scale2, int64_t rows_per_scale, int dtype,
+                                   ga_stream_t stream) {
+    const int epc = dtype == GA_BF16 ? 8 : 4;
+    GA_REQUIRE(g && x && rstd && dx && dx2 && scale2 && rows_per_scale > 0 && rows > 0 && C % epc == 0 && pick_group(C, epc) > 0,
+               "ga_layernorm_bwd_dp: bad args");
+    GA_REQUIRE(x_is_normalized || mean, "ga_layernorm_bwd_dp: mean required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == GA_BF16 ? ln_bwd_t<bf16_t>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s, dx2, scale2, rows_per_scale)
+                            : ln_bwd_t<float>(g, x, mean, rstd, w, dres, dx, dw, db, rows, C, x_is_normalized, s, dx2, scale2, rows_per_scale);
 }
 
 extern "C" int ga_bn_finalize(const float* sum, const float* sumsq, int64_t n, const float* w, const float* b,

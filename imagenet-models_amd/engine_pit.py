@@ -121,7 +121,8 @@ class MAPPiTEngine(MAPViTEngine):
             for j in range(depth[s] - 1, -1, -1):
                 cur = (cur + 1) % 3
                 dx = rot[cur][:M * C].view(M, C)
-                self._vit_block_bwd(f'transformers.{s}.blocks.{j}.', dy, dx, M, C, Ntok)
+                self._vit_block_bwd(f'transformers.{s}.blocks.{j}.', dy, dx, M, C, Ntok,
+                                    next_pre=f'transformers.{s}.blocks.{j - 1}.' if j > 0 else None)      # (stage seams add a feature seed)
                 dy = dx
             if s == 2:
                 Bk.mark('stage3')

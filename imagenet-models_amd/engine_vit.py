@@ -69,8 +69,10 @@ class MAPViTEngine(MAPEngine):
                label=pre + 'fc2')
         return y
 
-    def _vit_block_bwd(self, pre, dy, dx, M, C, Ntok):
-        """dy: gradient wrt the block output; writes dx (a different buffer) = gradient wrt the block input"""
+    def _vit_block_bwd(self, pre, dy, dx, M, C, Ntok, next_pre=None):
+        """dy: gradient wrt the block output; writes dx (a different buffer) = gradient wrt the block input.  next_pre: the block
+        that consumes dx unchanged as ITS dy (the next one of the backward chain, when no feature seed is added in between): this
+        block's last LayerNorm backward then also writes that block's DropPath-scaled copy (self._pre_dyz), saving it a pass"""
         Bk, dt, P, W = self.bwd, self.dt, self.P, self.W
         st = self.blocks[pre]
         dp1, dp2 = self.dp_scale.get(pre + '#1'), self.dp_scale.get(pre + '#2')
@@ -82,8 +84,10 @@ class MAPViTEngine(MAPEngine):
             Bk.join_async(f'blk{self._bwd_seq - 2}')
         dyz = dy
         if dp2 is not None:
-            dyz = self.tmp('dyz' + par, (M, C))
-            Bk.rowscale(dy, dp2, dyz, M * C, Ntok * C, dt, label=pre + 'dp2')
+            dyz = self._pre_dyz.pop(pre, None)
+            if dyz is None:
+                dyz = self.tmp('dyz' + par, (M, C))
+                Bk.rowscale(dy, dp2, dyz, M * C, Ntok * C, dt, label=pre + 'dp2')
         with self._wlane():
             Bk.wgrad(dyz, st['a'], self.grad(pre + 'mlp.fc2.weight'), M, C, 4 * C, dt, dbias=self.grad(pre + 'mlp.fc2.bias'),
                      label=pre + 'wg2')
@@ -97,12 +101,17 @@ class MAPViTEngine(MAPEngine):
         gx = self.tmp('g', (M, C))
         Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], gx, M, C, 4 * C, dt, ldb=pad8(4 * C), label=pre + 'dg1')
         dx1 = self.tmp('dx1' + par, (M, C))
-        Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b')
+        dx1z = dx1
+        if dp1 is not None and self.fuse_dp:       # the DropPath-scaled copy of dx1 rides on the LayerNorm backward that writes dx1
+            dx1z = self.tmp('dx1z' + par, (M, C))
+            Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b', dx2=dx1z,
+                             scale2=dp1, rows_per_scale=Ntok)
+        else:
+            Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b')
         Bk.weight_unfold(G1, C, 4 * C, C, gb=gb1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'], cs=P[pre + 'norm2.weight'],
                          v=P[pre + 'norm2.bias'], dW=self.grad(pre + 'mlp.fc1.weight'), db=self.grad(pre + 'mlp.fc1.bias'),
                          d_cs=self.grad(pre + 'norm2.weight'), d_v=self.grad(pre + 'norm2.bias'), label=pre + 'unf1')
-        dx1z = dx1
-        if dp1 is not None:
+        if dp1 is not None and not self.fuse_dp:
             dx1z = self.tmp('dx1z' + par, (M, C))
             Bk.rowscale(dx1, dp1, dx1z, M * C, Ntok * C, dt, label=pre + 'dp1')
         with self._wlane():
@@ -121,7 +130,18 @@ class MAPViTEngine(MAPEngine):
                          d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'qkv.unf')
         gq = self.tmp('g', (M, C))
         Bk.gemm(dqkv, W[pre + 'attn.qkv.weight.T'], gq, M, C, 3 * C, dt, ldb=pad8(3 * C), label=pre + 'qkv.dg')
-        Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b')
+        ndp = self.dp_scale.get(next_pre + '#2') if next_pre is not None else None
+        if ndp is not None and self.fuse_dp:
+            # the consumer's transients alternate with the block parity exactly like this block's (par of the next block = 1 - par)
+            npar = str((self._bwd_seq + 1) & 1) if side else ''
+            ndyz = self.tmp('dyz' + npar, (M, C))
+            if side:           # that buffer was block t-1's: its asynchronous weight gradients must be done before it is rewritten
+                Bk.join_async(f'blk{self._bwd_seq - 1}')
+            Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b', dx2=ndyz,
+                             scale2=ndp, rows_per_scale=Ntok)
+            self._pre_dyz[next_pre] = ndyz
+        else:
+            Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b')
         if side:
             Bk.async_mark(f'blk{self._bwd_seq}')
 
@@ -209,9 +229,9 @@ class MAPViTEngine(MAPEngine):
         Bk.copy2d(dfm, Np * C, dxs[cur][1:], Ntok * C, B, Np * C, dt, label='feat.last.b')
         for i in range(depth - 1, -1, -1):
             nxt = (cur + 1) % 3
-            self._vit_block_bwd(f'blocks.{i}.', dxs[cur], dxs[nxt], M, C, Ntok)
-            cur = nxt
             j = self.tap_at.get(i) if i > 0 else 0           # the feature taken at this block's INPUT (after block i; 0 = the embedding)
+            self._vit_block_bwd(f'blocks.{i}.', dxs[cur], dxs[nxt], M, C, Ntok, next_pre=f'blocks.{i - 1}.' if i > 0 and j is None else None)
+            cur = nxt
             if j is not None:
                 Bk.copy2d(seeds[j], Np * C, dxs[cur][1:], Ntok * C, B, Np * C, dt, accumulate=True, label=f'feat.{j}.b')
             if i == depth // 2:

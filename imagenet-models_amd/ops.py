@@ -529,7 +529,13 @@ class Plan:
         self._add('ga_layernorm_fwd', (_ptr(x), _ptr(w), _ptr(b), _ptr(y), _ptr(mean), _ptr(rstd), rows, Cdim, eps, dtype),
                   label, keep=(x, w, b, y, mean, rstd))
 
-    def layernorm_bwd(self, g, x, mean, rstd, w, dres, dx, dw, db, rows, Cdim, x_is_normalized, dtype, label=None):
+    def layernorm_bwd(self, g, x, mean, rstd, w, dres, dx, dw, db, rows, Cdim, x_is_normalized, dtype, label=None, dx2=None,
+                      scale2=None, rows_per_scale=1):
+        if dx2 is not None:        # second output: the stored dx times a per-sample scale (the consumer's DropPath factor)
+            self._add('ga_layernorm_bwd_dp', (_ptr(g), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dres), _ptr(dx), _ptr(dw), _ptr(db),
+                                              rows, Cdim, int(x_is_normalized), _ptr(dx2), _ptr(scale2), rows_per_scale, dtype), label,
+                      keep=(g, x, mean, rstd, w, dres, dx, dw, db, dx2, scale2))
+            return
         self._add('ga_layernorm_bwd', (_ptr(g), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dres), _ptr(dx), _ptr(dw),
                                        _ptr(db), rows, Cdim, int(x_is_normalized), dtype), label,
                   keep=(g, x, mean, rstd, w, dres, dx, dw, db))

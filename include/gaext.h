@@ -216,6 +216,11 @@ int ga_layernorm_fwd(const void* x, const float* w, const float* b, void* y, flo
 int ga_layernorm_bwd(const void* g, const void* x, const float* mean, const float* rstd, const float* w,
                      const void* dres, void* dx, float* dw, float* db, int64_t rows, int C, int x_is_normalized,
                      int dtype, ga_stream_t stream);
+/* the same with a second output dx2[row] = (dx[row] as stored) * scale2[row / rows_per_scale]: the DropPath-scaled copy the next
+ * block of the backward chain would otherwise make in a pass of its own (timm DropPath in Block.forward: x + drop_path(f(x))) */
+int ga_layernorm_bwd_dp(const void* g, const void* x, const float* mean, const float* rstd, const float* w, const void* dres,
+                        void* dx, float* dw, float* db, int64_t rows, int C, int x_is_normalized, void* dx2, const float* scale2,
+                        int64_t rows_per_scale, int dtype, ga_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * BatchNorm2d, train mode = per-process batch statistics (ga_convnext.py:261,270,276,283,409,420).
