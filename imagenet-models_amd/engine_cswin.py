@@ -110,7 +110,7 @@ class CSWinEngine(GAEngine):
             st['mlp'] = self._gmlp_fwd(pre + 'mlp.', st['t'], M, C, mg, y, x1, dp2, HW)
         return y
 
-    def _cs_block_bwd(self, pre, dy, dx):
+    def _cs_block_bwd(self, pre, dy, dx, next_pre=None):
         """dy: gradient wrt the block output; writes dx (a different buffer) = gradient wrt the block input"""
         Bk, dt, B, P, W = self.bwd, self.dt, self.B, self.P, self.W
         st = self.blocks[pre]
@@ -129,9 +129,15 @@ class CSWinEngine(GAEngine):
             Bk.join_async(f'blk{self._bwd_seq - 2}')
         dyz = dy
         if dp2 is not None:
-            dyz = self.tmp('dyz' + par, (M, C))
-            Bk.rowscale(dy, dp2, dyz, M * C, HW * C, dt, label=pre + 'dp2')
+            dyz = self._pre_dyz.pop(pre, None)           # written by the LayerNorm backward of the block before (backward order)
+            if dyz is None:
+                dyz = self.tmp('dyz' + par, (M, C))
+                Bk.rowscale(dy, dp2, dyz, M * C, HW * C, dt, label=pre + 'dp2')
         dx1 = self.tmp('dx1' + par, (M, C))
+        dx1z = dx1
+        fuse1 = dp1 is not None and self.fuse_dp and mg == 1
+        if fuse1:
+            dx1z = self.tmp('dx1z' + par, (M, C))
         if mg == 1:
             with self._wlane():
                 Bk.wgrad(dyz, st['a'], self.grad(pre + 'mlp.fc2.weight'), M, C, 4 * C, dt, dbias=self.grad(pre + 'mlp.fc2.bias'),
@@ -145,7 +151,11 @@ class CSWinEngine(GAEngine):
                 Bk.wgrad(dh, st['xn2'], G1, M, 4 * C, C, dt, label=pre + 'wg1')
             gx = self.tmp('g', (M, C))
             Bk.gemm(dh, W[pre + 'mlp.fc1.weight.T'], gx, M, C, 4 * C, dt, ldb=pad8(4 * C), label=pre + 'dg1')
-            Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b')
+            if fuse1:       # the DropPath-scaled copy of dx1 rides on the LayerNorm backward that writes dx1
+                Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b', dx2=dx1z,
+                                 scale2=dp1, rows_per_scale=HW)
+            else:
+                Bk.layernorm_bwd(gx, st['xn2'], None, st['r2'], None, dy, dx1, None, None, M, C, True, dt, label=pre + 'ln2b')
             Bk.weight_unfold(G1, C, 4 * C, C, gb=gb1, W=P[pre + 'mlp.fc1.weight'], b=P[pre + 'mlp.fc1.bias'],
                              cs=P[pre + 'norm2.weight'], v=P[pre + 'norm2.bias'], dW=self.grad(pre + 'mlp.fc1.weight'),
                              db=self.grad(pre + 'mlp.fc1.bias'), d_cs=self.grad(pre + 'norm2.weight'),
@@ -156,8 +166,7 @@ class CSWinEngine(GAEngine):
             Bk.layernorm_bwd(dtk, st['x1'], st['m2'], st['r2'], P[pre + 'norm2.weight'], dy, dx1, self.grad(pre + 'norm2.weight'),
                              self.grad(pre + 'norm2.bias'), M, C, False, dt, label=pre + 'ln2b')
         # --- attention branch
-        dx1z = dx1
-        if dp1 is not None:
+        if dp1 is not None and not fuse1:
             dx1z = self.tmp('dx1z' + par, (M, C))
             Bk.rowscale(dx1, dp1, dx1z, M * C, HW * C, dt, label=pre + 'dp1')
         with self._wlane():
@@ -187,7 +196,17 @@ class CSWinEngine(GAEngine):
                          d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'qkv.unf')
         gq = self.tmp('g', (M, C))
         Bk.gemm(dqkv, W[pre + 'qkv.weight.T'], gq, M, C, 3 * C, dt, ldb=pad8(3 * C), label=pre + 'qkv.dg')
-        Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b')
+        ndp = self.dp_scale.get(next_pre + '#2') if next_pre is not None else None
+        if ndp is not None and self.fuse_dp:
+            npar = str((self._bwd_seq + 1) & 1) if side else ''
+            ndyz = self.tmp('dyz' + npar, (M, C))
+            if side:           # that buffer was block t-1's: its asynchronous weight gradients must be done before it is rewritten
+                Bk.join_async(f'blk{self._bwd_seq - 1}')
+            Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b', dx2=ndyz,
+                             scale2=ndp, rows_per_scale=HW)
+            self._pre_dyz[next_pre] = ndyz
+        else:
+            Bk.layernorm_bwd(gq, st['xn1'], None, st['r1'], None, dx1, dx, None, None, M, C, True, dt, label=pre + 'ln1b')
         if side:
             Bk.async_mark(f'blk{self._bwd_seq}')
 
@@ -422,7 +441,9 @@ class CSWinEngine(GAEngine):
                     Bk.affine_act(dy, None, None, d_taps[j], dy, Mi, d[si], False, dt, label=f'tap.add.{j}')
                 dx = pp[turn % 3]          # not this block's dy nor the previous block's (still read by its asynchronous wgrads)
                 turn += 1
-                self._cs_block_bwd(f'stage{si + 1}.{j}.', dy, dx)
+                # the next block of the chain takes dx unchanged as its dy unless a tap gradient is added in between
+                nxt = f'stage{si + 1}.{j - 1}.' if j > 0 and not (si == 2 and (j - 1) in d_taps) else None
+                self._cs_block_bwd(f'stage{si + 1}.{j}.', dy, dx, next_pre=nxt)
                 dy = dx
             if si > 0:
                 Hp = stages[si - 1][0].reso
