@@ -99,6 +99,9 @@ _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
     'ga_device_info': ([C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    'ga_set_knob': ([C.c_char_p, i32], i32),
+    'ga_unset_knob': ([C.c_char_p], i32),
+    'ga_config_string': ([C.c_char_p, C.c_size_t], i32),
     'ga_gemm': ([C.POINTER(GemmDesc), vp], i32),
     'ga_wgrad': ([C.POINTER(WgradDesc), vp], i32),
     'ga_weight_prep': ([C.POINTER(WprepDesc), vp], i32),
@@ -228,6 +231,43 @@ def last_error():
     buf = C.create_string_buffer(512)
     load().ga_last_error(buf, 512)
     return buf.value.decode(errors='replace')
+
+
+def config_string():
+    """library version + every tuning knob that is not at its default (include/gaext.h: ga_config_string)"""
+    buf = C.create_string_buffer(1024)
+    load().ga_config_string(buf, 1024)
+    s = buf.value.decode(errors='replace')
+    # the host-side scheduling switches the engines read from the environment when they are built (engine.py: lanes, chains)
+    host = sorted(k for k in os.environ if k.startswith(('GAEXT_', 'GA_FUSED_MLP')) and k != 'GAEXT_LIB')
+    known = {'GAEXT_ASYNC_WGRAD', 'GAEXT_FWD_SPLIT', 'GAEXT_PAR_BRANCH', 'GAEXT_FWD_SKEW', 'GAEXT_FUSE_DP', 'GAEXT_HEAD_STREAMS',
+             'GA_FUSED_MLP', 'GAEXT_SMALL_SINGLE', 'GAEXT_SYNC_DEBUG'}
+    for k in host:
+        if k in known:
+            s += f' host:{k}={os.environ[k]}'
+    if os.environ.get('GAEXT_LIB'):
+        s += f' lib={os.environ["GAEXT_LIB"]}'
+    return s
+
+
+class knobs:
+    """context manager: `with knobs(NT_DMA=2, NT_PP=0): ...` sets library tuning knobs (ga_set_knob) and restores the defaults
+    (ga_unset_knob) on exit -- the kernel-form switches the tests and A/B tools use; the environment is read once only"""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        lib = load()
+        for k, v in self.kv.items():
+            check(lib.ga_set_knob(k.encode(), int(v)), f'ga_set_knob({k})')
+        return self
+
+    def __exit__(self, *exc):
+        lib = load()
+        for k in self.kv:
+            lib.ga_unset_knob(k.encode())
+        return False
 
 
 def check(rc, what):

@@ -729,8 +729,7 @@ int check_desc(const ga_attn_desc* d, const char* what) {
 }
 
 bool use_mfma(const ga_attn_desc* d) {
-    const char* e = getenv("GAEXT_ATTN_MFMA");
-    return (!e || atoi(e)) && d->dtype == GA_BF16 && d->hd % 16 == 0 && d->hd <= 64 && d->ldq % 8 == 0 && d->ldo % 8 == 0 && aligned16(d->qkv) && aligned16(d->out);
+    return GA_KNOB("ATTN_MFMA", 1) && d->dtype == GA_BF16 && d->hd % 16 == 0 && d->hd <= 64 && d->ldq % 8 == 0 && d->ldo % 8 == 0 && aligned16(d->qkv) && aligned16(d->out);
 }
 
 }  // namespace
@@ -739,7 +738,7 @@ extern "C" int ga_attn_fwd(const ga_attn_desc* d, ga_stream_t stream) {
     if (int rc = check_desc(d, "ga_attn_fwd")) return rc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (use_mfma(d)) {
-        static const int qt_env = [] { const char* e = getenv("GAEXT_ATTN_QT"); return e ? atoi(e) : 0; }();
+        const int qt_env = GA_KNOB("ATTN_QT", 0);
         const int qt = qt_env ? qt_env : (d->N >= 128 ? 2 : 1);
         const int nblk = (d->N + BQ * qt - 1) / (BQ * qt), nwg = nblk * d->B * d->H;
         if (qt == 2) hipLaunchKernelGGL(attn_fwd_mfma<2>, dim3(nwg), dim3(256), 3 * TILE + 8192, s, *d, nblk, nwg);
@@ -779,12 +778,12 @@ extern "C" int ga_attn_bwd(const ga_attn_desc* d, const void* dout, void* dqkv, 
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(g256), dim3(256), 0, s, *d, dout, delta);
     }
     if (use_mfma(d) && aligned16(dout) && aligned16(dqkv)) {
-        static const int qt_env = [] { const char* e = getenv("GAEXT_ATTN_QT"); return e ? atoi(e) : 0; }();
+        const int qt_env = GA_KNOB("ATTN_QT", 0);
         const int qt = qt_env ? qt_env : (d->N >= 256 ? 2 : 1);      // (N = 197: 0.381 vs 0.393 ms per backward with 2)
         const int nblk1 = (d->N + BQ * qt - 1) / (BQ * qt), nwg1 = nblk1 * d->B * d->H;
         if (qt == 2) hipLaunchKernelGGL(attn_bwd_dq_mfma<2>, dim3(nwg1), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk1, nwg1);
         else hipLaunchKernelGGL(attn_bwd_dq_mfma<1>, dim3(nwg1), dim3(256), 4 * TILE + 8192, s, *d, dout, dqkv, delta, nblk1, nwg1);
-        static const int kt_env = [] { const char* e = getenv("GAEXT_ATTN_KT"); return e ? atoi(e) : 0; }();
+        const int kt_env = GA_KNOB("ATTN_KT", 0);
         const int kt = kt_env ? kt_env : (d->N >= 128 ? 2 : 1);
         const int nblk2 = (d->N + BQ * kt - 1) / (BQ * kt), nwg2 = nblk2 * d->B * d->H;
         if (kt == 2) hipLaunchKernelGGL(attn_bwd_dkv_mfma<2>, dim3(nwg2), dim3(256), 4 * TILE + 8192 + 512, s, *d, dout, dqkv, delta, nblk2, nwg2);

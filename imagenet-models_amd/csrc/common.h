@@ -18,6 +18,16 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 void ga_set_error(const char* fmt, ...);
 int ga_check_launch(const char* what);
 
+// tuning knobs (runtime.hip): GAEXT_<NAME> from the environment, read ONCE when the knob is first looked up, or set through
+// ga_set_knob(); dispatch code keeps the slot pointer in a function-local static, so no launch ever calls getenv
+#include <atomic>
+const std::atomic<int>* ga_knob_slot(const char* name, int dflt);
+#define GA_KNOB(NAME, DFLT)                                                       \
+    ([]() -> int {                                                                \
+        static const std::atomic<int>* slot_ = ga_knob_slot(NAME, DFLT);          \
+        return slot_->load(std::memory_order_relaxed);                            \
+    }())
+
 #define GA_REQUIRE(cond, ...)                 \
     do {                                      \
         if (!(cond)) {                        \

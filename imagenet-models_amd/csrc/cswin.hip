@@ -935,8 +935,7 @@ int check_desc(const ga_cswin_attn_desc* d, const char* what) {
 }
 
 bool use_mfma(const ga_cswin_attn_desc* d) {
-    const char* e = getenv("GAEXT_CSWIN_MFMA");           // 0: generic form everywhere (read per call: tests switch it)
-    const int force = e ? atoi(e) : 1;
+    const int force = GA_KNOB("CSWIN_MFMA", 1);            // 0: generic form everywhere (tests switch it through ga_set_knob)
     if (!force || d->dtype != GA_BF16 || d->C / d->heads != 32) return false;
     for (int i = 0; i < d->nbranch; ++i)
         if (d->Hs[i] * d->Ws[i] > 112) return false;

@@ -912,8 +912,7 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
             const bool big = H % 14 == 0 && W % 14 == 0;
             const long ntiles = big ? (long)B * (H / 14) * (W / 14) : (long)B * cdiv(H, 7) * cdiv(W, 7);
             const int gx = (int)std::min<long>(ntiles, std::max(1, (big ? 2 : 4) * num_cus() / sl));
-            const char* e = getenv("GAEXT_DW_MFMA");        // 0: never, 1: heuristic (default), 2: every 14 x 14-tiled launch
-            const int use_mfma = e ? atoi(e) : 1;           // read per call so that a test can switch it
+            const int use_mfma = GA_KNOB("DW_MFMA", 1);     // 0: never, 1: heuristic (default), 2: every 14 x 14-tiled launch
             // the MFMA form pays a long prologue (Toeplitz fragments) per workgroup: ahead of the dot2 form only when
             // a workgroup walks many tiles (56 x 56 maps, also as half batches: 0.169 vs 0.192 ms; 28 x 28 and 14 x 14:
             // 5-10 % behind)
@@ -922,7 +921,7 @@ int launch_dwconv(const void* x, const float* w49, const float* bias, const void
                 const int slm = cdiv(C, DWM::CS);
                 // grid.x a multiple of 8: workgroup (x, y) then sits on XCD x % 8 for every slice y, so the 32-channel slices of
                 // one tile (64 of the 128 bytes of every line each) share one L2 instead of fetching the line once per slice
-                static const int xcd8 = [] { const char* e8 = getenv("GAEXT_DW_XCD8"); return e8 ? atoi(e8) : 1; }();
+                const int xcd8 = GA_KNOB("DW_XCD8", 1);
                 int gxm = (int)std::min<long>(ntiles, std::max(1, num_cus() / slm));
                 if (xcd8 && gxm >= 16) gxm = gxm / 8 * 8;
                 hipLaunchKernelGGL(dwconv7_mfma_kernel, dim3(gxm, slm), dim3(DWM::NT), DWM::LDS, s, (const bf16_t*)x, w49, bias,

@@ -785,7 +785,13 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
 constexpr int kPPThreads = 512, kPPHalf = 16384, kPPBuf = 4 * kPPHalf, kPPSmem = 2 * kPPBuf + 8 * 4096;
 
 template <int EPI>
-__global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_desc d, const int dbg) {
+__global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_desc d, const int dbg_arg) {
+#ifdef GAEXT_DEBUG
+    const int dbg = dbg_arg;            // timing experiments (results deliberately wrong): -DGAEXT_DEBUG builds only
+#else
+    constexpr int dbg = 0;              // release build: every `dbg` branch below is dead code and is not emitted
+    (void)dbg_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1470,11 +1476,7 @@ __global__ __launch_bounds__(256) void tn2_reduce_kernel(const float* __restrict
 // the wide form needs whole 32-row stages, plain bf16 operands, and an output that is accumulated into (so that it
 // may choose its own row split); it pays once the reduction is long enough to amortise the 256 x 256 tile
 bool tn2_eligible(const ga_wgrad_desc* d) {
-    static const int force = [] {
-        const char* e = getenv("GAEXT_TN2");      // 0 disables, for experiments
-        return e ? atoi(e) : 1;
-    }();
-    return force && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 32 == 0 &&
+    return GA_KNOB("TN2", 1) && d->dtype == GA_BF16 && d->x_kind == GA_A_PLAIN && d->x_act == GA_ACT_NONE && d->M % 32 == 0 &&
            d->M >= 8192 && (d->accumulate || d->split_m > 1) && (long)d->M * d->ldy < (1L << 31) && (long)d->M * d->ldx < (1L << 31);   // 32-bit byte offsets
 }
 
@@ -1482,7 +1484,7 @@ bool tn2_eligible(const ga_wgrad_desc* d) {
 size_t tn2_plan(const ga_wgrad_desc* d, int* split_out) {
     const int tiles = cdiv(d->N, 256) * cdiv(d->K, 256) * d->batch;
     const int stages = d->M / 32;
-    static const int wg_budget = [] { const char* e = getenv("GAEXT_TN2_WGS"); return e ? atoi(e) : 0; }();
+    const int wg_budget = GA_KNOB("TN2_WGS", 0);
     // 3/4 of the CUs: in the train step these launches share the chip with the dgrad chain (asynchronous lane), and
     // fewer row splits mean fewer partial tiles to write and reduce (same-box A/B: 192 vs 256 workgroups -0.13 ms/step)
     const int cus = wg_budget > 0 ? wg_budget : num_cus() * 3 / 4;
@@ -1490,7 +1492,7 @@ size_t tn2_plan(const ga_wgrad_desc* d, int* split_out) {
     split = cdiv(stages, cdiv(stages, split));                                // no empty row range
     *split_out = split;
     const long nk = (long)d->N * d->K;
-    static const long nk_min = [] { const char* e = getenv("GAEXT_TN2_PART_MIN"); return e ? atol(e) : 65536L; }();      // 256 x 256 outputs (CSWin proj) included: -0.2 ms/step there, neutral elsewhere
+    const long nk_min = GA_KNOB("TN2_PART_MIN", 65536);      // 256 x 256 outputs (CSWin proj) included: -0.2 ms/step there, neutral elsewhere
     return (split > 1 && nk >= nk_min) ? (size_t)d->batch * split * nk * sizeof(float) : 0;   // small outputs: atomics are cheaper
 }
 
@@ -1532,17 +1534,22 @@ void launch_nt_pp(const ga_gemm_desc* d, hipStream_t s) {
     const int tiles = cdiv(d->M, 256) * cdiv(d->N, 256);
     const int cap = std::max(8, (num_cus() / d->batch) / 8 * 8);
     dim3 grid(std::min(tiles, cap), 1, d->batch), block(kPPThreads);
-    const char* e = getenv("GAEXT_PP_DBG");
-    hipLaunchKernelGGL(kern, grid, block, kPPSmem, s, *d, e ? atoi(e) : 0);
+#ifdef GAEXT_DEBUG
+    const int dbg = GA_KNOB("PP_DBG", 0);         // timing experiments of the body (RESULTS DELIBERATELY WRONG): debug builds only
+#else
+    const int dbg = 0;
+#endif
+    hipLaunchKernelGGL(kern, grid, block, kPPSmem, s, *d, dbg);
 }
 
 // 8-wave ping-pong form: GAEXT_NT_PP = bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); unset: plain / fc1 / fc2, for
 // launches whose K loop is long enough to carry the un-overlapped epilogue (K >= GAEXT_NT_PP_MINK, default 512) and whose
 // last column tile is not mostly empty
 bool want_pp(const ga_gemm_desc* d, int epi) {
-    const char* e = getenv("GAEXT_NT_PP");
-    const int mask = e ? atoi(e) : 7;       // (dgrad2: its stored-GELU' operand is read inside the un-overlapped epilogue: measured slower)
-    static const int mink = [] { const char* m = getenv("GAEXT_NT_PP_MINK"); return m ? atoi(m) : 512; }();
+    const int pp = GA_KNOB("NT_PP", -1);    // -1: heuristic
+    const bool e = pp >= 0;
+    const int mask = e ? pp : 7;            // (dgrad2: its stored-GELU' operand is read inside the un-overlapped epilogue: measured slower)
+    const int mink = GA_KNOB("NT_PP_MINK", 512);
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
     if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < (e ? 256 : mink) || d->lda % 8 != 0 || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
     if ((long)d->M * d->lda >= (1L << 30) || (long)d->N * d->ldb >= (1L << 30) || d->lda < 64 || d->ldb < 64) return false;   // 32-bit byte offsets
@@ -1573,10 +1580,7 @@ int classify_epilogue(const ga_gemm_desc* d) {
 // tile reads the weight slab once per 256 rows.  Measured on MI355X (tools/gemm_bench.py): dgrad2 1.35-1.45x,
 // fc2 1.1-1.2x; the plain / fc1 epilogues (120 VGPRs, 4 workgroups per CU) are 5-15 % SLOWER with it.
 bool want_big_tile(const ga_gemm_desc* d, int epi) {
-    static const int force = [] {
-        const char* e = getenv("GAEXT_NT_BIG");   // 0 / 1 override for experiments; unset = heuristic
-        return e ? atoi(e) : -1;
-    }();
+    const int force = GA_KNOB("NT_BIG", -1);      // 0 / 1 override for experiments; -1 = heuristic
     if (d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || (epi != EPI_FC2 && epi != EPI_DG2)) return false;
     if (force >= 0) return force != 0;
     return (long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch >= 2L * num_cus();
@@ -1587,8 +1591,7 @@ bool want_big_tile(const ga_gemm_desc* d, int epi) {
 bool dma_offsets_fit(const ga_gemm_desc* d) { return (long)d->M * d->lda < (1L << 30) && (long)d->N * d->ldb < (1L << 30); }
 
 bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
-    const char* e = getenv("GAEXT_NT_DMA");       // 0 off, 1 heuristic (default), 2 every eligible launch; read per call
-    const int mode = e ? atoi(e) : 1;             // so that a test can switch it
+    const int mode = GA_KNOB("NT_DMA", 1);        // 0 off, 1 heuristic (default), 2 every eligible launch
     if (!mode || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || (tnw != 4 && tnw != 3) || !dma_offsets_fit(d)) return false;
     if ((long)cdiv(d->M, 256) * cdiv(d->N, 32 * tnw) * d->batch < num_cus()) return false;
     // measured (tools/gemm_bench.py): ahead only for the fc2 epilogue with a long reduction (K >= 1024, +8..20 %);
@@ -1598,22 +1601,21 @@ bool want_dma(const ga_gemm_desc* d, int epi, int tnw) {
 
 // 128 x 128 tile, 4 waves, LDS-DMA into a 2-slot ring, 80 KiB: two workgroups per CU without the ds_write staging pass
 bool want_dma2(const ga_gemm_desc* d, int epi) {
-    const char* e = getenv("GAEXT_NT_DMA2");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
+    // NT_DMA2: bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2)
     // unset: fc1 and dgrad2 (stage-2 shapes, same box, after the DMA went through buffer resources: fc1 0.126 -> 0.119 ms,
     // dgrad2 0.137 -> 0.118; fc2 / dgrad1 are 3-5 % slower with it and keep the register-staged form)
-    const int mask = e ? atoi(e) : 10;
+    const int mask = GA_KNOB("NT_DMA2", 10);
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !dma_offsets_fit(d)) return false;
-    const char* k = getenv("GAEXT_NT_DMA2_MINK");
-    if (d->K < (k ? atoi(k) : 256)) return false;
+    if (d->K < GA_KNOB("NT_DMA2_MINK", 256)) return false;
     return (mask >> epi) & 1;
 }
 
 // 256 x 256 tile, 8 waves (64 x 128 each), LDS-DMA into a 2-slot ring: wide-N launches
 bool want_t256(const ga_gemm_desc* d, int epi) {
-    const char* e = getenv("GAEXT_NT_T256");      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); read per call
+    const int t256 = GA_KNOB("NT_T256", -1);      // bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); -1: heuristic
     // unset: every epilogue, but only for the very tall launches (M >= 65536: the ViT trunk's 73,856 token rows, -4.8 % on the
     // MAP-ViT-B/384 step); on the ConvNeXt / CSWin stage-2/3 shapes (M = 50,176) the form measured -12 .. +5 % and stays off
-    const int mask = e ? atoi(e) : ((d->M >= 65536 && d->N >= 768) ? 15 : 0);      // (N >= 768: the CSWin stem's N = 256 launches lose 2 %)
+    const int mask = t256 >= 0 ? t256 : ((d->M >= 65536 && d->N >= 768) ? 15 : 0);      // (N >= 768: the CSWin stem's N = 256 launches lose 2 %)
     if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !dma_offsets_fit(d)) return false;
     if (d->N % 256 != 0 || d->K < 256) return false;
     if ((long)cdiv(d->M, 256) * (d->N / 256) * d->batch < num_cus()) return false;

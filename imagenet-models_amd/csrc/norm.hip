@@ -16,8 +16,7 @@ int pick_group(int C, int epc) {
         // of each row, i.e. HALF of every 128-byte line, and the streaming (non-temporal) loads do not keep the line
         // for the instruction that wants the other half: FETCH_SIZE showed 1.73x the algorithmic bytes.  16 lanes per
         // row (12 active) make every instruction cover whole rows: 0.053 vs 0.072 ms forward, 0.132 vs 0.145 backward
-        static const int g12 = [] { const char* e = getenv("GAEXT_LN_G12"); return e ? atoi(e) : 16; }();
-        return g12;
+        return GA_KNOB("LN_G12", 16);
     }
     for (int g = 4; g <= 64; g <<= 1)
         if (kMaxChunks * g >= nch) return g;

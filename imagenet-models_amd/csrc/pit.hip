@@ -389,8 +389,7 @@ __global__ __launch_bounds__(256) void rows_bcast_kernel(const T* __restrict__ s
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 bool fast_path() {       // GAEXT_DWPOOL_SIMPLE=1: the plain any-multiplier kernels (diagnostics / tests)
-    const char* e = getenv("GAEXT_DWPOOL_SIMPLE");
-    return !(e && atoi(e));
+    return !GA_KNOB("DWPOOL_SIMPLE", 0);
 }
 int grid_for(long n) { return (int)std::max<long>(1, std::min<long>(8192, (n + 255) / 256)); }
 

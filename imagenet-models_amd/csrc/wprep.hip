@@ -581,7 +581,7 @@ extern "C" int ga_weight_prep_batch(const ga_wprep_desc* jobs_dev, int n, ga_str
     GA_REQUIRE(jobs_dev && n > 0, "ga_weight_prep_batch: bad args");
     // grid.x workgroups walk one job with a grid stride: the few big jobs of a batch (fc1 / fc2 of stage 3: 2.4 M elements)
     // set its duration, so give every job enough workgroups to fill the chip on its own
-    static const int gx = [] { const char* e = getenv("GAEXT_BATCH_GX"); return e ? atoi(e) : 256; }();
+    const int gx = std::max(1, GA_KNOB("BATCH_GX", 256));
     hipLaunchKernelGGL(wprep_batch_kernel, dim3(gx, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
     return ga_check_launch("ga_weight_prep_batch");
 }
@@ -594,7 +594,7 @@ extern "C" int ga_small_batch(const ga_small_desc* jobs_dev, int n, ga_stream_t 
 
 extern "C" int ga_weight_unfold_batch(const ga_wunfold_desc* jobs_dev, int n, ga_stream_t stream) {
     GA_REQUIRE(jobs_dev && n > 0, "ga_weight_unfold_batch: bad args");
-    static const int gx = [] { const char* e = getenv("GAEXT_BATCH_GX"); return e ? atoi(e) : 256; }();
+    const int gx = std::max(1, GA_KNOB("BATCH_GX", 256));
     hipLaunchKernelGGL(unfold_batch_kernel, dim3(gx, n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs_dev);
     return ga_check_launch("ga_weight_unfold_batch");
 }

@@ -124,10 +124,6 @@ class MAPPiTEngine(MAPViTEngine):
                 self._vit_block_bwd(f'transformers.{s}.blocks.{j}.', dy, dx, M, C, Ntok,
                                     next_pre=f'transformers.{s}.blocks.{j - 1}.' if j > 0 else None)      # (stage seams add a feature seed)
                 dy = dx
-            if s == 2:
-                Bk.mark('stage3')
-            if s == 1:
-                Bk.mark('stage2')
             if s > 0:
                 # conv_head_pooling backward; the stage below's output also fed MultiScale: its seed is added
                 _, xprev, hwp, Cp = self.stage_io[s - 1]
@@ -139,6 +135,12 @@ class MAPPiTEngine(MAPViTEngine):
                 Bk.dwpool_bwd_data(dy, P[f'pools.{s - 1}.conv.weight'], dprev, B, hwp, hwp, Cp, mult, dt, label=f'pools.{s - 1}.dg')
                 Bk.copy2d(seeds[s], hwp * hwp * Cp, dprev, hwp * hwp * Cp, B, hwp * hwp * Cp, dt, accumulate=True, label=f'feat.{s}.b')
                 dy = dprev
+                # transformers.s and pools.(s-1) are final only after the pooling conv's weight gradient (asynchronous lane) and the
+                # deferred unfold jobs of the stage's blocks: join + flush BEFORE the mark the gradient buckets key on
+                if self.async_wgrad:
+                    Bk.join_async()
+                Bk.flush(f'stage{s + 1}.')
+                Bk.mark(f'stage{s + 1}')
         # dy: gradient wrt x0 from stage 0; x0 is also feature 0
         Bk.copy2d(seeds[0], w0 * w0 * dims[0], dy, w0 * w0 * dims[0], B, w0 * w0 * dims[0], dt, accumulate=True, label='feat.0.b')
         dposT = self.tmp('dposT', (w0 * w0, dims[0]), torch.float32)

@@ -235,6 +235,11 @@ class MAPViTEngine(MAPEngine):
             if j is not None:
                 Bk.copy2d(seeds[j], Np * C, dxs[cur][1:], Ntok * C, B, Np * C, dt, accumulate=True, label=f'feat.{j}.b')
             if i == depth // 2:
+                # every gradient of blocks[depth // 2 :] and of the final norm must be FINAL at the mark (TrainStep all-reduces
+                # the group's slice from here on): wait for the weight-gradient lane, emit the deferred unfold jobs
+                if self.async_wgrad:
+                    Bk.join_async()
+                Bk.flush('stage2.')
                 Bk.mark('stage2')
         # embedding: dtok, d(cls_token), d(pos_embed); patch projection weight gradient
         dtok = self.tmp('dtok', (Mp, C))

@@ -65,6 +65,9 @@ class Mixup:
         """x: (B, C, H, W) fp32 on the device, target: (B,) int64 -> (mixed x (a new tensor), dense target (B, num_classes))"""
         if not x.is_cuda:
             raise RuntimeError('Mixup runs on the HIP kernels only (no CPU fallback)')
+        if not x.is_floating_point():
+            raise TypeError(f'Mixup expects a normalised floating-point batch, got {x.dtype}: normalise uint8 input first '
+                            '(TrainStep does; engine._normalize_u8)')
         B, _, H, W = x.shape
         assert B % 2 == 0, 'Batch size should be even when using this'
         lam, use_cutmix = self._params_per_batch()

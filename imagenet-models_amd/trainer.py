@@ -125,7 +125,9 @@ class TrainStep:
         # the reference divides the loss by grad_accumulation (train.py:750); DDP averages over ranks
         scale = 1.0 / (self.accum * self.world)
         if self.mixup_fn is not None:
-            x, target = self.mixup_fn(x, target)
+            # a uint8 batch (PrefetchLoader layout) is normalised on the device FIRST: Mixup blends normalised pixels, and a
+            # float tensor coming back from it would make the engine skip the normalisation
+            x, target = self.mixup_fn(eng._normalize_u8(x), target)
         loss = eng.forward_loss(x, target, self.lam, self.kind, self.smoothing, scale, self.bce_threshold)
         bwd = eng.bwd
         if self.world > 1 and last_micro:

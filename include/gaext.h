@@ -56,6 +56,17 @@ int ga_last_error(char* buf, size_t n);
 /* number of compute units / LDS per CU etc. of the current device (used for grid sizing); 0 on success */
 int ga_device_info(int* num_cu, int* lds_bytes, int* wave_size);
 
+/* Tuning knobs (kernel-form selection; no reference counterpart -- the reference delegates kernel choice to cuDNN / cuBLAS
+ * heuristics behind torch.backends.cudnn.benchmark, GA/train.py:400).  Each knob NAME takes its value from the environment
+ * variable GAEXT_<NAME> once, when the dispatch code first asks for it, or from ga_set_knob(); no launch ever reads the
+ * environment.  ga_unset_knob() returns a knob to its built-in default.  ga_config_string() writes "libgaext <version> gfx950"
+ * followed by every knob that is NOT at its default as " NAME=value(env|api)" (NUL-terminated, truncated to n) and returns
+ * the untruncated length -- a bench / parity record shows what actually ran.  Result-changing debug switches do not exist in a
+ * release build (they need -DGAEXT_DEBUG, which ga_config_string reports as DEBUG-BUILD). */
+int ga_set_knob(const char* name, int value);
+int ga_unset_knob(const char* name);
+int ga_config_string(char* buf, size_t n);
+
 /* ------------------------------------------------------------------------------------------------------------
  * ga_gemm:  C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] )          (both operands K-contiguous)
  * replaces: nn.Linear / 1x1, 2x2-s2, 4x4-s4 and 3x3 nn.Conv2d forward AND their data-gradients

@@ -25,8 +25,9 @@ def _case(dt, B, N, H, hd, tol, force_simple=False):
     ref = (att @ x[2]).transpose(1, 2).reshape(B * N, C)
     ref.backward(do.float())
     dref = x.grad.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * C)
+    from imagenet_models_amd import _lib
     if force_simple:
-        os.environ['GAEXT_ATTN_MFMA'] = '0'
+        _lib.load().ga_set_knob(b'ATTN_MFMA', 0)
     try:
         out = torch.empty(B * N, C, dtype=dt, device='cuda')
         lse = torch.empty(B, H, N, device='cuda')
@@ -38,7 +39,7 @@ def _case(dt, B, N, H, hd, tol, force_simple=False):
         p.attn_bwd(d, do.cuda(), dqkv, ws)
         torch.cuda.synchronize()
     finally:
-        os.environ.pop('GAEXT_ATTN_MFMA', None)
+        _lib.load().ga_unset_knob(b'ATTN_MFMA')
 
     def err(a, b):
         return float((a.float().cpu() - b).abs().max() / (b.abs().max() + 1e-12))

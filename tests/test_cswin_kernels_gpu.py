@@ -63,7 +63,8 @@ def _attn_case(dt, B, reso, C, heads, stripes, seed, force_simple=False):
     dqkv_ref = q3.grad.permute(1, 2, 0, 3).reshape(B * L, 3 * C)
     # ---- GPU
     if force_simple:
-        os.environ['GAEXT_CSWIN_MFMA'] = '0'
+        from imagenet_models_amd import _lib
+        _lib.load().ga_set_knob(b'CSWIN_MFMA', 0)
     out = torch.empty(B * L, C, dtype=dt, device='cuda')
     dqkv = torch.zeros(B * L, 3 * C, dtype=dt, device='cuda')
     lwg = [w.cuda() for w in lw]
@@ -117,7 +118,8 @@ def test_stripe_attention_generic_form_bf16_hd32():
     try:
         _attn_case(torch.bfloat16, 2, 14, 64, 2, [(14, 7), (7, 14)], seed=12, force_simple=True)
     finally:
-        os.environ.pop('GAEXT_CSWIN_MFMA', None)
+        from imagenet_models_amd import _lib
+        _lib.load().ga_unset_knob(b'CSWIN_MFMA')
 
 
 @pytest.mark.parametrize('name', ['lepe_v', 'lepe_h', 'lepe_full', 'lepe_s1', 'lepe_s2h'])

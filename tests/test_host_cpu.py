@@ -25,6 +25,28 @@ def test_library_exports_every_declared_symbol():
     assert lib.ga_version() >= 100
 
 
+def test_tuning_knobs_are_a_table_not_the_environment():
+    """include/gaext.h ga_set_knob / ga_unset_knob / ga_config_string: no launch reads the environment; a non-default knob shows
+    up in the configuration string (what a bench or parity record prints); result-changing debug switches are compiled out"""
+    import subprocess
+    from imagenet_models_amd import _lib
+    lib = _lib.load()
+    base = _lib.config_string()
+    assert base.startswith('libgaext ') and 'gfx950' in base and 'DEBUG-BUILD' not in base
+    assert 'NT_DMA' not in base
+    with _lib.knobs(NT_DMA=2, TN2=0):
+        s = _lib.config_string()
+        assert 'NT_DMA=2(api)' in s and 'TN2=0(api)' in s, s
+    assert _lib.config_string() == base
+    assert lib.ga_set_knob(b'', 1) != 0 and lib.ga_set_knob(b'X' * 40, 1) != 0
+    # getenv appears in the runtime's knob table only; the debug knob of the ping-pong GEMM body is not in a release build
+    for f in os.listdir(os.path.join(ROOT, 'imagenet-models_amd', 'csrc')):
+        if f.endswith('.hip') and f != 'runtime.hip':
+            assert 'getenv' not in open(os.path.join(ROOT, 'imagenet-models_amd', 'csrc', f)).read(), f
+    strs = subprocess.run(['strings', _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert 'PP_DBG' not in strs
+
+
 def test_library_never_allocates_device_memory():
     """include/gaext.h: every pointer is caller-owned; the two reducing entry points take a caller workspace"""
     import subprocess

@@ -200,21 +200,18 @@ def test_gemm_stem(dt):
 @pytest.mark.parametrize('form', ['dma256', 'dma128', 't256', 'pp'])
 @pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384), (66000, 512, 328),
                                    (33000, 1536, 768), (40100, 264, 520), (12500, 3072, 768), (50200, 384, 1536)])
-def test_gemm_lds_dma_form_bf16(shape, form, monkeypatch):
+def test_gemm_lds_dma_form_bf16(shape, form, knobs):
     """large-M bf16 launches take the 256-row LDS-DMA form (ragged M, ragged K slab, 96- and 128-wide column tiles):
     plain + column sums, fc1 (GELU and GELU' outputs), fc2 (row scale + residual), dgrad2 (x stored GELU' + sums)"""
     ops = _imp()
     if form == 'dma256':
-        monkeypatch.setenv('GAEXT_NT_DMA', '2')      # every eligible launch, not only the shapes the heuristic picks
+        knobs(NT_DMA=2)      # every eligible launch, not only the shapes the heuristic picks
     elif form == 't256':                             # 256 x 256 tile, 8 waves (N % 256 == 0 and K >= 256 only)
-        monkeypatch.setenv('GAEXT_NT_DMA', '0')
-        monkeypatch.setenv('GAEXT_NT_T256', '15')
+        knobs(NT_DMA=0, NT_T256=15)
     elif form == 'pp':                               # 8-wave ping-pong form (K >= 256)
-        monkeypatch.setenv('GAEXT_NT_PP', '15')
+        knobs(NT_PP=15)
     else:                                            # 128 x 128 tile, 4 waves, 2-slot ring, two workgroups per CU
-        monkeypatch.setenv('GAEXT_NT_DMA', '0')
-        monkeypatch.setenv('GAEXT_NT_DMA2', '15')
-        monkeypatch.setenv('GAEXT_NT_DMA2_MINK', '8')
+        knobs(NT_DMA=0, NT_DMA2=15, NT_DMA2_MINK=8)
     dt = torch.bfloat16
     M, N, K = shape
     g = gen(5)
@@ -391,10 +388,10 @@ def test_weight_prep_fold_unfold(dt):
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('geom', [(2, 14, 14, 96), (1, 28, 28, 72), (3, 7, 7, 128), (2, 10, 9, 16), (1, 56, 56, 32),
                                   (2, 28, 28, 40, 'mfma')])
-def test_dwconv7(dt, geom, monkeypatch):
+def test_dwconv7(dt, geom, knobs):
     ops = _imp()
     if len(geom) == 5:     # force the matrix-core (Toeplitz) form of the bf16 forward / backward-data kernel
-        monkeypatch.setenv('GAEXT_DW_MFMA', '2')
+        knobs(DW_MFMA=2)
         geom = geom[:4]
     Bn, H, W, Cc = geom
     g = gen(11)

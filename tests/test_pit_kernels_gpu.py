@@ -53,9 +53,9 @@ def test_pos_add(dt, tol):
 @pytest.mark.parametrize('dt,tol', [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize('simple', [0, 1])
 @pytest.mark.parametrize('B,H,Cin,mult', [(2, 7, 48, 2), (2, 27, 144, 2), (1, 14, 288, 2), (3, 4, 96, 1), (2, 5, 8, 3), (70, 14, 16, 2)])
-def test_dwpool(dt, tol, B, H, Cin, mult, simple, monkeypatch):
+def test_dwpool(dt, tol, B, H, Cin, mult, simple, knobs):
     """simple = 1: the any-multiplier kernels; 0: the LDS-weight / wave-per-chunk forms multipliers 1 and 2 take"""
-    monkeypatch.setenv('GAEXT_DWPOOL_SIMPLE', str(simple))
+    knobs(DWPOOL_SIMPLE=simple)
     ops = _ops()
     g = torch.Generator().manual_seed(H + Cin)
     Co, Ho = Cin * mult, (H - 1) // 2 + 1

@@ -159,10 +159,16 @@ def main():
         raise SystemExit('train.py: only --synthetic data is shipped (no dataset / network in this environment)')
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', str(args.local_rank))) % max(1, torch.cuda.device_count())
+    local = int(os.environ.get('LOCAL_RANK', str(args.local_rank)))
+    backend = os.environ.get('GA_DIST_BACKEND', 'nccl')          # gloo: rehearsal with ranks sharing a device
+    ndev = max(1, torch.cuda.device_count())
+    if local >= ndev:
+        if world > 1 and backend == 'nccl':
+            raise SystemExit(f'train.py: LOCAL_RANK {local} but only {ndev} GPU(s) are visible: RCCL needs one device per rank '
+                             '(GA_DIST_BACKEND=gloo rehearses several ranks on one device)')
+        local %= ndev
     torch.cuda.set_device(local)
     if world > 1:
-        backend = os.environ.get('GA_DIST_BACKEND', 'nccl')      # gloo: rehearsal with ranks sharing a device
         if backend == 'nccl':
             dist.init_process_group('nccl', init_method='env://', device_id=torch.device('cuda', local))
         else:
