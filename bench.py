@@ -303,7 +303,7 @@ def main():
                                     f'batch {a.batch}/GPU, drop_path 0.2, synthetic 3x{img}x{img}',
                            global_batch=a.batch * world, parallelism=f'dp{world}', dist_backend=backend,
                            allreduce_buckets=len(step.buckets), gflop_per_img=gflop),
-               loss=round(loss_val, 4))
+               loss=round(loss_val, 4), library=A._lib.config_string())
 
     if rank == 0 and not a.no_kernel_times:
         eng = step.eng
