@@ -1098,6 +1098,415 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
 }
 
 // ================================================================================================
+// NT kernel, 3-slot ring form ("r3", round 3; bf16, plain operands, one of the compile-time epilogues).
+//
+// Why another body: on the K = 192 .. 768 launches of the ConvNeXt / CSWin trunks (M = 12,544 .. 200,704 token rows) the
+// 8-wave forms run ONE workgroup per CU, so a tile's epilogue (bias / GELU + GELU' / x stored GELU' / + shortcut, 128 values
+// per lane) is paid un-overlapped after a K loop of only 3 .. 12 slabs, and the 4-wave 128 x 128 LDS-DMA form reads 0.5
+// fragments per MFMA with one slab in flight.  This form is built for TWO INDEPENDENT workgroups per CU:
+//   * 256 x 128 output tile per 256-thread workgroup, 4 waves as 2 (m) x 2 (n), 128 x 64 per wave (32 accumulator tiles =
+//     128 VGPRs; 12 fragment reads per 32 MFMAs), exactly 80 KiB of LDS -> two workgroups per CU whose K loops and epilogues
+//     drift apart: one's epilogue (VALU, stores) runs under the other's MFMAs on the same SIMDs;
+//   * K stages of 32 (64-byte rows): a stage = A 256 rows + B 128 rows = 24 KiB, ring of THREE stages, filled by LDS-DMA
+//     (buffer_load ... lds, 6 pieces of 1 KiB per wave and stage); two stages are in flight while one is multiplied, ONE
+//     barrier per stage, counted s_waitcnt vmcnt(6).  The stage stream runs across the workgroup's output tiles, so the
+//     first two stages of the next tile land during the epilogue.  Every stage top issues exactly 6 pieces -- beyond the end
+//     of the stream they carry out-of-range offsets (zeros into a free slot) -- so the counted wait is exact everywhere;
+//   * 64-byte rows: lane l of a fragment read takes row l & 15, 16-byte chunk l >> 4; chunk c of row r sits at
+//     c ^ f(r >> 2), f = (0, 3, 2, 1): conflict-free for the four 16-lane groups ds_read_b128 is served in.  The DMA writes
+//     LDS lane-linearly, so the permutation is applied to the SOURCE chunk each lane fetches;
+//   * epilogue per wave, no workgroup barrier: 8 rows x 64 columns at a time through a private 2 KiB fp32 staging piece
+//     (XOR-swizzled) -> 8 consecutive columns per lane, 16-byte stores of whole 128-byte row segments.  The epilogue operands
+//     (bias; stored GELU' of dgrad2 / shortcut of fc2, 16 x 16 B per lane) are requested by asm buffer loads at the top of the
+//     tile's LAST stage and right after its MFMAs; one s_waitcnt vmcnt(0) before the first staging piece retires them
+//     together with the two stages in flight, which is why the first two stages of a tile need no wait of their own and the
+//     epilogue's stores are never waited for before the third stage.
+// ================================================================================================
+constexpr int kR3Threads = 256, kR3Slot = (256 + 128) * 64, kR3Stage = 2048, kR3Smem = 3 * kR3Slot + 4 * kR3Stage;   // 81,920 B
+static_assert(kR3Smem == 81920, "two workgroups per CU need exactly 80 KiB each");
+
+__device__ __forceinline__ u32x4_t r3_bload16(u32x4_s rs, unsigned voff) {        // read-once operand: streaming
+    u32x4_t v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+__device__ __forceinline__ u32x4_t r3_bload16_c(u32x4_s rs, unsigned voff) {      // re-read by other tiles (bias): cached
+    u32x4_t v;
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ float r3_bload4(u32x4_s rs, unsigned voff) {
+    float v;
+    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(rs) : "memory");
+    return v;
+}
+__device__ __forceinline__ void r3_bstore16(u32x4_s rs, unsigned voff, u32x4_t v) {    // offsets >= num_records are dropped
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rs) : "memory");
+}
+__device__ __forceinline__ u32x4_t r3_pack8(const float v[8]) {
+    u32x4_t a;
+    a[0] = pack2bf(v[0], v[1]); a[1] = pack2bf(v[2], v[3]); a[2] = pack2bf(v[4], v[5]); a[3] = pack2bf(v[6], v[7]);
+    return a;
+}
+
+// arrival tickets per CU: the two co-resident workgroups of a CU draw consecutive tickets, so ticket parity tells them apart
+// (placement is never relied on for correctness: the parity only decides which of the two starts half a tile late)
+__device__ int g_r3_ticket[4096];
+
+// DBG != 0: timing experiments (RESULTS DELIBERATELY WRONG), instantiated by -DGAEXT_DEBUG builds only: 1 no epilogue, 2 no global
+// stores, 4 no GELU, 8 no operand loads, 16 no DMA, 32 wait-free K loop.  Compile-time on purpose: a run-time switch kept every
+// variant's registers live at once, hipcc spilled the destination registers of in-flight asm loads (guide 5.7 item 1) and a
+// garbage store offset inside the then 2 GiB buffer window faulted.
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm_desc d, const int stagger) {
+    constexpr int dbg = DBG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (d.N + 127) / 128, tiles_m = (d.M + 255) / 256;
+    const int nwg = tiles_n * tiles_m;
+    const int z = blockIdx.z;
+    const int za = d.a_batch_mod > 0 ? z % d.a_batch_mod : z;
+    const bf16_t* Ab = reinterpret_cast<const bf16_t*>(d.A) + (long)za * d.strideA;
+    const bf16_t* Bb = reinterpret_cast<const bf16_t*>(d.B) + (long)z * d.strideB;
+    const int nk = (d.K + 31) / 32;
+    const int my_tiles = (nwg - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * nk;                                   // stages in this workgroup's stream
+
+    // ---- fragment read addresses: row (lane & 15) of a 16-row piece (1 KiB), chunk (lane >> 4) ^ f(row >> 2)
+    const int frow = lane & 15;
+    const unsigned fa = frow * 64 + ((((lane >> 4) ^ ((4 - (frow >> 2)) & 3))) << 4);
+    const unsigned char* aF = smem + wm * 8192 + fa;               // + tm * 1024 (+ slot)
+    const unsigned char* bF = smem + 16384 + wn * 4096 + fa;       // + tn * 1024 (+ slot)
+
+    // ---- LDS-DMA roles: wave w brings A pieces 4w .. 4w+3 and B pieces 2w, 2w+1 of every stage (a piece = 16 rows x 64 B).
+    // Lane l writes row l >> 2, LDS chunk l & 3 of its piece, which must hold SOURCE chunk (l & 3) ^ f((l >> 2) >> 2)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int dchunk = ((lane & 3) ^ ((4 - (lane >> 4)) & 3)) * 8;  // element offset of this lane's chunk inside the 32-wide stage
+    constexpr unsigned kOob = 0x80000000u;                         // >= num_records: the piece reads as zeros
+    // buffer windows = the exact extent of each matrix: an offset beyond it (kOob, or anything a bug produces) reads as zeros or
+    // drops the store instead of touching memory that is not the operand's
+    auto extent = [](long rows, long ld, long cols, int esz) { return (unsigned)(((rows - 1) * ld + cols) * esz); };
+    const u32x4_s rsA = make_rsrc(Ab, extent(d.M, d.lda, d.K, 2)), rsB = make_rsrc(Bb, extent(d.N, d.ldb, d.K, 2));
+    const int ktail = d.K & 31;                                    // > 0: the last stage is ragged
+    unsigned aoff[4], boff[2];
+    int ivt = blockIdx.x, ikt = 0;                                 // issue-side cursor: output tile, stage inside it
+    auto dma_rows = [&]() {
+        if (ivt < nwg) {
+            const int bid = xcd_remap(ivt, nwg);
+            const int tm_ = bid / tiles_n, tn_ = bid - tm_ * tiles_n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = (long)tm_ * 256 + (wave * 4 + i) * 16 + (lane >> 2);
+                aoff[i] = m < d.M ? (unsigned)(m * d.lda + dchunk) * 2u : kOob;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long n = (long)tn_ * 128 + (wave * 2 + i) * 16 + (lane >> 2);
+                boff[i] = n < d.N ? (unsigned)(n * d.ldb + dchunk) * 2u : kOob;
+            }
+        } else {                                                   // beyond the stream: keep the op count, fetch nothing
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aoff[i] = kOob;
+            boff[0] = boff[1] = kOob;
+        }
+    };
+    // a stage = EXACTLY 6 vector-memory operations per wave, issued as three pairs (part 0, 1, 2) that the K loop spreads between
+    // its MFMA groups: a burst of 6 at the stage top cost ~600 clocks of issue against the 512 the stage's 32 MFMAs take
+    // (no-epilogue timing variant: 990 TFLOP/s with the burst against 1440 without any DMA)
+    auto dma_part = [&](int slot, int part) {
+        const bool kdead = ktail && ikt == nk - 1 && dchunk >= ktail;
+        const unsigned soff = (unsigned)ikt * 64u;
+        const unsigned dst = lds0 + slot * kR3Slot;
+        if (part == 0) blds16x2(rsA, kdead ? kOob : aoff[0], kdead ? kOob : aoff[1], soff, dst + (wave * 4) * 1024);
+        if (part == 1) blds16x2(rsA, kdead ? kOob : aoff[2], kdead ? kOob : aoff[3], soff, dst + (wave * 4 + 2) * 1024);
+        if (part == 2) {
+            blds16x2(rsB, kdead ? kOob : boff[0], kdead ? kOob : boff[1], soff, dst + 16384 + (wave * 2) * 1024);
+            if (++ikt == nk) {
+                ikt = 0;
+                ivt += gridDim.x;
+                dma_rows();
+            }
+        }
+    };
+    auto dma_issue = [&](int slot) {
+        dma_part(slot, 0);
+        dma_part(slot, 1);
+        dma_part(slot, 2);
+    };
+
+    f32x4_t acc[4][8];                                             // [tn][tm]: C[m = tm*16 + (lane&15)][n = tn*16 + (lane>>4)*4 + r]
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = zero4;
+
+    // ---- epilogue operands
+    constexpr bool kOp = EPI == EPI_DG2 || EPI == EPI_FC2;
+    const bf16_t* Pb = EPI == EPI_DG2 ? (d.H ? reinterpret_cast<const bf16_t*>(d.H) + (long)z * d.strideH : nullptr)
+                                      : (d.R ? reinterpret_cast<const bf16_t*>(d.R) + (long)z * d.strideR : nullptr);
+    const long ldp = EPI == EPI_DG2 ? d.ldh : d.ldr;
+    const u32x4_s rsP = make_rsrc(Pb, (kOp && Pb && !(dbg & 8)) ? extent(d.M, ldp, d.N, 2) : 0u);
+    const u32x4_s rsBias = make_rsrc(d.bias ? d.bias + (long)z * d.strideBias : nullptr, d.bias ? (unsigned)d.N * 4u : 0u);
+    u32x4_t opn[kOp ? 4 : 1][2], biasv[2];                  // operand pieces tm, tm+4 share registers (rolling prefetch)
+    float rsc[EPI == EPI_FC2 ? 4 : 1][2];                          // DropPath row scales (fc2), requested with the operand pieces
+    const u32x4_s rsRS = make_rsrc(EPI == EPI_FC2 ? d.rowscale : nullptr,
+                                   (EPI == EPI_FC2 && d.rowscale) ? (unsigned)(((d.M - 1) / d.rows_per_scale + 1) * 4) : 0u);
+    auto rs_off = [&](long m) -> unsigned { return m < d.M ? ((unsigned)m / (unsigned)d.rows_per_scale) * 4u : kOob; };
+    const int q = lane & 7, rr = lane >> 3;
+    float* stage = reinterpret_cast<float*>(smem + 3 * kR3Slot + wave * kR3Stage);
+
+    int vt = blockIdx.x, kt = 0, cslot = 0;
+    int tile_m = 0, tile_n = 0;
+    bool first = true;
+    dma_rows();
+    dma_issue(0);
+    dma_issue(1);
+    // Two workgroups that start together on one CU run the same program in lockstep -- K loops together, epilogues together --
+    // and the timing variants showed their phases simply ADD (K loop + staging + GELU + stores = the measured time).  The
+    // second arrival on a CU therefore starts `stagger` x 64 clocks late (about half a tile), so that one workgroup's epilogue
+    // (VALU, LDS staging, stores) runs beside the other's MFMAs for the rest of the launch.
+    if (stagger > 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID [3:0]
+        const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+        int ticket = 0;
+        if (tid == 0) ticket = atomicAdd(&g_r3_ticket[key], 1);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        // only wave 0 knows the ticket; every wave sleeps on the first barrier behind it anyway
+        if (wave == 0 && (ticket & 1)) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+#pragma unroll 1
+    for (int g = 0; g < S; ++g) {
+        if (kt == 0) {
+            const int bid = xcd_remap(vt, nwg);
+            tile_m = bid / tiles_n;
+            tile_n = bid - tile_m * tiles_n;
+        }
+        // this wave's pieces of stage g have landed: the workgroup's first tile waits with the next stage's 6 pieces in flight;
+        // later tiles retired stages 0 and 1 in the previous epilogue's drain and wait from stage 2 on (which also retires that
+        // epilogue's stores -- two stages after they were issued)
+        if ((first || kt >= 2) && !(dbg & 32)) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // ... everyone's; nobody reads the slot of stage g-1 any more
+        const int n = tile_n * 128 + wn * 64 + q * 8;
+        const bool n_ok = n < d.N;                                 // N % 8 == 0: a piece of 8 columns is wholly in or out
+        const long mrow0 = (long)tile_m * 256 + wm * 128 + rr;
+        if (kt == nk - 1) {                                        // the tile's last stage: request bias and operand pieces 0-3
+            biasv[0] = r3_bload16_c(rsBias, n_ok ? (unsigned)n * 4u : kOob);
+            biasv[1] = r3_bload16_c(rsBias, n_ok ? (unsigned)n * 4u + 16u : kOob);
+            if constexpr (kOp) {
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const long m = mrow0 + tm * 16 + 8 * p;
+                        opn[tm][p] = r3_bload16(rsP, (n_ok && m < d.M) ? (unsigned)(m * ldp + n) * 2u : kOob);
+                        if constexpr (EPI == EPI_FC2) rsc[tm][p] = r3_bload4(rsRS, rs_off(m));
+                    }
+            }
+        }
+        const int islot = cslot >= 1 ? cslot - 1 : 2;              // stage g+2 -> slot (g+2) % 3 = (g-1) % 3, free since the barrier
+        {
+            const unsigned sb = cslot * kR3Slot;
+            bf16x8_t af[8], bfr[4];
+            // fragment reads run two row tiles ahead of the MFMAs that use them (left alone, hipcc re-uses two fragment
+            // registers and waits for every pair of reads right before its first MFMA)
+#define R3_RA(i) af[i] = *reinterpret_cast<const bf16x8_t*>(aF + sb + (i) * 1024)
+#define R3_MMA(i)                                                                                               \
+    _Pragma("unroll") for (int tn = 0; tn < 4; ++tn)                                                             \
+        acc[tn][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[tn], af[i], acc[tn][i], 0, 0, 0)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) bfr[tn] = *reinterpret_cast<const bf16x8_t*>(bF + sb + tn * 1024);
+            R3_RA(0); R3_RA(1); R3_RA(2); R3_RA(3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(dbg & 16)) dma_part(islot, 0);
+            R3_MMA(0); R3_MMA(1);
+            __builtin_amdgcn_sched_barrier(0);
+            R3_RA(4); R3_RA(5);
+            if (!(dbg & 16)) dma_part(islot, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            R3_MMA(2); R3_MMA(3);
+            __builtin_amdgcn_sched_barrier(0);
+            R3_RA(6); R3_RA(7);
+            if (!(dbg & 16)) dma_part(islot, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            R3_MMA(4); R3_MMA(5); R3_MMA(6); R3_MMA(7);
+#undef R3_RA
+#undef R3_MMA
+        }
+        cslot = cslot == 2 ? 0 : cslot + 1;
+        if (++kt < nk) continue;
+        kt = 0;
+        first = false;
+        if (dbg & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(acc[i][j]));
+            // (every register an asm load targets must be named by the wait: a register the compiler believes dead is re-used,
+            // e.g. for an address, while the load is still in flight)
+            if constexpr (kOp)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(opn[0][0]), "+v"(opn[0][1]), "+v"(opn[1][0]), "+v"(opn[1][1]), "+v"(opn[2][0]), "+v"(opn[2][1]),
+                               "+v"(opn[3][0]), "+v"(opn[3][1]), "+v"(biasv[0]), "+v"(biasv[1]), "+v"(rsc[0][0]), "+v"(rsc[0][EPI == EPI_FC2]),
+                               "+v"(rsc[EPI == EPI_FC2][0]), "+v"(rsc[EPI == EPI_FC2][EPI == EPI_FC2]), "+v"(rsc[2 * (EPI == EPI_FC2)][0]),
+                               "+v"(rsc[2 * (EPI == EPI_FC2)][EPI == EPI_FC2]), "+v"(rsc[3 * (EPI == EPI_FC2)][0]), "+v"(rsc[3 * (EPI == EPI_FC2)][EPI == EPI_FC2])
+                             :: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(biasv[0]), "+v"(biasv[1])::"memory");
+            vt += gridDim.x;
+            continue;
+        }
+        // ================= epilogue of output tile vt: per wave, no workgroup barrier =================
+        // every vector-memory operation from here to the end of the operand pipeline is an UNCONDITIONAL asm statement (rows /
+        // columns beyond the matrix carry out-of-range buffer offsets), so the counted waits below are exact
+        if constexpr (kOp) {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(opn[0][0]), "+v"(opn[0][1]), "+v"(opn[1][0]), "+v"(opn[1][1]), "+v"(opn[2][0]), "+v"(opn[2][1]),
+                           "+v"(opn[3][0]), "+v"(opn[3][1]), "+v"(biasv[0]), "+v"(biasv[1])
+                         :: "memory");
+            if constexpr (EPI == EPI_FC2) {                        // (same drain: names the row-scale registers too)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) asm volatile("" : "+v"(rsc[tm][0]), "+v"(rsc[tm][1]));
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(biasv[0]), "+v"(biasv[1]) :: "memory");
+        }
+        {
+            float bias[8], csum[8], csq[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bias[j] = __uint_as_float(biasv[0][j]);
+                bias[4 + j] = __uint_as_float(biasv[1][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[j] = csq[j] = 0.f;
+            const bool do_csum = (EPI == EPI_PLAIN || EPI == EPI_DG2) && d.colsum != nullptr;
+            const u32x4_s rsC = make_rsrc(reinterpret_cast<bf16_t*>(d.C) + (long)z * d.strideC, extent(d.M, d.ldc, d.N, 2));
+            const u32x4_s rsC2 = make_rsrc((EPI == EPI_FC1 && d.C2) ? reinterpret_cast<bf16_t*>(d.C2) + (long)z * d.strideC : nullptr,
+                                           (EPI == EPI_FC1 && d.C2) ? extent(d.M, d.ldc, d.N, 2) : 0u);
+#pragma unroll
+            for (int tm = 0; tm < 8; ++tm) {
+                if constexpr (kOp) {                               // operand piece tm >= 4 was requested 4 pieces ago, after the stores of
+                    if (tm >= 4) {                                 // piece tm-4: younger = 2 stores per later piece + 2 loads per later request
+                        // fc2 requests 4 loads per piece (2 operand + 2 row-scale), dgrad2 2; every piece stores twice
+                        constexpr int L = EPI == EPI_FC2 ? 4 : 2;
+                        constexpr int ST = (dbg & 2) ? 0 : 2;    // (the no-store timing variant issues none)
+                        constexpr int kYoung[4] = {3 * ST + 3 * L, 3 * ST + 2 * L, 3 * ST + L, 3 * ST};
+                        constexpr int R = EPI == EPI_FC2 ? 1 : 0;
+                        if (tm == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(opn[0][0]), "+v"(opn[0][1]), "+v"(rsc[0][0]), "+v"(rsc[0][R]) : "n"(kYoung[0]) : "memory");
+                        if (tm == 5) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(opn[1][0]), "+v"(opn[1][1]), "+v"(rsc[R][0]), "+v"(rsc[R][R]) : "n"(kYoung[1]) : "memory");
+                        if (tm == 6) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(opn[2][0]), "+v"(opn[2][1]), "+v"(rsc[2 * R][0]), "+v"(rsc[2 * R][R]) : "n"(kYoung[2]) : "memory");
+                        if (tm == 7) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(opn[3][0]), "+v"(opn[3][1]), "+v"(rsc[3 * R][0]), "+v"(rsc[3 * R][R]) : "n"(kYoung[3]) : "memory");
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {                      // rows 8p .. 8p+7 of the 16-row accumulator tiles
+                    // (no waits around the staging piece: LDS operations of ONE wave execute in issue order, so these writes follow
+                    // the previous piece's reads and precede this piece's; hipcc keeps the order of may-alias LDS accesses)
+                    if (((lane >> 3) & 1) == p) {
+                        const int row = lane & 7;
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) {
+                            const int u = tn * 4 + (lane >> 4);
+                            *reinterpret_cast<f32x4_t*>(stage + row * 64 + ((u ^ row) << 2)) = acc[tn][tm];
+                        }
+                    }
+                    const f32x4_t lo = *reinterpret_cast<const f32x4_t*>(stage + rr * 64 + (((2 * q) ^ rr) << 2));
+                    const f32x4_t hi = *reinterpret_cast<const f32x4_t*>(stage + rr * 64 + (((2 * q + 1) ^ rr) << 2));
+                    const long m = mrow0 + tm * 16 + 8 * p;
+                    float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
+                                  hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
+                    const bool live = n_ok && m < d.M;
+                    const unsigned coff = live ? (unsigned)(m * d.ldc + n) * 2u : kOob;
+                    if constexpr (EPI == EPI_FC1) {
+                        float w[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (dbg & 4) w[j] = v[j] * 0.5f;
+                            else gelu_both_fast(v[j], v[j], w[j]);
+                        }
+                        if (!(dbg & 2)) r3_bstore16(rsC2, coff, r3_pack8(w));
+                        else asm volatile("" ::"v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+                    }
+                    if constexpr (EPI == EPI_DG2) {
+                        float h[8];
+                        unpack8(make_uint4(opn[tm & 3][p][0], opn[tm & 3][p][1], opn[tm & 3][p][2], opn[tm & 3][p][3]), h);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= h[j];
+                    }
+                    if constexpr (EPI == EPI_FC2) {
+                        if (d.rowscale) {
+                            const float sc = rsc[tm & 3][p];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] *= sc;
+                        }
+                        float r[8];
+                        unpack8(make_uint4(opn[tm & 3][p][0], opn[tm & 3][p][1], opn[tm & 3][p][2], opn[tm & 3][p][3]), r);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += r[j];
+                    }
+                    if (do_csum && live) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            csum[j] += v[j];
+                            csq[j] += v[j] * v[j];
+                        }
+                    }
+                    if (!(dbg & 2)) r3_bstore16(rsC, coff, r3_pack8(v));
+                    else asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+                }
+                if constexpr (kOp) {
+                    if (tm < 4) {                                  // request piece tm+4 into the registers piece tm has just left
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const long m = mrow0 + (tm + 4) * 16 + 8 * p;
+                            opn[tm][p] = r3_bload16(rsP, (n_ok && m < d.M) ? (unsigned)(m * ldp + n) * 2u : kOob);
+                            if constexpr (EPI == EPI_FC2) rsc[tm][p] = r3_bload4(rsRS, rs_off(m));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) acc[tn][tm] = zero4;
+            }
+            if (do_csum) {                                         // lanes q, q+8, .. hold the same 8 columns over different rows
+                // reduce over the 8 row lanes, then pass the wave's 64 column sums through the (idle) staging piece so that lane
+                // l owns column l: ONE 256-byte atomic per statistic and tile instead of 8 instructions of 8 lanes each (the
+                // narrow form made dgrad2 at M = 200,704 3x slower than its no-epilogue time: 150 k contended atomic instructions)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int o = 8; o < 64; o <<= 1) {
+                        csum[j] += __shfl_xor(csum[j], o, 64);
+                        csq[j] += __shfl_xor(csq[j], o, 64);
+                    }
+                }
+                if (rr == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        stage[q * 8 + j] = csum[j];
+                        stage[64 + q * 8 + j] = csq[j];
+                    }
+                }
+                const float a = stage[lane], b = stage[64 + lane];
+                const int nc = tile_n * 128 + wn * 64 + lane;
+                if (nc < d.N) {
+                    atomicAdd(d.colsum + (long)z * d.strideCol + nc, a);
+                    if (d.colsumsq) atomicAdd(d.colsumsq + (long)z * d.strideCol + nc, b);
+                }
+            }
+        }
+        vt += gridDim.x;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (S == 0 cannot happen: grid <= tiles)
+}
+
+// ================================================================================================
 // TN (wgrad) kernel: dW[n][k] = sum_m Y[m][n] X[m][k]
 // LDS images are [rows = m][128 columns]; bf16: 64 rows x 256 B, fp32: 32 rows x 512 B (16 KiB each)
 // ================================================================================================
@@ -1542,6 +1951,72 @@ void launch_nt_pp(const ga_gemm_desc* d, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, kPPSmem, s, *d, dbg);
 }
 
+template <int EPI, int DBG = 0>
+void launch_nt_r3_(const ga_gemm_desc* d, hipStream_t s) {
+    auto kern = gemm_nt_r3_kernel<EPI, DBG>;
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kR3Smem) == hipSuccess;
+    if (!ok) {
+        ga_set_error("ga_gemm: cannot reserve %d bytes of LDS", kR3Smem);
+        return;
+    }
+    const int tiles = cdiv(d->M, 256) * cdiv(d->N, 128);
+    const int cap = std::max(8, (2 * num_cus() / d->batch) / 8 * 8);       // two workgroups per CU
+    dim3 grid(std::min(tiles, cap), 1, d->batch), block(kR3Threads);
+    // start skew of the second workgroup of a CU, in units of 64 clocks.  Off by default: measured 0, 40, 80, 160, 240 on the
+    // MLP shapes of stages 1-3 (tools/r3_ab.py, R3_ARMS): within +-3 % of each other, no trend -- the two workgroups of a CU do
+    // not run in lockstep, their phases add up because each is bound by the CU's shared issue / LDS paths
+    const int stagger = std::max(0, GA_KNOB("R3_STAGGER", 0));
+    hipLaunchKernelGGL(kern, grid, block, kR3Smem, s, *d, stagger);
+}
+template <int EPI>
+void launch_nt_r3(const ga_gemm_desc* d, hipStream_t s) {
+#ifdef GAEXT_DEBUG
+    switch (GA_KNOB("R3_DBG", 0)) {     // the timing-experiment variants exist in debug builds only
+        case 1: return launch_nt_r3_<EPI, 1>(d, s);
+        case 2: return launch_nt_r3_<EPI, 2>(d, s);
+        case 4: return launch_nt_r3_<EPI, 4>(d, s);
+        case 6: return launch_nt_r3_<EPI, 6>(d, s);
+        case 8: return launch_nt_r3_<EPI, 8>(d, s);
+        case 10: return launch_nt_r3_<EPI, 10>(d, s);
+        case 17: return launch_nt_r3_<EPI, 17>(d, s);
+        case 33: return launch_nt_r3_<EPI, 33>(d, s);
+        default: break;
+    }
+#endif
+    launch_nt_r3_<EPI, 0>(d, s);
+}
+
+// 3-slot ring form (256 x 128 tiles, two workgroups per CU): NT_R3 = bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2);
+// -1 = the heuristic below
+bool want_pp(const ga_gemm_desc* d, int epi);
+bool want_r3(const ga_gemm_desc* d, int epi) {
+    const int r3 = GA_KNOB("NT_R3", -1);
+    const bool forced = r3 >= 0;
+    const int mask = forced ? r3 : 15;
+    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
+    if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || d->lda % 8 != 0 || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
+    if ((long)d->M * d->lda >= (1L << 30) || (long)d->N * d->ldb >= (1L << 30)) return false;              // 32-bit byte offsets
+    if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) & 15) return false;
+    if ((long)d->M * d->ldc >= (1L << 30) || d->c_kind != GA_C_PLAIN || d->c_f32) return false;
+    if (epi == EPI_FC1 && d->C2 && (reinterpret_cast<uintptr_t>(d->C2) & 15)) return false;
+    if (epi == EPI_DG2 && (d->ldh % 8 != 0 || (reinterpret_cast<uintptr_t>(d->H) & 15) || (long)d->M * d->ldh >= (1L << 30))) return false;
+    if (epi == EPI_FC2 && (d->ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(d->R) & 15) || (long)d->M * d->ldr >= (1L << 30))) return false;
+    if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 3)) return false;
+    if (forced) return true;
+    // heuristic from same-process A/B rounds against the other forms (tools/r3_ab.py, gpurun_out/r03/r3_ab*.log; MI355X):
+    //   fc1 / fc2 / dgrad2 epilogues at M = 6,272 .. 200,704, K = 192 .. 3072: x1.04 .. 1.76 everywhere measured
+    //   plain: ahead for K <= 512 (x1.13 .. 1.18) and for the K = 768 .. 2208 launches of the heads (x1.03 .. 1.10); behind the
+    //   8-wave ping-pong body on very wide / very long / very tall launches (N 2208: x0.91, K 3072: x0.83, 8192^3: x0.88,
+    //   M 73,856 of the ViT trunk: x0.91 .. 0.97) and behind the 128-column forms at N < 384 with a mid-length K (x0.95)
+    if ((long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch < num_cus() / 2) return false;      // too few tiles to fill the chip
+    const bool pp = want_pp(d, epi);
+    if (d->M >= 65536 && pp) return false;
+    if (epi != EPI_PLAIN) return true;
+    if (d->K <= 512) return true;
+    if (pp) return d->N < 2048 && d->K < 3072;
+    return d->N >= 384 ? d->K < 3072 : d->K >= 1024;
+}
+
 // 8-wave ping-pong form: GAEXT_NT_PP = bit mask of epilogues (1 plain, 2 fc1, 4 fc2, 8 dgrad2); unset: plain / fc1 / fc2, for
 // launches whose K loop is long enough to carry the un-overlapped epilogue (K >= GAEXT_NT_PP_MINK, default 512) and whose
 // last column tile is not mostly empty
@@ -1701,7 +2176,14 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
     const int epi = classify_epilogue(d);
-    if (want_dma(d, epi, tnw)) {
+    if (want_r3(d, epi)) {
+        switch (epi) {
+            case EPI_PLAIN: launch_nt_r3<EPI_PLAIN>(d, s); break;
+            case EPI_FC1: launch_nt_r3<EPI_FC1>(d, s); break;
+            case EPI_FC2: launch_nt_r3<EPI_FC2>(d, s); break;
+            default: launch_nt_r3<EPI_DG2>(d, s); break;
+        }
+    } else if (want_dma(d, epi, tnw)) {
         if (tnw == 4) {
             switch (epi) {
                 case EPI_PLAIN: launch_nt_<bf16_t, 4, 4, true, false, EPI_PLAIN, true>(d, s); break;

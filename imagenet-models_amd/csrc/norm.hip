@@ -62,50 +62,65 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
         }
     }
-    for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
-        float v[kMaxCh][E];
-        float s = 0.f;
+    // U rows per thread and iteration: their loads are issued back to back, so every lane keeps U * (chunks per lane) 16-byte
+    // loads in flight (one row at a time left the C = 96 .. 384 norms at 3 - 4.5 TB/s: too few bytes in flight per CU)
+    constexpr int U = 2;
+    const long rstep = (long)gridDim.x * rpb;
+    for (long row0 = (long)blockIdx.x * rpb + rib; row0 < rows; row0 += U * rstep) {
+        float v[U][kMaxCh][E];
 #pragma unroll
-        for (int j = 0; j < kMaxCh; ++j) {
-            const int ci = lg + G * j;
-            if (ci < nch) {
-                ld_chunk_nt(x + row * C + ci * E, v[j]);
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rstep;
 #pragma unroll
-                for (int e = 0; e < E; ++e) s += v[j][e];
-            } else {
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch && row < rows) {
+                    ld_chunk_nt(x + row * C + ci * E, v[u][j]);
+                } else {
 #pragma unroll
-                for (int e = 0; e < E; ++e) v[j][e] = 0.f;
-            }
-        }
-        const float mu = group_sum<G>(s) * invC;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < kMaxCh; ++j) {
-            const int ci = lg + G * j;
-            if (ci < nch) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float dlt = v[j][e] - mu;
-                    q += dlt * dlt;
+                    for (int e = 0; e < E; ++e) v[u][j][e] = 0.f;
                 }
             }
         }
-        const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
-        if (lg == 0) {
-            if (mean) mean[row] = mu;
-            if (rstd) rstd[row] = rs;
-        }
 #pragma unroll
-        for (int j = 0; j < kMaxCh; ++j) {
-            const int ci = lg + G * j;
-            if (ci < nch) {
-                float o[E];
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rstep;
+            if (row >= rows) break;
+            float s = 0.f;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    o[e] = (v[j][e] - mu) * rs;
-                    if constexpr (AFF) o[e] = fmaf(o[e], wv[j][e], bv[j][e]);
+            for (int j = 0; j < kMaxCh; ++j)
+#pragma unroll
+                for (int e = 0; e < E; ++e) s += v[u][j][e];
+            const float mu = group_sum<G>(s) * invC;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const float dlt = v[u][j][e] - mu;
+                        q += dlt * dlt;
+                    }
                 }
-                st_chunk(y + row * C + ci * E, o);
+            }
+            const float rs = rsqrtf(group_sum<G>(q) * invC + eps);
+            if (lg == 0) {
+                if (mean) mean[row] = mu;
+                if (rstd) rstd[row] = rs;
+            }
+#pragma unroll
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch) {
+                    float o[E];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        o[e] = (v[u][j][e] - mu) * rs;
+                        if constexpr (AFF) o[e] = fmaf(o[e], wv[j][e], bv[j][e]);
+                    }
+                    st_chunk(y + row * C + ci * E, o);
+                }
             }
         }
     }
@@ -141,52 +156,73 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
                 wv[j][e] = (w && ci < nch) ? w[ci * E + e] : 1.f;
             }
     }
-    for (long row = (long)blockIdx.x * rpb + rib; row < rows; row += (long)gridDim.x * rpb) {
-        const float rs = rstd[row];
-        const float mu = xnorm ? 0.f : mean[row];
-        const float sc = xnorm ? 1.f : rs;
-        float gv[kMaxCh][E], xh[kMaxCh][E];
-        float s1 = 0.f, s2 = 0.f;
+    // U rows per thread and iteration (loads of all of them first): more 16-byte loads in flight per lane for the narrow rows
+    constexpr int U = AFF ? (kMaxCh == 1 ? 2 : 1) : (kMaxCh == 1 ? 4 : 2);
+    const long rstep = (long)gridDim.x * rpb;
+    for (long row0 = (long)blockIdx.x * rpb + rib; row0 < rows; row0 += U * rstep) {
+        float gv[U][kMaxCh][E], xh[U][kMaxCh][E], rsv[U], muv[U];
 #pragma unroll
-        for (int j = 0; j < kMaxCh; ++j) {
-            const int ci = lg + G * j;
-            if (ci < nch) {
-                ld_chunk_nt(g + row * C + ci * E, gv[j]);
-                ld_chunk(x + row * C + ci * E, xh[j]);
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rstep;
+            const bool live = row < rows;
+            rsv[u] = live ? rstd[row] : 0.f;
+            muv[u] = (live && !xnorm) ? mean[row] : 0.f;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    xh[j][e] = (xh[j][e] - mu) * sc;
-                    if constexpr (AFF) {
-                        aw[j][e] = fmaf(gv[j][e], xh[j][e], aw[j][e]);
-                        ab[j][e] += gv[j][e];
-                        gv[j][e] *= wv[j][e];
-                    }
-                    s1 += gv[j][e];
-                    s2 = fmaf(gv[j][e], xh[j][e], s2);
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch && live) {
+                    ld_chunk_nt(g + row * C + ci * E, gv[u][j]);
+                    ld_chunk(x + row * C + ci * E, xh[u][j]);
                 }
             }
         }
-        s1 = group_sum<G>(s1) * invC;
-        s2 = group_sum<G>(s2) * invC;
 #pragma unroll
-        for (int j = 0; j < kMaxCh; ++j) {
-            const int ci = lg + G * j;
-            if (ci < nch) {
-                float o[E];
-                if (dres) {
-                    ld_chunk(dres + row * C + ci * E, o);
-                } else {
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rstep;
+            if (row >= rows) break;
+            const float rs = rsv[u];
+            const float mu = muv[u];
+            const float sc = xnorm ? 1.f : rs;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) o[e] = 0.f;
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        xh[u][j][e] = (xh[u][j][e] - mu) * sc;
+                        if constexpr (AFF) {
+                            aw[j][e] = fmaf(gv[u][j][e], xh[u][j][e], aw[j][e]);
+                            ab[j][e] += gv[u][j][e];
+                            gv[u][j][e] *= wv[j][e];
+                        }
+                        s1 += gv[u][j][e];
+                        s2 = fmaf(gv[u][j][e], xh[u][j][e], s2);
+                    }
                 }
+            }
+            s1 = group_sum<G>(s1) * invC;
+            s2 = group_sum<G>(s2) * invC;
 #pragma unroll
-                for (int e = 0; e < E; ++e) o[e] += rs * (gv[j][e] - s1 - xh[j][e] * s2);
-                st_chunk(dx + row * C + ci * E, o);
-                if (dx2) {      // second output: the stored value times a per-sample scale (the consumer block's DropPath factor)
-                    const float sc2 = scale2[row / rows_per_scale];
+            for (int j = 0; j < kMaxCh; ++j) {
+                const int ci = lg + G * j;
+                if (ci < nch) {
+                    float o[E];
+                    if (dres) {
+                        ld_chunk(dres + row * C + ci * E, o);
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < E; ++e) o[e] = elt<T>::round(o[e]) * sc2;
-                    st_chunk(dx2 + row * C + ci * E, o);
+                        for (int e = 0; e < E; ++e) o[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) o[e] += rs * (gv[u][j][e] - s1 - xh[u][j][e] * s2);
+                    st_chunk(dx + row * C + ci * E, o);
+                    if (dx2) {      // second output: the stored value times a per-sample scale (the consumer block's DropPath factor)
+                        const float sc2 = scale2[row / rows_per_scale];
+#pragma unroll
+                        for (int e = 0; e < E; ++e) o[e] = elt<T>::round(o[e]) * sc2;
+                        st_chunk(dx2 + row * C + ci * E, o);
+                    }
                 }
             }
         }

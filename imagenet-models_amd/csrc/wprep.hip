@@ -192,15 +192,57 @@ __global__ __launch_bounds__(256) void axpy_f32_kernel(float* __restrict__ y, co
 template <typename T>
 __global__ __launch_bounds__(256) void rowscale_kernel(const T* __restrict__ x, const float* __restrict__ s,
                                                        T* __restrict__ y, long n8, long elems_per_scale) {
-    const unsigned eps8 = (unsigned)(elems_per_scale >> 3);
-    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)n8; i += gridDim.x * 256u) {
-        const long e = (long)i * 8;
-        const float sc = s[i / eps8];
-        float v[8];
-        load8(x + e, v);
+    // a pure streaming pass (every byte read once, written once): U chunks of 16 bytes in flight per lane, non-temporal both
+    // ways, one scale lookup per chunk through a reciprocal (the 32-bit division cost ~20 VALU slots per chunk)
+    constexpr int U = 4;
+    constexpr int E = 16 / (int)sizeof(T);                    // elements per 16-byte chunk
+    const unsigned epsc = (unsigned)(elems_per_scale / E);    // chunks per scale
+    const float inv = 1.0f / (float)epsc;
+    const unsigned nc = (unsigned)(n8 * 8 / E);
+    const unsigned stride = gridDim.x * 256u;
+    auto scale_of = [&](unsigned i) {
+        unsigned q = (unsigned)((float)i * inv);              // exact up to 2^24 chunks per scale table entry boundary: fix up
+        const long r = (long)i - (long)q * epsc;
+        if (r < 0) --q;
+        else if (r >= (long)epsc) ++q;
+        return s[q];
+    };
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    for (; (unsigned long long)i + (U - 1) * (unsigned long long)stride < nc; i += U * stride) {
+        uint4 v[U];
+        float sc[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= sc;
-        store8(y + e, v);
+        for (int u = 0; u < U; ++u) v[u] = load16_nt(x + (long)(i + u * stride) * E);
+#pragma unroll
+        for (int u = 0; u < U; ++u) sc[u] = scale_of(i + u * stride);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (sizeof(T) == 2) {
+                float f[8];
+                unpack8(v[u], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] *= sc[u];
+                store8_nt(y + (long)(i + u * stride) * E, f);
+            } else {
+                const uint4 o = make_uint4(__float_as_uint(__uint_as_float(v[u].x) * sc[u]), __float_as_uint(__uint_as_float(v[u].y) * sc[u]),
+                                           __float_as_uint(__uint_as_float(v[u].z) * sc[u]), __float_as_uint(__uint_as_float(v[u].w) * sc[u]));
+                store16_nt(y + (long)(i + u * stride) * E, o);
+            }
+        }
+    }
+    for (; i < nc; i += stride) {
+        const float sc = scale_of(i);
+        const uint4 v = load16_nt(x + (long)i * E);
+        if constexpr (sizeof(T) == 2) {
+            float f[8];
+            unpack8(v, f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] *= sc;
+            store8_nt(y + (long)i * E, f);
+        } else {
+            store16_nt(y + (long)i * E, make_uint4(__float_as_uint(__uint_as_float(v.x) * sc), __float_as_uint(__uint_as_float(v.y) * sc),
+                                                   __float_as_uint(__uint_as_float(v.z) * sc), __float_as_uint(__uint_as_float(v.w) * sc)));
+        }
     }
 }
 
@@ -549,10 +591,10 @@ extern "C" int ga_rowscale(const void* x, const float* s, void* y, int64_t n, in
     GA_REQUIRE(x && s && y && n > 0 && n % 8 == 0 && elems_per_scale % 8 == 0, "ga_rowscale: bad args");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GA_BF16)
-        hipLaunchKernelGGL(rowscale_kernel<bf16_t>, dim3(nblocks(n / 8, 8192)), dim3(256), 0, st, (const bf16_t*)x, s,
+        hipLaunchKernelGGL(rowscale_kernel<bf16_t>, dim3(nblocks(n / 8 / 4, 2048)), dim3(256), 0, st, (const bf16_t*)x, s,
                            (bf16_t*)y, (long)(n / 8), (long)elems_per_scale);
     else
-        hipLaunchKernelGGL(rowscale_kernel<float>, dim3(nblocks(n / 8, 8192)), dim3(256), 0, st, (const float*)x, s,
+        hipLaunchKernelGGL(rowscale_kernel<float>, dim3(nblocks(n / 8 / 2, 2048)), dim3(256), 0, st, (const float*)x, s,
                            (float*)y, (long)(n / 8), (long)elems_per_scale);
     return ga_check_launch("ga_rowscale");
 }

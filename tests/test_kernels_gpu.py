@@ -197,7 +197,7 @@ def test_gemm_stem(dt):
     assert_close(dW, ww.grad.reshape(N, 48), tol(dt, 2), 'stem wgrad')
 
 
-@pytest.mark.parametrize('form', ['dma256', 'dma128', 't256', 'pp'])
+@pytest.mark.parametrize('form', ['dma256', 'dma128', 't256', 'pp', 'r3'])
 @pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384), (66000, 512, 328),
                                    (33000, 1536, 768), (40100, 264, 520), (12500, 3072, 768), (50200, 384, 1536)])
 def test_gemm_lds_dma_form_bf16(shape, form, knobs):
@@ -210,6 +210,8 @@ def test_gemm_lds_dma_form_bf16(shape, form, knobs):
         knobs(NT_DMA=0, NT_T256=15)
     elif form == 'pp':                               # 8-wave ping-pong form (K >= 256)
         knobs(NT_PP=15)
+    elif form == 'r3':                               # 256 x 128 tile, 4 waves, 3-slot ring of 32-deep stages, two workgroups per CU
+        knobs(NT_R3=15)
     else:                                            # 128 x 128 tile, 4 waves, 2-slot ring, two workgroups per CU
         knobs(NT_DMA=0, NT_DMA2=15, NT_DMA2_MINK=8)
     dt = torch.bfloat16
@@ -246,6 +248,49 @@ def test_gemm_lds_dma_form_bf16(shape, form, knobs):
     ref = (a @ b.t()) * h
     assert_close(Cout, ref, 2e-2, 'dma dgrad2')
     assert_close(cs, ref.sum(0), 3e-3, 'dma dgrad2 colsum')
+
+
+@pytest.mark.parametrize('shape', [(300, 136, 64, 1), (257, 96, 72, 1), (1000, 1000, 768, 1), (5, 40, 96, 1), (2600, 384, 200, 2),
+                                   (131072 + 40, 128, 96, 1), (70, 1000, 1536, 1)])
+def test_gemm_ring3_form_small_and_batched(shape, knobs):
+    """the 3-slot ring form on shapes that stress its stream logic: fewer tiles than workgroups, one tile per workgroup, K of two
+    and three stages with a ragged tail, column tiles that are mostly empty, batch > 1 (grid z), more tiles than workgroups"""
+    ops = _imp()
+    knobs(NT_R3=15)
+    dt = torch.bfloat16
+    M, N, K, Z = shape
+    g = gen(9)
+    a, A = rnd((Z, M, K), dt, g)
+    b, B = rnd((Z, N, K), dt, g, 1 / math.sqrt(K))
+    bias = torch.randn(Z, N, generator=g)
+    h, Hm = rnd((Z, M, N), dt, g)
+    base = a @ b.transpose(1, 2) + bias[:, None, :]
+    P = ops.Plan(eager=True)
+    kw = dict(batch=Z, strideA=M * K, strideB=N * K, strideC=M * N)
+    Cout = torch.empty(Z, M, N, dtype=dt, device='cuda')
+    cs, cq = torch.zeros(Z, N, device='cuda'), torch.zeros(Z, N, device='cuda')
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), strideBias=N, colsum=cs, colsumsq=cq, strideCol=N, **kw)
+    assert_close(Cout, base, 2e-2, 'r3 plain')
+    assert_close(cs, base.sum(1), 2e-3, 'r3 colsum')
+    assert_close(cq, (base * base).sum(1), 2e-3, 'r3 colsumsq')
+    C2 = torch.empty_like(Cout)
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), strideBias=N, act=ops.ACT_GELU, C2=C2, c2_mode=2, **kw)
+    xr = base.clone().requires_grad_(True)
+    act = F.gelu(xr)
+    act.sum().backward()
+    assert_close(Cout, act, 2e-2, 'r3 fc1 gelu')
+    assert_close(C2, xr.grad, 2e-2, "r3 fc1 gelu'")
+    rs = torch.rand((M + 6) // 7, generator=g) + 0.5
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), strideBias=N, rowscale=rs.cuda(), rows_per_scale=7, R=Hm, ldr=N,
+           strideR=M * N, **kw)
+    assert_close(Cout, base * rs.repeat_interleave(7)[:M][None, :, None] + h, 2e-2, 'r3 fc2')
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), bias=bias.cuda(), strideBias=N, R=Hm, ldr=N, strideR=M * N, **kw)
+    assert_close(Cout, base + h, 2e-2, 'r3 fc2 without row scale')
+    cs.zero_()
+    P.gemm(A, B, Cout, M, N, K, ops.ga_dtype(dt), H=Hm, ldh=N, strideH=M * N, h_is_deriv=True, colsum=cs, strideCol=N, **kw)
+    ref = (a @ b.transpose(1, 2)) * h
+    assert_close(Cout, ref, 2e-2, 'r3 dgrad2')
+    assert_close(cs, ref.sum(1), 3e-3, 'r3 dgrad2 colsum')
 
 
 # ----------------------------------------------------------------------------------------------------------
