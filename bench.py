@@ -66,6 +66,10 @@ def parse():
     ap.add_argument('--no-measured-peaks', action='store_true')
     ap.add_argument('--no-ddp-bb', action='store_true', help='no per-forward BatchNorm buffer broadcast (GA/train.py:283)')
     ap.add_argument('--kernel-table', default='', help='write the per-kernel-family table (json) here')
+    ap.add_argument('--comm', default='torch', choices=['torch', 'native', 'native-bf16'],
+                    help="gradient exchange for N > 1: torch.distributed's nccl (= RCCL) backend, or the library's own RCCL entry points "
+                         '(ga_allreduce_bucket; native-bf16: bf16 wire)')
+    ap.add_argument('--force-buckets', action='store_true', help='N = 1: still run the segmented backward + bucket reductions')
     return ap.parse_args()
 
 
@@ -267,7 +271,11 @@ def main():
         dist.broadcast(model.flat_state()['params'], 0)
         dist.broadcast(model.flat_state()['buffers'], 0)
     opt = A.create_optimizer_v2(model, opt=a.opt, lr=1e-3, weight_decay=0.05, momentum=0.9)
-    step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce', broadcast_buffers=not a.no_ddp_bb)
+    comm = None
+    if a.comm != 'torch' and (world > 1 or a.force_buckets):
+        comm = A.NativeComm(wire='bf16' if a.comm == 'native-bf16' else 'fp32')
+    step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce', broadcast_buffers=not a.no_ddp_bb, comm=comm,
+                       force_buckets=a.force_buckets)
     g = torch.Generator().manual_seed(42 + rank)
     img = getattr(model, 'cfg', {}).get('img_size', 224)
     x = torch.randn(a.batch, 3, img, img, generator=g).cuda()
@@ -301,7 +309,7 @@ def main():
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype=a.math, data='synthetic',
                config=dict(workload=f'{a.model} train step (fwd + GA loss lam=-0.8 + bwd + all-reduce + {a.opt}), '
                                     f'batch {a.batch}/GPU, drop_path 0.2, synthetic 3x{img}x{img}',
-                           global_batch=a.batch * world, parallelism=f'dp{world}', dist_backend=backend,
+                           global_batch=a.batch * world, parallelism=f'dp{world}', dist_backend=backend, grad_exchange=a.comm,
                            allreduce_buckets=len(step.buckets), gflop_per_img=gflop),
                loss=round(loss_val, 4), library=A._lib.config_string())
 

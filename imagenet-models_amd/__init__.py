@@ -26,4 +26,5 @@ from .loss import ga_loss, heads_topk, accuracy_from_topk, map_loss, heads_mean_
 from .optim import create_optimizer_v2, FusedSGD, FusedAdamW, FusedLamb, CosineLRScheduler  # noqa: E402,F401
 from .mixup import Mixup  # noqa: E402,F401
 from .trainer import TrainStep, distribute_bn, make_buckets  # noqa: E402,F401
+from .comm import NativeComm  # noqa: E402,F401
 from .checkpoint import save_checkpoint, load_checkpoint, ModelEma  # noqa: E402,F401

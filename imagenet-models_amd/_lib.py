@@ -99,6 +99,15 @@ _SIGS = {
     'ga_version': ([], i32),
     'ga_last_error': ([C.c_char_p, C.c_size_t], i32),
     'ga_device_info': ([C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    'ga_comm_unique_id': ([vp], i32),
+    'ga_comm_init': ([C.POINTER(vp), i32, i32, vp], i32),
+    'ga_comm_destroy': ([vp], i32),
+    'ga_comm_info': ([vp, C.POINTER(i32), C.POINTER(i32)], i32),
+    'ga_allreduce_workspace': ([i64, i32], C.c_size_t),
+    'ga_allreduce_bucket': ([vp, vp, i64, i32, f32, vp, C.c_size_t, vp], i32),
+    'ga_reduce_scatter_bucket': ([vp, vp, vp, i64, f32, vp], i32),
+    'ga_allgather_bucket': ([vp, vp, vp, i64, vp], i32),
+    'ga_comm_broadcast': ([vp, vp, i64, i32, vp], i32),
     'ga_set_knob': ([C.c_char_p, i32], i32),
     'ga_unset_knob': ([C.c_char_p], i32),
     'ga_config_string': ([C.c_char_p, C.c_size_t], i32),

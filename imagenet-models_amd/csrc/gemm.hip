@@ -1189,7 +1189,13 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
     // buffer windows = the exact extent of each matrix: an offset beyond it (kOob, or anything a bug produces) reads as zeros or
     // drops the store instead of touching memory that is not the operand's
     auto extent = [](long rows, long ld, long cols, int esz) { return (unsigned)(((rows - 1) * ld + cols) * esz); };
-    const u32x4_s rsA = make_rsrc(Ab, extent(d.M, d.lda, d.K, 2)), rsB = make_rsrc(Bb, extent(d.N, d.ldb, d.K, 2));
+    // A-operand kinds: plain rows, or the 2 x 2 / stride-2 patches of an NHWC map (GA_A_PATCH2, the downsample convs): a patch row
+    // is TWO runs of 2C contiguous elements (taps (0,0)(0,1) and (1,0)(1,1)), so the lane offsets point at the patch origin and
+    // the second half of the K stages adds one image row (W * C elements) through the scalar offset -- no gather code in the loop
+    const bool patch2 = d.a_kind == GA_A_PATCH2;
+    const unsigned p2_row = patch2 ? (unsigned)(d.a_W * d.a_C - 2 * d.a_C) * 2u : 0u;   // bytes added from stage nk/2 on
+    const u32x4_s rsA = make_rsrc(Ab, patch2 ? extent(4L * d.M, d.a_C, d.a_C, 2) : extent(d.M, d.lda, d.K, 2)),
+                  rsB = make_rsrc(Bb, extent(d.N, d.ldb, d.K, 2));
     const int ktail = d.K & 31;                                    // > 0: the last stage is ragged
     unsigned aoff[4], boff[2];
     int ivt = blockIdx.x, ikt = 0;                                 // issue-side cursor: output tile, stage inside it
@@ -1200,7 +1206,13 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const long m = (long)tm_ * 256 + (wave * 4 + i) * 16 + (lane >> 2);
-                aoff[i] = m < d.M ? (unsigned)(m * d.lda + dchunk) * 2u : kOob;
+                if (patch2) {
+                    const unsigned OW = (unsigned)d.a_W >> 1, OH = (unsigned)d.a_H >> 1;
+                    const unsigned ox = (unsigned)m % OW, t = (unsigned)m / OW, oy = t % OH, b = t / OH;
+                    aoff[i] = m < d.M ? (unsigned)((((long)b * d.a_H + 2 * oy) * d.a_W + 2 * ox) * d.a_C + dchunk) * 2u : kOob;
+                } else {
+                    aoff[i] = m < d.M ? (unsigned)(m * d.lda + dchunk) * 2u : kOob;
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -1219,9 +1231,10 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
     auto dma_part = [&](int slot, int part) {
         const bool kdead = ktail && ikt == nk - 1 && dchunk >= ktail;
         const unsigned soff = (unsigned)ikt * 64u;
+        const unsigned soffA = soff + (2 * ikt >= nk ? p2_row : 0u);
         const unsigned dst = lds0 + slot * kR3Slot;
-        if (part == 0) blds16x2(rsA, kdead ? kOob : aoff[0], kdead ? kOob : aoff[1], soff, dst + (wave * 4) * 1024);
-        if (part == 1) blds16x2(rsA, kdead ? kOob : aoff[2], kdead ? kOob : aoff[3], soff, dst + (wave * 4 + 2) * 1024);
+        if (part == 0) blds16x2(rsA, kdead ? kOob : aoff[0], kdead ? kOob : aoff[1], soffA, dst + (wave * 4) * 1024);
+        if (part == 1) blds16x2(rsA, kdead ? kOob : aoff[2], kdead ? kOob : aoff[3], soffA, dst + (wave * 4 + 2) * 1024);
         if (part == 2) {
             blds16x2(rsB, kdead ? kOob : boff[0], kdead ? kOob : boff[1], soff, dst + 16384 + (wave * 2) * 1024);
             if (++ikt == nk) {
@@ -1993,9 +2006,12 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     const int r3 = GA_KNOB("NT_R3", -1);
     const bool forced = r3 >= 0;
     const int mask = forced ? r3 : 15;
-    if (!mask || d->dtype != GA_BF16 || d->a_kind != GA_A_PLAIN || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
-    if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || d->lda % 8 != 0 || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
-    if ((long)d->M * d->lda >= (1L << 30) || (long)d->N * d->ldb >= (1L << 30)) return false;              // 32-bit byte offsets
+    const bool patch2 = d->a_kind == GA_A_PATCH2;       // 2 x 2 / stride-2 patches (downsample convs): plain epilogue only
+    if (patch2 && (epi != EPI_PLAIN || d->a_C % 16 != 0 || d->K != 4 * d->a_C || 4L * d->M * d->a_C >= (1L << 30) || d->a_batch_mod || d->batch != 1))
+        return false;
+    if (!mask || d->dtype != GA_BF16 || (d->a_kind != GA_A_PLAIN && !patch2) || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
+    if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || (!patch2 && d->lda % 8 != 0) || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
+    if ((!patch2 && (long)d->M * d->lda >= (1L << 30)) || (long)d->N * d->ldb >= (1L << 30)) return false;   // 32-bit byte offsets
     if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) & 15) return false;
     if ((long)d->M * d->ldc >= (1L << 30) || d->c_kind != GA_C_PLAIN || d->c_f32) return false;
     if (epi == EPI_FC1 && d->C2 && (reinterpret_cast<uintptr_t>(d->C2) & 15)) return false;
@@ -2038,8 +2054,8 @@ bool want_pp(const ga_gemm_desc* d, int epi) {
 }
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
-int classify_epilogue(const ga_gemm_desc* d) {
-    if (d->a_kind != GA_A_PLAIN || d->a_act != GA_ACT_NONE || d->alpha != 1.0f || d->c_kind != GA_C_PLAIN || d->c_f32 ||
+int classify_epilogue(const ga_gemm_desc* d, bool allow_patch2 = false) {
+    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && d->a_kind == GA_A_PATCH2)) || d->a_act != GA_ACT_NONE || d->alpha != 1.0f || d->c_kind != GA_C_PLAIN || d->c_f32 ||
         d->relu_after)
         return EPI_GENERIC;
     const bool act0 = d->act == GA_ACT_NONE;
@@ -2176,6 +2192,10 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
     const int epi = classify_epilogue(d);
+    if (d->a_kind == GA_A_PATCH2 && classify_epilogue(d, true) == EPI_PLAIN && want_r3(d, EPI_PLAIN)) {
+        launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map
+        return ga_check_launch("ga_gemm");
+    }
     if (want_r3(d, epi)) {
         switch (epi) {
             case EPI_PLAIN: launch_nt_r3<EPI_PLAIN>(d, s); break;

@@ -62,9 +62,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
             }
         }
     }
-    // U rows per thread and iteration: their loads are issued back to back, so every lane keeps U * (chunks per lane) 16-byte
-    // loads in flight (one row at a time left the C = 96 .. 384 norms at 3 - 4.5 TB/s: too few bytes in flight per CU)
-    constexpr int U = 2;
+    // U rows per thread and iteration (their loads issued back to back).  Measured round 3, same box, alternating builds
+    // (tools/ew_bench.py): U = 2 changes nothing forward (0.053 ms = 5.8 TB/s at C = 96, M = 802,816 either way) -- the
+    // 2048-thread-per-CU occupancy already keeps enough loads in flight -- so the simple form stays
+#ifdef GA_LN_UNROLL
+    constexpr int U = GA_LN_UNROLL;       // (A/B builds)
+#else
+    constexpr int U = 1;
+#endif
     const long rstep = (long)gridDim.x * rpb;
     for (long row0 = (long)blockIdx.x * rpb + rib; row0 < rows; row0 += U * rstep) {
         float v[U][kMaxCh][E];
@@ -156,8 +161,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
                 wv[j][e] = (w && ci < nch) ? w[ci * E + e] : 1.f;
             }
     }
-    // U rows per thread and iteration (loads of all of them first): more 16-byte loads in flight per lane for the narrow rows
-    constexpr int U = AFF ? (kMaxCh == 1 ? 2 : 1) : (kMaxCh == 1 ? 4 : 2);
+    // U rows per thread and iteration: measured SLOWER backward with U = 2 / 4 (block norm of C = 96: 0.097 vs 0.079 ms, affine
+    // form 0.149 vs 0.115; same box, alternating builds): the extra registers cost occupancy, which is what keeps loads in flight
+#ifdef GA_LN_UNROLL
+    constexpr int U = GA_LN_UNROLL;
+#else
+    constexpr int U = 1;
+#endif
     const long rstep = (long)gridDim.x * rpb;
     for (long row0 = (long)blockIdx.x * rpb + rib; row0 < rows; row0 += U * rstep) {
         float gv[U][kMaxCh][E], xh[U][kMaxCh][E], rsv[U], muv[U];

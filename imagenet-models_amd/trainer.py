@@ -65,7 +65,14 @@ def distribute_bn(model, world, reduce=False, group=None):
 class TrainStep:
     def __init__(self, model, optimizer, batch, lam=0.0, loss='ce', smoothing=0.0, grad_accumulation=1,
                  process_group=None, clip_grad=None, clip_mode='norm', broadcast_buffers=True, bucket_elems=BUCKET_ELEMS,
-                 mixup_fn=None, bce_target_thresh=None):
+                 mixup_fn=None, bce_target_thresh=None, comm=None, force_buckets=False, nan_guard=False):
+        """comm: an imagenet_models_amd.NativeComm -- the gradient buckets (and the BatchNorm-buffer broadcast) go through the
+        library's own RCCL entry points (ga_allreduce_bucket on a side stream) instead of torch.distributed.
+        force_buckets: take the segmented-backward + bucketed-reduction path even with one rank (tests: the real collective
+        path on a one-GPU box).
+        nan_guard: the device-side counterpart of MAP/train.py:887-891 (all_gather of the loss + isnan + exit): the loss value
+        rides in the LAST gradient bucket's reduction as one extra element; `last_loss_sum` (a device tensor, the sum of the
+        ranks' scaled losses) can be inspected by the caller at its logging interval -- no host synchronisation per step."""
         self.model, self.opt = model, optimizer
         self.eng = model.engine(batch, True)
         self.lam, self.kind, self.smoothing = lam, _KINDS[loss], smoothing
@@ -82,7 +89,13 @@ class TrainStep:
         self.flat_g = st['grads']
         self.flat_buffers = st['buffers']
         self.broadcast_buffers = broadcast_buffers and self.flat_buffers.numel() > 0     # NativeDDP default (GA/train.py:514)
-        self.buckets = make_buckets(st, model.grad_groups(), bucket_elems) if self.world > 1 else []
+        self.comm = comm
+        if comm is not None and comm.world != self.world:
+            raise ValueError(f'comm has {comm.world} ranks, the process group {self.world}')
+        self.bucketed = self.world > 1 or force_buckets
+        self.buckets = make_buckets(st, model.grad_groups(), bucket_elems) if self.bucketed else []
+        self.nan_guard = nan_guard
+        self.last_loss_sum = torch.zeros(1, device=self.flat_g.device) if nan_guard else None
         # gradient clipping (timm dispatch_clip_grad through NativeScaler, GA/train.py:312-333): global L2 norm or
         # value clamp over the flat gradient buffer, after the all-reduce, before the optimizer
         if clip_mode not in ('norm', 'value', 'agc'):
@@ -120,8 +133,14 @@ class TrainStep:
         eng = self.eng
         self.model.check_flat_generation(self.gen, 'TrainStep')
         last_micro = (self.micro + 1) % self.accum == 0
-        if self.world > 1 and self.broadcast_buffers:
-            dist.broadcast(self.flat_buffers, 0, group=self.pg)      # rank 0's BatchNorm statistics before every forward
+        if self.world > 1 and self.broadcast_buffers:                # rank 0's BatchNorm statistics before every forward
+            if self.comm is not None:
+                main = torch.cuda.current_stream()
+                self.comm.after(main)
+                self.comm.broadcast(self.flat_buffers, 0)
+                self.comm.join(main)
+            else:
+                dist.broadcast(self.flat_buffers, 0, group=self.pg)
         # the reference divides the loss by grad_accumulation (train.py:750); DDP averages over ranks
         scale = 1.0 / (self.accum * self.world)
         if self.mixup_fn is not None:
@@ -130,14 +149,28 @@ class TrainStep:
             x, target = self.mixup_fn(eng._normalize_u8(x), target)
         loss = eng.forward_loss(x, target, self.lam, self.kind, self.smoothing, scale, self.bce_threshold)
         bwd = eng.bwd
-        if self.world > 1 and last_micro:
+        if self.bucketed and last_micro:
             works, pos = [], 0
+            main = torch.cuda.current_stream()
             for mark, a, b in self.buckets:
                 stop = len(bwd.calls) if mark == 'end' else bwd.marks[mark]
                 if stop > pos:
                     bwd.run_range(pos, stop)
                     pos = stop
-                works.append(dist.all_reduce(self.flat_g[a:b], group=self.pg, async_op=True))
+                if self.comm is not None:            # RCCL through the C ABI, on the comm stream, behind this segment
+                    self.comm.after(main)
+                    self.comm.allreduce(self.flat_g[a:b])
+                elif self.world > 1 or dist.is_initialized():
+                    works.append(dist.all_reduce(self.flat_g[a:b], group=self.pg, async_op=True))
+            if self.nan_guard:                        # one float beside the last bucket: sum over ranks of the scaled loss
+                self.last_loss_sum.copy_(loss.reshape(1), non_blocking=True)
+                if self.comm is not None:
+                    self.comm.after(main)
+                    self.comm.allreduce(self.last_loss_sum)
+                elif self.world > 1 or dist.is_initialized():
+                    works.append(dist.all_reduce(self.last_loss_sum, group=self.pg, async_op=True))
+            if self.comm is not None:
+                self.comm.join(main)
             for w in works:
                 w.wait()
         else:

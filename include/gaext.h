@@ -597,6 +597,33 @@ int ga_rowscale(const void* x, const float* s, void* y, int64_t n, int64_t elems
 int ga_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, ga_stream_t stream);
 int ga_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, ga_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Gradient exchange over RCCL / xGMI.  replaces: NativeDDP(model, device_ids=[local_rank]) and its bucket reducer
+ * (GA/train.py:514, MAP/train.py:576), the per-forward buffer broadcast (`broadcast_buffers`), timm distribute_bn
+ * (GA/train.py:665-674).  One communicator per process (one process per GPU).  The 128-byte id comes from rank 0
+ * (ga_comm_unique_id) and reaches the other ranks through the caller's side channel (torch.distributed's store in
+ * imagenet_models_amd.comm).  librccl is resolved at run time: GA_ERR_UNSUPPORTED when it cannot be loaded.
+ * Every call only enqueues on `stream`; buffers are caller-owned device memory.
+ *   ga_allreduce_bucket:      grads[0..n) := scale * sum over ranks, in place.  wire_dtype GA_F32: ncclAllReduce on the slice;
+ *                             GA_BF16: packed to bf16 in `workspace` (ga_allreduce_workspace(n, GA_BF16) bytes), reduced in
+ *                             bf16, unpacked -- half the wire bytes, bf16 summation (an option, not the default).
+ *   ga_reduce_scatter_bucket: shard[0..n_per_rank) := scale * sum over ranks of grads[rank*n_per_rank ..] (grads holds
+ *                             world * n_per_rank elements); ga_allgather_bucket is its inverse.  Together they are the
+ *                             all-reduce with room for a sharded (ZeRO-1) optimizer step in between.
+ *   ga_comm_broadcast:        n_f32 floats from `root` (initial parameters, BatchNorm running statistics).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct ga_comm* ga_comm_t;
+int ga_comm_unique_id(void* id128);
+int ga_comm_init(ga_comm_t* comm, int rank, int world, const void* id128);
+int ga_comm_destroy(ga_comm_t comm);
+int ga_comm_info(ga_comm_t comm, int* rank, int* world);
+size_t ga_allreduce_workspace(int64_t n, int wire_dtype);
+int ga_allreduce_bucket(ga_comm_t comm, float* grads, int64_t n, int wire_dtype, float scale, void* workspace, size_t ws_bytes,
+                        ga_stream_t stream);
+int ga_reduce_scatter_bucket(ga_comm_t comm, const float* grads, float* shard, int64_t n_per_rank, float scale, ga_stream_t stream);
+int ga_allgather_bucket(ga_comm_t comm, const float* shard, float* full, int64_t n_per_rank, ga_stream_t stream);
+int ga_comm_broadcast(ga_comm_t comm, void* buf, int64_t n_f32, int root, ga_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,12 @@ import os
 
 import torch
 
-BF16_REL, BF16_COS = 0.1, 0.99          # the bf16-mode gate of every model test
+# The bf16-mode gate of every model test.  Calibrated on MI355X (round 3, every family, GA_GRADCHECK_REPORT=1): the worst tensors of
+# the throughput mode sit at rel 0.13 .. 0.25, cos 0.969 .. 0.993 (small per-channel parameters -- depthwise biases, LayerNorm /
+# BatchNorm affine gradients -- that sum bf16-rounded activations over 10^4 .. 10^6 rows; the weight matrices are at rel <= 0.1).
+# rel <= 0.3 and cos >= 0.95 leave no room for a sign error (rel 2, cos -1), a dropped term of a third of the gradient or a
+# wrong scale by more than 30 %.
+BF16_REL, BF16_COS = 0.3, 0.95
 REPORT_ONLY = os.environ.get('GA_GRADCHECK_REPORT', '') == '1'    # calibration runs: print, do not assert
 
 

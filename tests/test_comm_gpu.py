@@ -1,0 +1,100 @@
+"""GPU: the RCCL side of the boundary on the one GPU the test box has.
+
+  * imagenet_models_amd.NativeComm (ga_comm_* / ga_allreduce_bucket / ga_reduce_scatter_bucket / ga_allgather_bucket /
+    ga_comm_broadcast, include/gaext.h) with ONE rank: every collective is a real RCCL call on a real communicator and must
+    be the identity (x scale; bf16 wire: the bf16 rounding of the input);
+  * TrainStep's segmented backward + bucketed reduction (the path N > 1 takes, GA/train.py:514) forced on with one rank, the
+    buckets going through the native communicator on its side stream: the step must equal the plain one-stream step;
+  * the same through torch.distributed's `nccl` backend (= RCCL) with world_size 1, in a child process (tests/nccl_ws1_check.py).
+Reference: NativeDDP's reducer averages gradients over ranks; with one rank the reduced gradient is the local one."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_native_comm_single_rank_collectives():
+    import imagenet_models_amd as A
+    c = A.NativeComm(wire='fp32')
+    assert (c.rank, c.world) == (0, 1)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn((1 << 20) + 3, device='cuda', generator=g)
+    main = torch.cuda.current_stream()
+    y = x.clone()
+    c.after(main)
+    c.allreduce(y)
+    c.join(main)
+    assert torch.equal(y, x)
+    c.after(main)
+    c.allreduce(y, scale=0.25)
+    c.join(main)
+    assert torch.equal(y, x * 0.25)
+    shard, full = torch.empty_like(x), torch.empty_like(x)
+    c.after(main)
+    c.reduce_scatter(x, shard, scale=2.0)
+    c.allgather(shard, full)
+    c.broadcast(full, 0)
+    c.join(main)
+    assert torch.equal(full, x * 2.0)
+    cb = A.NativeComm(wire='bf16')
+    z = x[:(1 << 20)].clone()                   # (16-byte aligned slice)
+    cb.after(main)
+    cb.allreduce(z)
+    cb.join(main)
+    assert torch.equal(z, x[:(1 << 20)].bfloat16().float())
+    torch.cuda.synchronize()
+    c.close()
+    cb.close()
+
+
+def _small_model():
+    import imagenet_models_amd as A
+    from oracle import ga_convnext_oracle as O
+    cfg = O.make_cfg(dims=(16, 32, 64, 128, 128), depths=(1, 1, 6, 1, 1), gram_dim=32, dim_embed=64, num_classes=40, naggre=2)
+    sd = O.fill_state(cfg)
+    m = A.GA_ConvNeXt(num_classes=40, depths=cfg['depths'], dims=cfg['dims'], gram_embedding_gropus=cfg['gram_groups'],
+                      dim_embed=cfg['dim_embed'], stage3_naggre=cfg['naggre'], gram_dim=cfg['gram_dim'], math_mode='fp32')
+    m.load_state_dict(sd)
+    return m.cuda().train(), O
+
+
+@pytest.mark.parametrize('wire', ['fp32', 'bf16'])
+def test_trainstep_buckets_through_native_comm_equal_plain_step(wire):
+    import imagenet_models_amd as A
+    B = 8
+    res = {}
+    for tag in ('plain', 'native'):
+        m, O = _small_model()
+        opt = A.create_optimizer_v2(m, opt='adamw', lr=1e-2, weight_decay=0.05)
+        x = O.gen_input(B, seed=2).cuda()
+        y = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+        if tag == 'native':
+            comm = A.NativeComm(wire=wire)
+            step = A.TrainStep(m, opt, B, lam=-0.8, comm=comm, force_buckets=True, bucket_elems=50_000, nan_guard=True)
+            assert len(step.buckets) >= 4
+        else:
+            step = A.TrainStep(m, opt, B, lam=-0.8)
+        loss = step(x, y)
+        torch.cuda.synchronize()
+        res[tag] = (float(loss), m.flat_state()['params'].clone())
+        if tag == 'native':
+            assert abs(float(step.last_loss_sum) - float(loss)) <= (1e-6 if wire == 'fp32' else 1e-2) * abs(float(loss))
+            comm.close()
+    assert abs(res['plain'][0] - res['native'][0]) < 1e-6 * abs(res['plain'][0])
+    d = (res['plain'][1] - res['native'][1]).abs().max()
+    ref = res['plain'][1].abs().max()
+    # AdamW's first step moves every weight by ~lr whatever the gradient's size: the fp32 wire must reproduce the plain step to
+    # atomics noise; the bf16 wire rounds every gradient to 8 bits, which AdamW's normalisation mostly hides -- bounded, not equal
+    assert float(d) <= (2e-5 if wire == 'fp32' else 2.5e-2) * float(ref), (float(d), float(ref))
+
+
+def test_trainstep_buckets_through_torch_nccl_world1():
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_ws1_check.py')], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and 'NCCL_WS1_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -147,6 +147,27 @@ def test_gemm_patch2_and_unpatch(dt):
     assert_close(DX, xx.grad.permute(0, 2, 3, 1), tol(dt), 'patch2 dgrad')
 
 
+@pytest.mark.parametrize('geom', [(2, 8, 12, 16, 24), (3, 28, 28, 96, 192), (5, 14, 14, 384, 768), (1, 10, 6, 48, 136), (40, 56, 56, 96, 192)])
+def test_gemm_patch2_ring3_form_bf16(geom, knobs):
+    """the downsample conv (2 x 2 / stride 2, ga_convnext.py:127) on the 3-slot ring form: patch rows fetched as two runs of 2C
+    elements by LDS-DMA (lane offsets at the patch origin, the second run through the scalar offset), bias epilogue"""
+    ops = _imp()
+    knobs(NT_R3=15)
+    dt = torch.bfloat16
+    g = gen(14)
+    Bn, H, W, Cc, N = geom
+    x, X = rnd((Bn, H, W, Cc), dt, g)
+    w, _ = rnd((N, Cc, 2, 2), dt, g, 0.5 / math.sqrt(Cc))
+    bias = torch.randn(N, generator=g)
+    Wm = w.permute(0, 2, 3, 1).reshape(N, 4 * Cc).contiguous()
+    M = Bn * (H // 2) * (W // 2)
+    Cout = torch.empty(M, N, dtype=dt, device='cuda')
+    ops.Plan(eager=True).gemm(X, Wm.to(dt).cuda(), Cout, M, N, 4 * Cc, ops.ga_dtype(dt), a_kind=ops.A_PATCH2, a_dims=(H, W, Cc),
+                              bias=bias.cuda())
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=2).permute(0, 2, 3, 1).reshape(M, N)
+    assert_close(Cout, ref, 2e-2, 'patch2 on the ring form')
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_gemm_conv3_fwd_and_dgrad(dt):
     ops = _imp()

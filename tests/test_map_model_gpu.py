@@ -12,6 +12,8 @@ import numpy as np
 import pytest
 import torch
 
+from _gradcheck import assert_grads_close, BF16_REL, BF16_COS
+
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
@@ -132,7 +134,10 @@ def _train_compare(mode, golden, tol_out, tol_loss, tol_grad, drop_path=0.0, hea
     e_bn = max(rel(new_sd[n], ostats[n].float()) for n in ostats if not n.endswith('num_batches_tracked'))
     print(f'[{golden} {mode} dp={drop_path} drop={head_drop}] logits {e_out:.2e} loss {e_loss:.2e} bn {e_bn:.2e} worst grads {worst}')
     assert e_out < tol_out and e_loss < tol_loss
-    assert worst[0][1] < tol_grad, worst
+    if mode == 'bf16':      # whole-tensor gates (tests/_gradcheck.py): norm-relative error and direction of every gradient
+        assert_grads_close(grads, ograds, BF16_REL, BF16_COS, f'{golden} bf16')
+    else:
+        assert worst[0][1] < tol_grad, worst
     assert e_bn < max(tol_out, 2e-3)
     return z, outs, loss, grads
 

@@ -5,6 +5,8 @@ multi_group_loss, every gradient.  fp32 mode: logits / loss 1e-3, gradients 2e-2
 import pytest
 import torch
 
+from _gradcheck import assert_grads_close, BF16_REL, BF16_COS
+
 pytestmark = pytest.mark.gpu
 
 V7 = dict(img_size=64, patch_size=16, embed_dim=64, depth=3, vit_heads=1, num_classes=40, last_dim=64, n_groups=2, n_tokens=2,
@@ -95,7 +97,11 @@ def test_train_step(over, mode, tols, dp):
     new_sd = m.state_dict()
     e_bn = max(rel(new_sd[n], ostats[n].float()) for n in ostats if not n.endswith('num_batches_tracked'))
     print(f'[map_vit {over["embed_dim"]} {mode} dp={dp}] logits {e_out:.2e} loss {e_loss:.2e} bn {e_bn:.2e} worst grads {worst}')
-    assert e_out < tols[0] and e_loss < tols[1] and worst[0][1] < tols[2], worst
+    assert e_out < tols[0] and e_loss < tols[1]
+    if mode == 'bf16':      # whole-tensor gates (tests/_gradcheck.py): norm-relative error and direction of every gradient
+        assert_grads_close(grads, ograds, BF16_REL, BF16_COS, 'bf16 train step')
+    else:
+        assert worst[0][1] < tols[2], worst
     assert e_bn < max(tols[0], 2e-3)
 
 

@@ -63,7 +63,12 @@ for stage, (C, res) in enumerate([(96, 56), (192, 28), (384, 14), (768, 7)]):
         report(f's{stage} layernorm fwd', timeit(p), e * M * C * 2)
         dwv = torch.zeros(C, device='cuda'); dbv = torch.zeros(C, device='cuda')
         p = ops.Plan(); p.layernorm_bwd(z, y, None, rstd, None, None, x, dwv, dbv, M, C, True, dt)
-        report(f's{stage} layernorm bwd', timeit(p), e * M * C * 3)
+        report(f's{stage} layernorm bwd (affine grads)', timeit(p), e * M * C * 3)
+        p = ops.Plan(); p.layernorm_bwd(z, y, None, rstd, None, None, x, None, None, M, C, True, dt)
+        report(f's{stage} layernorm bwd (block norm)', timeit(p), e * M * C * 3)
+        sc = torch.rand(B, device='cuda')
+        p = ops.Plan(); p.rowscale(x, sc, y, M * C, res * res * C, dt)
+        report(f's{stage} rowscale', timeit(p), e * M * C * 2)
     if 'bn' in WHAT and stage == 2:
         # bottleneck-like shapes: (B*196, 192) and (B*196, 768)
         for Cb in (192, 768):
