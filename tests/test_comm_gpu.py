@@ -70,7 +70,7 @@ def test_trainstep_buckets_through_native_comm_equal_plain_step(wire):
     res = {}
     for tag in ('plain', 'native'):
         m, O = _small_model()
-        opt = A.create_optimizer_v2(m, opt='adamw', lr=1e-2, weight_decay=0.05)
+        opt = A.create_optimizer_v2(m, opt='sgd', lr=1e-2, momentum=0.9, weight_decay=0.05)
         x = O.gen_input(B, seed=2).cuda()
         y = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(2)).cuda()
         if tag == 'native':
@@ -79,18 +79,29 @@ def test_trainstep_buckets_through_native_comm_equal_plain_step(wire):
             assert len(step.buckets) >= 4
         else:
             step = A.TrainStep(m, opt, B, lam=-0.8)
+        p0 = m.flat_state()['params'].clone()
         loss = step(x, y)
         torch.cuda.synchronize()
         res[tag] = (float(loss), m.flat_state()['params'].clone())
+        slices = m.flat_state()['slices']
         if tag == 'native':
             assert abs(float(step.last_loss_sum) - float(loss)) <= (1e-6 if wire == 'fp32' else 1e-2) * abs(float(loss))
             comm.close()
     assert abs(res['plain'][0] - res['native'][0]) < 1e-6 * abs(res['plain'][0])
-    d = (res['plain'][1] - res['native'][1]).abs().max()
-    ref = res['plain'][1].abs().max()
-    # AdamW's first step moves every weight by ~lr whatever the gradient's size: the fp32 wire must reproduce the plain step to
-    # atomics noise; the bf16 wire rounds every gradient to 8 bits, which AdamW's normalisation mostly hides -- bounded, not equal
-    assert float(d) <= (2e-5 if wire == 'fp32' else 2.5e-2) * float(ref), (float(d), float(ref))
+    _assert_same_update(res['plain'][1], res['native'][1], p0, slices, 1e-3 if wire == 'fp32' else 2e-2)
+
+
+def _assert_same_update(pa, pb, p0, slices, tol):
+    """SGD: the parameter change is lr x gradient, so comparing the two steps' updates slice by slice compares the reduced
+    gradients.  Per slice: |difference| <= tol x (slice max) + 1e-4 x (global max) -- the criterion of tests/ddp_check.py: slices
+    whose true gradient is zero (biases in front of a train-mode BatchNorm) hold only atomics / cancellation noise, which differs
+    between any two backward passes; a slice reduced before it was complete, or twice, is off by its own magnitude."""
+    ua, ub = pa - p0, pb - p0
+    umax = float(ua.abs().max())
+    for n, (off, k) in slices.items():
+        d = float((ua[off:off + k] - ub[off:off + k]).abs().max())
+        ref = float(ua[off:off + k].abs().max())
+        assert d <= tol * ref + 1e-4 * umax, f'{n}: updates differ by {d:.3e} (slice max {ref:.3e}, global max {umax:.3e})'
 
 
 def test_trainstep_buckets_through_torch_nccl_world1():
