@@ -1400,7 +1400,16 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
 #pragma unroll
             for (int j = 0; j < 8; ++j) csum[j] = csq[j] = 0.f;
             const bool do_csum = (EPI == EPI_PLAIN || EPI == EPI_DG2) && d.colsum != nullptr;
-            const u32x4_s rsC = make_rsrc(reinterpret_cast<bf16_t*>(d.C) + (long)z * d.strideC, extent(d.M, d.ldc, d.N, 2));
+            // C-output kinds: plain rows, or GA_C_UNPATCH2 (the downsample conv's data gradient): row m = (b, oy, ox), the 8-column
+            // piece n = (tap, channel) goes to pixel (2 oy + tap / 2, 2 ox + tap % 2) of the NHWC gradient map
+            const bool unpatch2 = EPI == EPI_PLAIN && d.c_kind == GA_C_UNPATCH2;
+            const u32x4_s rsC = make_rsrc(reinterpret_cast<bf16_t*>(d.C) + (long)z * d.strideC,
+                                          unpatch2 ? extent(4L * d.M, d.c_C, d.c_C, 2) : extent(d.M, d.ldc, d.N, 2));
+            unsigned up_col = 0;
+            if (unpatch2 && n_ok) {
+                const int tap = n / d.c_C, ch = n - tap * d.c_C;
+                up_col = (unsigned)(((tap >> 1) * d.c_W + (tap & 1)) * d.c_C + ch);
+            }
             const u32x4_s rsC2 = make_rsrc((EPI == EPI_FC1 && d.C2) ? reinterpret_cast<bf16_t*>(d.C2) + (long)z * d.strideC : nullptr,
                                            (EPI == EPI_FC1 && d.C2) ? extent(d.M, d.ldc, d.N, 2) : 0u);
 #pragma unroll
@@ -1436,7 +1445,12 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
                     float v[8] = {lo[0] + bias[0], lo[1] + bias[1], lo[2] + bias[2], lo[3] + bias[3],
                                   hi[0] + bias[4], hi[1] + bias[5], hi[2] + bias[6], hi[3] + bias[7]};
                     const bool live = n_ok && m < d.M;
-                    const unsigned coff = live ? (unsigned)(m * d.ldc + n) * 2u : kOob;
+                    unsigned coff = live ? (unsigned)(m * d.ldc + n) * 2u : kOob;
+                    if (unpatch2 && live) {
+                        const unsigned OW = (unsigned)d.c_W >> 1, OH = (unsigned)d.c_H >> 1;
+                        const unsigned ox = (unsigned)m % OW, t = (unsigned)m / OW, oy = t % OH, b = t / OH;
+                        coff = (unsigned)((((long)b * d.c_H + 2 * oy) * d.c_W + 2 * ox) * d.c_C + up_col) * 2u;
+                    }
                     if constexpr (EPI == EPI_FC1) {
                         float w[8];
 #pragma unroll
@@ -2013,7 +2027,10 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || (!patch2 && d->lda % 8 != 0) || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
     if ((!patch2 && (long)d->M * d->lda >= (1L << 30)) || (long)d->N * d->ldb >= (1L << 30)) return false;   // 32-bit byte offsets
     if ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) | reinterpret_cast<uintptr_t>(d->C)) & 15) return false;
-    if ((long)d->M * d->ldc >= (1L << 30) || d->c_kind != GA_C_PLAIN || d->c_f32) return false;
+    const bool unpatch2 = d->c_kind == GA_C_UNPATCH2;   // scatter of the downsample conv's data gradient: plain epilogue only
+    if (unpatch2 && (epi != EPI_PLAIN || d->colsum || d->c_C % 8 != 0 || d->N != 4 * d->c_C || 4L * d->M * d->c_C >= (1L << 30) || d->batch != 1))
+        return false;
+    if ((!unpatch2 && (long)d->M * d->ldc >= (1L << 30)) || (d->c_kind != GA_C_PLAIN && !unpatch2) || d->c_f32) return false;
     if (epi == EPI_FC1 && d->C2 && (reinterpret_cast<uintptr_t>(d->C2) & 15)) return false;
     if (epi == EPI_DG2 && (d->ldh % 8 != 0 || (reinterpret_cast<uintptr_t>(d->H) & 15) || (long)d->M * d->ldh >= (1L << 30))) return false;
     if (epi == EPI_FC2 && (d->ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(d->R) & 15) || (long)d->M * d->ldr >= (1L << 30))) return false;
@@ -2055,7 +2072,8 @@ bool want_pp(const ga_gemm_desc* d, int epi) {
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
 int classify_epilogue(const ga_gemm_desc* d, bool allow_patch2 = false) {
-    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && d->a_kind == GA_A_PATCH2)) || d->a_act != GA_ACT_NONE || d->alpha != 1.0f || d->c_kind != GA_C_PLAIN || d->c_f32 ||
+    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && d->a_kind == GA_A_PATCH2)) || d->a_act != GA_ACT_NONE || d->alpha != 1.0f ||
+        (d->c_kind != GA_C_PLAIN && !(allow_patch2 && d->c_kind == GA_C_UNPATCH2)) || d->c_f32 ||
         d->relu_after)
         return EPI_GENERIC;
     const bool act0 = d->act == GA_ACT_NONE;
@@ -2192,8 +2210,8 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
     const int epi = classify_epilogue(d);
-    if (d->a_kind == GA_A_PATCH2 && classify_epilogue(d, true) == EPI_PLAIN && want_r3(d, EPI_PLAIN)) {
-        launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map
+    if ((d->a_kind == GA_A_PATCH2 || d->c_kind == GA_C_UNPATCH2) && classify_epilogue(d, true) == EPI_PLAIN && want_r3(d, EPI_PLAIN)) {
+        launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map / its data gradient
         return ga_check_launch("ga_gemm");
     }
     if (want_r3(d, epi)) {

@@ -166,6 +166,15 @@ def test_gemm_patch2_ring3_form_bf16(geom, knobs):
                               bias=bias.cuda())
     ref = F.conv2d(x.permute(0, 3, 1, 2), w, bias, stride=2).permute(0, 2, 3, 1).reshape(M, N)
     assert_close(Cout, ref, 2e-2, 'patch2 on the ring form')
+    # its data gradient: dX = unpatch(dY @ Wm) -- rows scattered back to the 2 x 2 pixels of the NHWC map (GA_C_UNPATCH2)
+    if N % 8 == 0:
+        dy, DY = rnd((M, N), dt, g)
+        DX = torch.zeros(Bn, H, W, Cc, dtype=dt, device='cuda')
+        ops.Plan(eager=True).gemm(DY, Wm.t().contiguous().to(dt).cuda(), DX, M, 4 * Cc, N, ops.ga_dtype(dt), c_kind=ops.C_UNPATCH2,
+                                  c_dims=(H, W, Cc))
+        xx = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+        F.conv2d(xx, w.to(dt).float(), stride=2).backward(dy.reshape(Bn, H // 2, W // 2, N).permute(0, 3, 1, 2))
+        assert_close(DX, xx.grad.permute(0, 2, 3, 1), 2e-2, 'unpatch2 on the ring form')
 
 
 @pytest.mark.parametrize('dt', DT)
