@@ -167,6 +167,9 @@ _SIGS = {
     'ga_map_tokens_bwd': ([vp, vp, i32, i32, i32, i32, i32, vp], i32),
     'ga_class_attn_mt_fwd': ([vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp], i32),
     'ga_class_attn_mt_bwd': ([vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_mt_ia_fwd': ([vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp], i32),
+    'ga_class_attn_mt_ia_bwd': ([vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32,
+                                 vp], i32),
     'ga_map_loss_fwd_bwd': ([vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, f32, f32, i32, vp], i32),
     'ga_gelu_fwd': ([vp, vp, i64, i32, vp], i32),
     'ga_gelu_bwd': ([vp, vp, vp, i64, i32, vp], i32),

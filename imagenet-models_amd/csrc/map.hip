@@ -274,6 +274,200 @@ __global__ __launch_bounds__(512) void mt_attn_bwd_kernel(const T* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// `interactive` class attention (map.py:96-98,130-136): two linears over the HEAD axis around the softmax,
+//     S = scale q k^T;  U = S + W1 S + b1;  A = softmax_n(U);  Pm = A + W2 A + b2;  D = Pm * mask;  out = D v
+// (W1, W2 [heads][heads], the "S" / "A" above indexed [head][key]).  Used by the MAP heads of map_resnet50 / map_mobilenet_v1 /
+// map_faster_vit_3_224; none of the registered in-scope models turns it on, so these kernels are written for clarity, not
+// speed: one workgroup per sample, fp32 in LDS, a thread per (head, key) for the head mixing, a wave per head for the softmax.
+// Saved for backward: P = A (the softmax output), as in the plain kernels.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kIaThr = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kIaThr) void mt_attn_ia_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv_cls, const T* __restrict__ kv_tok,
+                                                               long tok_ld, T* __restrict__ out, float* __restrict__ P,
+                                                               const float* __restrict__ mask, const float* __restrict__ W1,
+                                                               const float* __restrict__ b1, const float* __restrict__ W2,
+                                                               const float* __restrict__ b2, int Tn, int N, int heads, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, HN = heads * N;
+    float* S = sm;              // [heads][N]
+    float* A = S + HN;          // [heads][N]
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const T* kvc = kv_cls + b * Tn * 2 * E;
+    const T* kvt = kv_tok + b * (N - Tn) * tok_ld - (long)Tn * tok_ld;
+    auto row = [&](int n) { return n < Tn ? kvc + (long)n * 2 * E : kvt + (long)n * tok_ld; };
+    for (int t = 0; t < Tn; ++t) {
+        const T* qt = q + (b * Tn + t) * E;
+        for (int i = tid; i < HN; i += kIaThr) {                 // raw scores
+            const int h = i / N, n = i - h * N;
+            const T* kr = row(n) + h * hd;
+            float s = 0.f;
+            for (int e = 0; e < hd; ++e) s = fmaf(elt<T>::ld(qt + h * hd + e), elt<T>::ld(kr + e), s);
+            S[i] = s * scale;
+        }
+        __syncthreads();
+        for (int i = tid; i < HN; i += kIaThr) {                 // U = S + W1 S + b1
+            const int h = i / N, n = i - h * N;
+            float u = S[i] + b1[h];
+            for (int g = 0; g < heads; ++g) u = fmaf(W1[h * heads + g], S[g * N + n], u);
+            A[i] = u;
+        }
+        __syncthreads();
+        for (int h = wave; h < heads; h += kIaThr / 64) {        // softmax over the keys, a wave per head
+            float* ar = A + h * N;
+            float mx = -3.0e38f;
+            for (int n = lane; n < N; n += 64) mx = fmaxf(mx, ar[n]);
+            mx = wave_max(mx);
+            float sum = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                const float e = __expf(ar[n] - mx);
+                ar[n] = e;
+                sum += e;
+            }
+            const float inv = 1.f / wave_sum(sum);
+            const long pofs = ((b * Tn + t) * heads + h) * N;
+            for (int n = lane; n < N; n += 64) {
+                const float a = ar[n] * inv;
+                ar[n] = a;
+                P[pofs + n] = a;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < HN; i += kIaThr) {                 // D = (A + W2 A + b2) * mask   (into S)
+            const int h = i / N, n = i - h * N;
+            float pm = A[i] + b2[h];
+            for (int g = 0; g < heads; ++g) pm = fmaf(W2[h * heads + g], A[g * N + n], pm);
+            S[i] = mask ? pm * mask[((b * Tn + t) * heads + h) * N + n] : pm;
+        }
+        __syncthreads();
+        for (int c = tid; c < E; c += kIaThr) {                  // out = D v
+            const int h = c / hd;
+            float o = 0.f;
+            for (int n = 0; n < N; ++n) o = fmaf(S[h * N + n], elt<T>::ld(row(n) + E + c), o);
+            elt<T>::st(out + (b * Tn + t) * E + c, o);
+        }
+        __syncthreads();
+    }
+}
+
+// backward: dq, dkv_cls, dkv_tok rows (overwritten); dW1, db1, dW2, db2 accumulated (fp32 atomics over the samples)
+template <typename T>
+__global__ __launch_bounds__(kIaThr) void mt_attn_ia_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ q, const T* __restrict__ kv_cls,
+                                                               const T* __restrict__ kv_tok, long tok_ld, const float* __restrict__ P,
+                                                               const float* __restrict__ mask, const float* __restrict__ W1,
+                                                               const float* __restrict__ W2, const float* __restrict__ b2,
+                                                               T* __restrict__ dq, T* __restrict__ dkv_cls, T* __restrict__ dkv_tok,
+                                                               long dtok_ld, float* __restrict__ dW1, float* __restrict__ db1,
+                                                               float* __restrict__ dW2, float* __restrict__ db2, int Tn, int N, int heads,
+                                                               int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int E = heads * hd, HN = heads * N;
+    float* Dall = sm;                   // [T][heads][N]   D = Pm * mask          (weights of dv)
+    float* dSall = Dall + Tn * HN;      // [T][heads][N]   gradient wrt the scaled raw scores
+    float* St = dSall + Tn * HN;        // [heads][N]      raw scores of token t
+    float* At = St + HN;                // [heads][N]      softmax output
+    float* Gt = At + HN;                // [heads][N]      dPm, then dU
+    float* Xt = Gt + HN;                // [heads][N]      dA
+    const long b = blockIdx.x;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = kIaThr / 64;
+    const T* kvc = kv_cls + b * Tn * 2 * E;
+    const T* kvt = kv_tok + b * (N - Tn) * tok_ld - (long)Tn * tok_ld;
+    T* dkc = dkv_cls + b * Tn * 2 * E;
+    T* dkt = dkv_tok + b * (N - Tn) * dtok_ld - (long)Tn * dtok_ld;
+    auto row = [&](int n) { return n < Tn ? kvc + (long)n * 2 * E : kvt + (long)n * tok_ld; };
+    for (int t = 0; t < Tn; ++t) {
+        const T* qt = q + (b * Tn + t) * E;
+        const T* dot_ = dout + (b * Tn + t) * E;
+        const long pbase = (b * Tn + t) * (long)HN;
+        for (int i = tid; i < HN; i += kIaThr) {
+            const int h = i / N, n = i - h * N;
+            const T* kr = row(n) + h * hd;
+            float s = 0.f, g = 0.f;
+            for (int e = 0; e < hd; ++e) {
+                s = fmaf(elt<T>::ld(qt + h * hd + e), elt<T>::ld(kr + e), s);
+                g = fmaf(elt<T>::ld(dot_ + h * hd + e), elt<T>::ld(kr + E + e), g);     // dD = dout . v
+            }
+            St[i] = s * scale;
+            At[i] = P[pbase + i];
+            Gt[i] = mask ? g * mask[pbase + i] : g;                                       // dPm = dD * mask
+        }
+        __syncthreads();
+        for (int i = tid; i < HN; i += kIaThr) {                 // D (for dv) and dA = dPm + W2^T dPm
+            const int h = i / N, n = i - h * N;
+            float pm = At[i] + b2[h], da = Gt[i];
+            for (int g = 0; g < heads; ++g) {
+                pm = fmaf(W2[h * heads + g], At[g * N + n], pm);
+                da = fmaf(W2[g * heads + h], Gt[g * N + n], da);
+            }
+            Dall[t * HN + i] = mask ? pm * mask[pbase + i] : pm;
+            Xt[i] = da;
+        }
+        for (int pr = wave; pr < heads * heads; pr += NW) {      // dW2[h][g] += sum_n dPm[h][n] A[g][n];  db2[h] += sum_n dPm[h][n]
+            const int h = pr / heads, g = pr - h * heads;
+            float a = 0.f, bsum = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                a = fmaf(Gt[h * N + n], At[g * N + n], a);
+                bsum += Gt[h * N + n];
+            }
+            a = wave_sum(a);
+            bsum = wave_sum(bsum);
+            if (lane == 0) {
+                atomicAdd(dW2 + pr, a);
+                if (g == 0) atomicAdd(db2 + h, bsum);
+            }
+        }
+        __syncthreads();
+        for (int h = wave; h < heads; h += NW) {                 // softmax backward: dU = A (dA - <dA, A>)   (into Gt)
+            float dot = 0.f;
+            for (int n = lane; n < N; n += 64) dot = fmaf(Xt[h * N + n], At[h * N + n], dot);
+            dot = wave_sum(dot);
+            for (int n = lane; n < N; n += 64) Gt[h * N + n] = At[h * N + n] * (Xt[h * N + n] - dot);
+        }
+        __syncthreads();
+        for (int i = tid; i < HN; i += kIaThr) {                 // dS = dU + W1^T dU
+            const int h = i / N, n = i - h * N;
+            float ds = Gt[i];
+            for (int g = 0; g < heads; ++g) ds = fmaf(W1[g * heads + h], Gt[g * N + n], ds);
+            dSall[t * HN + i] = ds;
+        }
+        for (int pr = wave; pr < heads * heads; pr += NW) {      // dW1[h][g] += sum_n dU[h][n] S[g][n];  db1[h] += sum_n dU[h][n]
+            const int h = pr / heads, g = pr - h * heads;
+            float a = 0.f, bsum = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                a = fmaf(Gt[h * N + n], St[g * N + n], a);
+                bsum += Gt[h * N + n];
+            }
+            a = wave_sum(a);
+            bsum = wave_sum(bsum);
+            if (lane == 0) {
+                atomicAdd(dW1 + pr, a);
+                if (g == 0) atomicAdd(db1 + h, bsum);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < Tn * E; i += kIaThr) {                 // dq[t][c] = scale sum_n dS[t][h][n] k[n][c]
+        const int t = i / E, c = i - t * E, h = c / hd;
+        float a = 0.f;
+        for (int n = 0; n < N; ++n) a = fmaf(dSall[(t * heads + h) * N + n], elt<T>::ld(row(n) + c), a);
+        elt<T>::st(dq + (b * Tn + t) * E + c, a * scale);
+    }
+    for (int i = tid; i < N * E; i += kIaThr) {                  // dk[n][c] = scale sum_t dS q;  dv[n][c] = sum_t D dout
+        const int n = i / E, c = i - n * E, h = c / hd;
+        float dk = 0.f, dv = 0.f;
+        for (int t = 0; t < Tn; ++t) {
+            dk = fmaf(dSall[(t * heads + h) * N + n], elt<T>::ld(q + (b * Tn + t) * E + c), dk);
+            dv = fmaf(Dall[(t * heads + h) * N + n], elt<T>::ld(dout + (b * Tn + t) * E + c), dv);
+        }
+        T* drow = n < Tn ? dkc + (long)n * 2 * E : dkt + (long)n * dtok_ld;
+        elt<T>::st(drow + c, dk * scale);
+        elt<T>::st(drow + E + c, dv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // elementwise helpers (8 elements per thread)
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -431,6 +625,41 @@ extern "C" int ga_class_attn_mt_bwd(const void* dout, const void* q, const void*
     else { using T = float; if (T_ <= 4) MT_LAUNCH(T, 4); else if (T_ <= 6) MT_LAUNCH(T, 6); else MT_LAUNCH(T, 8); }
 #undef MT_LAUNCH
     return ga_check_launch("ga_class_attn_mt_bwd");
+}
+
+extern "C" int ga_class_attn_mt_ia_fwd(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P,
+                                       const float* mask, const float* W1, const float* b1, const float* W2, const float* b2, int B, int T_,
+                                       int N, int heads, int hd, float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(q && kv_cls && kv_tok && out && P && W1 && b1 && W2 && b2 && B > 0 && T_ >= 1 && T_ <= kMaxT && N > T_ && heads >= 1 && hd >= 1,
+               "ga_class_attn_mt_ia_fwd: bad args (T <= %d)", kMaxT);
+    GA_REQUIRE(tok_ld >= 2 * heads * hd, "ga_class_attn_mt_ia_fwd: tok_ld");
+    const size_t lds = (size_t)2 * heads * N * sizeof(float);
+    GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_ia_fwd: %zu B of LDS needed", lds);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    auto reserve = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    static const bool ok = reserve(reinterpret_cast<const void*>(mt_attn_ia_fwd_kernel<bf16_t>)) && reserve(reinterpret_cast<const void*>(mt_attn_ia_fwd_kernel<float>));
+    GA_REQUIRE(ok, "ga_class_attn_mt_ia_fwd: cannot reserve LDS");
+    MAP_DISPATCH(dtype, mt_attn_ia_fwd_kernel, dim3(B), dim3(kIaThr), lds, s, (const T*)q, (const T*)kv_cls, (const T*)kv_tok, (long)tok_ld, (T*)out, P,
+                 mask, W1, b1, W2, b2, T_, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_mt_ia_fwd");
+}
+
+extern "C" int ga_class_attn_mt_ia_bwd(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, const float* P,
+                                       const float* mask, const float* W1, const float* W2, const float* b2, void* dq, void* dkv_cls,
+                                       void* dkv_tok, int64_t dtok_ld, float* dW1, float* db1, float* dW2, float* db2, int B, int T_, int N,
+                                       int heads, int hd, float scale, int dtype, ga_stream_t stream) {
+    GA_REQUIRE(dout && q && kv_cls && kv_tok && P && W1 && W2 && b2 && dq && dkv_cls && dkv_tok && dW1 && db1 && dW2 && db2 && B > 0 && T_ >= 1 &&
+                   T_ <= kMaxT && N > T_, "ga_class_attn_mt_ia_bwd: bad args (T <= %d)", kMaxT);
+    GA_REQUIRE(tok_ld >= 2 * heads * hd && dtok_ld >= 2 * heads * hd, "ga_class_attn_mt_ia_bwd: row strides");
+    const size_t lds = (size_t)(2 * T_ + 4) * heads * N * sizeof(float);
+    GA_REQUIRE(lds <= 160 * 1024, "ga_class_attn_mt_ia_bwd: %zu B of LDS needed", lds);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    auto reserve = [](const void* f) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; };
+    static const bool ok = reserve(reinterpret_cast<const void*>(mt_attn_ia_bwd_kernel<bf16_t>)) && reserve(reinterpret_cast<const void*>(mt_attn_ia_bwd_kernel<float>));
+    GA_REQUIRE(ok, "ga_class_attn_mt_ia_bwd: cannot reserve LDS");
+    MAP_DISPATCH(dtype, mt_attn_ia_bwd_kernel, dim3(B), dim3(kIaThr), lds, s, (const T*)dout, (const T*)q, (const T*)kv_cls, (const T*)kv_tok,
+                 (long)tok_ld, P, mask, W1, W2, b2, (T*)dq, (T*)dkv_cls, (T*)dkv_tok, (long)dtok_ld, dW1, db1, dW2, db2, T_, N, heads, hd, scale);
+    return ga_check_launch("ga_class_attn_mt_ia_bwd");
 }
 
 extern "C" int ga_gelu_fwd(const void* x, void* y, int64_t n, int dtype, ga_stream_t stream) {

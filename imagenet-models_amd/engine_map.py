@@ -82,13 +82,16 @@ class MAPEngine(GAEngine):
         cfg, B, T, F, dt, P = self.cfg, self.B, self.training, self.fwd, self.dt, self.P
         L, G, Tn, E, nh = cfg['last_dim'], cfg['n_groups'], cfg['n_tokens'], cfg['ca_dim'], cfg['num_heads']
         bp, NC = cfg['bp_dim'], cfg['num_classes']
-        Tq = Tn + 1                      # gram tokens + the self-distillation (mean) token
+        sdt = self.sdt = bool(cfg.get('self_distill_token', True))     # CAP's extra mean token + MAPHead.self_dt_heads (map.py:273-275,490-491)
+        hfn = self.head_fn = cfg.get('head_fn', 'norm')                # heads: NormHead | SplitNormHead | nn.Linear (map.py:402-448,485-489)
+        assert hfn in ('norm', 'split', 'linear')
+        Tq = Tn + (1 if sdt else 0)      # gram tokens (+ the self-distillation mean token)
         HW = Hc * Hc
         hd = E // nh
         assert E % nh == 0 and hd % 8 == 0 and E <= 512 and L % 8 == 0 and bp % 8 == 0 and NC % 8 == 0 and Tq <= 8
         self.G, self.Tq = G, Tq
         H = self.mh = dict(x=x)
-        nlog = 2 * G if T else G
+        nlog = 2 * G if (T and sdt) else G
         self.logits = self.buf('logits', (nlog, B, NC), torch.float32)
         # ---- dropout masks (training, p > 0): [attn | proj | mlp] per group in ONE fp32 buffer, refilled every step
         pd, pa = (cfg['head_drop'], cfg['head_attn_drop']) if T else (0.0, 0.0)
@@ -141,10 +144,31 @@ class MAPEngine(GAEngine):
         fo['WT'] = self.buf('wT.fc.org', (G, Tn * L, pad8(NC))) if T else None
         fo['b'] = self.buf('w.fc.org.b', (G, NC), torch.float32)
         for k in range(G):
-            self.prep.weight_prep(P[f'head.heads.{k}.head.weight'], 1, NC, Tn * L, 1, 1, dt, out=fo['W'][k], ldo=Tn * L,
+            if hfn == 'split':
+                # SplitNormHead (map.py:415-441): sum_t head_t(LayerNorm_t(token t)).  The T LayerNorms run as ONE affine-free
+                # LayerNorm over the (B * T) token rows; their affine parts fold into the T linears, which then are one
+                # [NC][T * L] operand (column block t = head_t.weight * gamma_t) with bias sum_t (head_t.weight beta_t + bias_t)
+                fo['bt'] = self.buf('w.fc.org.bt', (G, Tn, NC), torch.float32)
+                wt = [self.buf(f'w.fc.org.split.{k}.{t}', (NC, L)) for t in range(Tn)]      # (weight_prep pads an output row to ldo: it
+                for t in range(Tn):                                                          # cannot write a column slice directly)
+                    self.prep.weight_prep(P[f'head.heads.{k}.head.{t}.weight'], 1, NC, L, 1, 1, dt, out=wt[t], ldo=L,
+                                          outT=fo['WT'][k][t * L:] if T else None, ldt=pad8(NC) if T else 0,
+                                          cs=P[f'head.heads.{k}.norm.{t}.weight'], label=f'prep.heads.{k}.{t}')
+                    self.prep.bias_fold(P[f'head.heads.{k}.head.{t}.weight'], P[f'head.heads.{k}.head.{t}.bias'], None,
+                                        P[f'head.heads.{k}.norm.{t}.bias'], fo['bt'][k, t], NC, L)
+                self.prep.flush('prep.split.')
+                for t in range(Tn):
+                    self.prep.copy2d(wt[t], L, fo['W'][k][:, t * L:], Tn * L, NC, L, dt, label=f'prep.heads.{k}.{t}.place')
+                self.prep.zero(fo['b'][k], label=f'prep.heads.{k}.b0')
+                for t in range(Tn):          # (one batch per term: the jobs of a batch run concurrently and these share a destination)
+                    self.prep.axpy_f32(fo['b'][k], fo['bt'][k, t], 1.0, NC)
+                    self.prep.flush(f'prep.split.sum{t}.')
+                continue
+            wn = f'head.heads.{k}.weight' if hfn == 'linear' else f'head.heads.{k}.head.weight'
+            self.prep.weight_prep(P[wn], 1, NC, Tn * L, 1, 1, dt, out=fo['W'][k], ldo=Tn * L,
                                   outT=fo['WT'][k] if T else None, ldt=pad8(NC) if T else 0, label=f'prep.heads.{k}')
-            self.prep.bias_fold(None, P[f'head.heads.{k}.head.bias'], None, None, fo['b'][k], NC, Tn * L)
-        if T:
+            self.prep.bias_fold(None, P[wn[:-6] + 'bias'], None, None, fo['b'][k], NC, Tn * L)
+        if T and sdt:
             fa = self.fc_avg = dict(x=self.act('fc.avg.x', (G, B, L)))
             fa['W'] = self.buf('w.fc.avg', (G, NC, L))
             fa['WT'] = self.buf('wT.fc.avg', (G, L, pad8(NC)))
@@ -163,7 +187,7 @@ class MAPEngine(GAEngine):
         F.lane, self.tmp_prefix = 0, ''
         F.gemm(fo['x'], fo['W'], self.logits, B, NC, Tn * L, dt, batch=G, strideA=B * Tn * L, strideB=NC * Tn * L, strideC=B * NC,
                bias=fo['b'], strideBias=NC, c_f32=True, label='fc.org')
-        if T:
+        if T and sdt:
             fa = self.fc_avg
             F.gemm(fa['x'], fa['W'], self.logits[G:], B, NC, L, dt, batch=G, strideA=B * L, strideB=NC * L, strideC=B * NC,
                    bias=fa['b'], strideBias=NC, c_f32=True, label='fc.avg')
@@ -215,7 +239,7 @@ class MAPEngine(GAEngine):
         e2 = self.tmp('e2', (B, gd * Tn))
         F.affine_act(h['e'], h['bn_e']['scale'], h['bn_e']['shift'], None, e2, B, gd * Tn, False, dt, label=gp + 'bpr.bn')
         h['cls0'] = self.buf(ap + 'cls0', (R, L))                  # [B][Tq][L]: gram tokens, then their mean
-        F.map_tokens_fwd(e2, h['cls0'], B, L, Tn, True, dt, label=gp + 'tokens')
+        F.map_tokens_fwd(e2, h['cls0'], B, L, Tn, self.sdt, dt, label=gp + 'tokens')
         # --- CABlock: class rows normalised on their own (norm1's affine part folded into q / k|v)
         g1, b1 = P[ap + 'norm1.weight'], P[ap + 'norm1.bias']
         h['cn'] = self.act(ap + 'cn', (R, L))
@@ -234,8 +258,13 @@ class MAPEngine(GAEngine):
         h['ao'] = self.act(ap + 'ao', (R, E))
         h['P'] = self.act(ap + 'P', (B, Tq, nh, Tq + HW), torch.float32)
         h['scale'] = hd ** -0.5
-        F.class_attn_mt_fwd(h['q'], h['kvc'], h['kvt'], tk['ld'], h['ao'], h['P'], dm.get('attn'), B, Tq, Tq + HW, nh, hd, h['scale'], dt,
-                            label=ap + 'attn')
+        if cfg.get('interactive', False):    # head-mixing linears around the softmax (map.py:96-98,130-136): fp32 masters read directly
+            F.class_attn_mt_ia_fwd(h['q'], h['kvc'], h['kvt'], tk['ld'], h['ao'], h['P'], dm.get('attn'), P[ap + 'attn.w1.weight'],
+                                   P[ap + 'attn.w1.bias'], P[ap + 'attn.w2.weight'], P[ap + 'attn.w2.bias'], B, Tq, Tq + HW, nh, hd,
+                                   h['scale'], dt, label=ap + 'attn')
+        else:
+            F.class_attn_mt_fwd(h['q'], h['kvc'], h['kvt'], tk['ld'], h['ao'], h['P'], dm.get('attn'), B, Tq, Tq + HW, nh, hd, h['scale'], dt,
+                                label=ap + 'attn')
         Wpr = self._w_plain(ap + 'attn.proj.weight', L, E, 1, 1)
         h['cls1'] = self.buf(ap + 'cls1', (R, L))
         if 'proj' in dm:
@@ -253,12 +282,19 @@ class MAPEngine(GAEngine):
         h['mlp'] = self._gmlp_fwd(ap + 'mlp.', h['t'], R, L, mg, h['cls2'], h['cls1'], None, 1, act='relu', drop_mask=dm.get('mlp'))
         # --- NormHead inputs: the T gram tokens flattened (heads) / the mean token (self_dt_heads), each LayerNorm-ed (eps 1e-5)
         hp = f'head.heads.{k}.'
-        h['org'] = self.act(hp + 'org', (B, Tn * L))
-        F.copy2d(h['cls2'], Tq * L, h['org'], Tn * L, B, Tn * L, dt, label=hp + 'org')
-        h['om'], h['orr'] = self.act(hp + 'm', (B,), torch.float32), self.act(hp + 'r', (B,), torch.float32)
-        F.layernorm_fwd(h['org'], P[hp + 'norm.weight'], P[hp + 'norm.bias'], self.fc_org['x'][k], h['om'], h['orr'], B, Tn * L, 1e-5,
-                        dt, label=hp + 'ln')
-        if T:
+        if self.head_fn == 'linear':         # nn.Linear on the flattened tokens: no norm
+            F.copy2d(h['cls2'], Tq * L, self.fc_org['x'][k], Tn * L, B, Tn * L, dt, label=hp + 'org')
+        else:
+            h['org'] = self.act(hp + 'org', (B, Tn * L))
+            F.copy2d(h['cls2'], Tq * L, h['org'], Tn * L, B, Tn * L, dt, label=hp + 'org')
+            if self.head_fn == 'split':      # one affine-free LayerNorm per token row (B * Tn rows of L); affine folded into the linears
+                h['orr'] = self.act(hp + 'r', (B * Tn,), torch.float32)
+                F.layernorm_fwd(h['org'], None, None, self.fc_org['x'][k], None, h['orr'], B * Tn, L, 1e-5, dt, label=hp + 'ln')
+            else:
+                h['om'], h['orr'] = self.act(hp + 'm', (B,), torch.float32), self.act(hp + 'r', (B,), torch.float32)
+                F.layernorm_fwd(h['org'], P[hp + 'norm.weight'], P[hp + 'norm.bias'], self.fc_org['x'][k], h['om'], h['orr'], B, Tn * L, 1e-5,
+                                dt, label=hp + 'ln')
+        if T and self.sdt:
             sp = f'head.self_dt_heads.{k}.'
             h['avg'] = self.act(sp + 'avg', (B, L))
             F.copy2d(h['cls2'][:, :].view(B, Tq * L)[:, Tn * L:], Tq * L, h['avg'], L, B, L, dt, label=sp + 'avg')
@@ -282,14 +318,22 @@ class MAPEngine(GAEngine):
         hp, sp = f'head.heads.{k}.', f'head.self_dt_heads.{k}.'
         # --- NormHeads -> gradient wrt cls2 [B][Tq][L]
         dcls2 = self.tmp('dcls2', (R, L))
-        dorg = self.tmp('dorg', (B, Tn * L))
-        Bk.layernorm_bwd(self.fc_org['dx'][k], h['org'], h['om'], h['orr'], P[hp + 'norm.weight'], None, dorg,
-                         self.grad(hp + 'norm.weight'), self.grad(hp + 'norm.bias'), B, Tn * L, False, dt, label=hp + 'lnb')
-        Bk.copy2d(dorg, Tn * L, dcls2, Tq * L, B, Tn * L, dt, label=hp + 'dorg')
-        davg = self.tmp('davg', (B, L))
-        Bk.layernorm_bwd(self.fc_avg['dx'][k], h['avg'], h['am_'], h['ar'], P[sp + 'norm.weight'], None, davg,
-                         self.grad(sp + 'norm.weight'), self.grad(sp + 'norm.bias'), B, L, False, dt, label=sp + 'lnb')
-        Bk.copy2d(davg, L, dcls2.view(B, Tq * L)[:, Tn * L:], Tq * L, B, L, dt, label=sp + 'davg')
+        if self.head_fn == 'linear':
+            Bk.copy2d(self.fc_org['dx'][k], Tn * L, dcls2, Tq * L, B, Tn * L, dt, label=hp + 'dorg')
+        else:
+            dorg = self.tmp('dorg', (B, Tn * L))
+            if self.head_fn == 'split':      # fc_org['x'][k] holds xhat (affine-free): LayerNorm backward from the stored normalised rows
+                Bk.layernorm_bwd(self.fc_org['dx'][k], self.fc_org['x'][k], None, h['orr'], None, None, dorg, None, None, B * Tn, L, True, dt,
+                                 label=hp + 'lnb')
+            else:
+                Bk.layernorm_bwd(self.fc_org['dx'][k], h['org'], h['om'], h['orr'], P[hp + 'norm.weight'], None, dorg,
+                                 self.grad(hp + 'norm.weight'), self.grad(hp + 'norm.bias'), B, Tn * L, False, dt, label=hp + 'lnb')
+            Bk.copy2d(dorg, Tn * L, dcls2, Tq * L, B, Tn * L, dt, label=hp + 'dorg')
+        if self.sdt:
+            davg = self.tmp('davg', (B, L))
+            Bk.layernorm_bwd(self.fc_avg['dx'][k], h['avg'], h['am_'], h['ar'], P[sp + 'norm.weight'], None, davg,
+                             self.grad(sp + 'norm.weight'), self.grad(sp + 'norm.bias'), B, L, False, dt, label=sp + 'lnb')
+            Bk.copy2d(davg, L, dcls2.view(B, Tq * L)[:, Tn * L:], Tq * L, B, L, dt, label=sp + 'davg')
         # --- GroupConvMlp + norm2
         dtk = self.tmp('dt', (R, L))
         self._gmlp_bwd(ap + 'mlp.', h['mlp'], dcls2, h['t'], R, L, mg, dtk)
@@ -310,8 +354,14 @@ class MAPEngine(GAEngine):
         E2 = tk['E2']
         dq = self.tmp('dq', (R, E))
         dkvc = self.tmp('dkvc', (R, E2))
-        Bk.class_attn_mt_bwd(dao, h['q'], h['kvc'], h['kvt'], tk['ld'], h['P'], dm.get('attn'), dq, dkvc, tk['dkv'][:, k * E2:], tk['ld'],
-                             B, Tq, Tq + HW, nh, hd, h['scale'], dt, label=ap + 'attnb')
+        if cfg.get('interactive', False):
+            Bk.class_attn_mt_ia_bwd(dao, h['q'], h['kvc'], h['kvt'], tk['ld'], h['P'], dm.get('attn'), P[ap + 'attn.w1.weight'],
+                                    P[ap + 'attn.w2.weight'], P[ap + 'attn.w2.bias'], dq, dkvc, tk['dkv'][:, k * E2:], tk['ld'],
+                                    self.grad(ap + 'attn.w1.weight'), self.grad(ap + 'attn.w1.bias'), self.grad(ap + 'attn.w2.weight'),
+                                    self.grad(ap + 'attn.w2.bias'), B, Tq, Tq + HW, nh, hd, h['scale'], dt, label=ap + 'attnb')
+        else:
+            Bk.class_attn_mt_bwd(dao, h['q'], h['kvc'], h['kvt'], tk['ld'], h['P'], dm.get('attn'), dq, dkvc, tk['dkv'][:, k * E2:], tk['ld'],
+                                 B, Tq, Tq + HW, nh, hd, h['scale'], dt, label=ap + 'attnb')
         g1, b1 = P[ap + 'norm1.weight'], P[ap + 'norm1.bias']
         # class rows' share of the effective k|v weight gradient (the image rows' share: one wgrad after the loop)
         Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], R, E2, L, dt, dbias=tk['gb'][k * E2:], label=ap + 'kvc.wg')
@@ -327,7 +377,7 @@ class MAPEngine(GAEngine):
         Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, dcls1, dcls1, None, None, R, L, True, dt, label=ap + 'ln1cb')
         # --- tokens -> bp_reduction BN + grouped conv
         de2 = self.tmp('de2', (B, gd * Tn))
-        Bk.map_tokens_bwd(dcls1, de2, B, L, Tn, True, dt, label=gp + 'tokensb')
+        Bk.map_tokens_bwd(dcls1, de2, B, L, Tn, self.sdt, dt, label=gp + 'tokensb')
         de = self.tmp('de', (B, gd * Tn))
         self._bn_bwd(gp + 'bp_reduction.1.', h['bn_e'], de2, None, h['e'], de, B, gd * Tn)
         Kg, Kp, cg = h['Kg'], h['Kp'], h['cg']
@@ -363,16 +413,27 @@ class MAPEngine(GAEngine):
         gradient of the multi-scale concat (the trunk-specific part takes it from there)"""
         Bk, dt, B, P, W, cfg = self.bwd, self.dt, self.B, self.P, self.W, self.cfg
         L, G, Tn, E, NC, bp = cfg['last_dim'], cfg['n_groups'], cfg['n_tokens'], cfg['ca_dim'], cfg['num_classes'], cfg['bp_dim']
-        self.dlogits = self.buf('dlogits', (2 * G, B, NC))
+        sdt, hfn = self.sdt, self.head_fn
+        self.dlogits = self.buf('dlogits', ((2 if sdt else 1) * G, B, NC))
         Bk.zero(self.arena, label='zero.arena')
         # classifiers: one batched wgrad + dgrad for the heads, one for the self_dt_heads
-        for fc, dl, name, cin in ((self.fc_org, self.dlogits[:G], 'heads', Tn * L), (self.fc_avg, self.dlogits[G:], 'self_dt_heads', L)):
+        fcs = [(self.fc_org, self.dlogits[:G], 'heads', Tn * L)] + ([(self.fc_avg, self.dlogits[G:], 'self_dt_heads', L)] if sdt else [])
+        for fc, dl, name, cin in fcs:
             Gfc, gbfc = self.gbuf((G, NC, cin)), self.gbuf((G, NC))
             Bk.wgrad(dl, fc['x'], Gfc, B, NC, cin, dt, batch=G, strideY=B * NC, strideX=B * cin, strideW=NC * cin, dbias=gbfc,
                      strideDbias=NC, label=f'fc.{name}.wg')
             for k in range(G):
-                Bk.axpy_f32(self.grad(f'head.{name}.{k}.head.weight'), Gfc[k], 1.0, NC * cin)
-                Bk.axpy_f32(self.grad(f'head.{name}.{k}.head.bias'), gbfc[k], 1.0, NC)
+                if name == 'heads' and hfn == 'split':      # undo the LayerNorm fold per token: dW_t, d(bias_t), d(gamma_t), d(beta_t)
+                    for t in range(Tn):
+                        hk = f'head.heads.{k}.'
+                        Bk.weight_unfold(Gfc[k][:, t * L:], Tn * L, NC, L, gb=gbfc[k], W=P[hk + f'head.{t}.weight'], b=P[hk + f'head.{t}.bias'],
+                                         cs=P[hk + f'norm.{t}.weight'], v=P[hk + f'norm.{t}.bias'], dW=self.grad(hk + f'head.{t}.weight'),
+                                         db=self.grad(hk + f'head.{t}.bias'), d_cs=self.grad(hk + f'norm.{t}.weight'),
+                                         d_v=self.grad(hk + f'norm.{t}.bias'), label=hk + f'{t}.unf')
+                    continue
+                wn = f'head.{name}.{k}.weight' if (name == 'heads' and hfn == 'linear') else f'head.{name}.{k}.head.weight'
+                Bk.axpy_f32(self.grad(wn), Gfc[k], 1.0, NC * cin)
+                Bk.axpy_f32(self.grad(wn[:-6] + 'bias'), gbfc[k], 1.0, NC)
             fc['dx'] = self.tmp(f'dfc.{name}', (G, B, cin))
             Bk.gemm(dl, fc['WT'], fc['dx'], B, cin, NC, dt, batch=G, strideA=B * NC, strideB=cin * pad8(NC), ldb=pad8(NC),
                     strideC=B * cin, label=f'fc.{name}.dg')
@@ -444,4 +505,6 @@ class MAPEngine(GAEngine):
     def _loss_operands(self):
         """fused MAP loss (MAP/train.py:792-839): org logits of the G groups, their avg logits, and the two gradients"""
         G = self.G
+        if not self.sdt:         # plain list of group logits: multi_group_loss reduces to the GA form (MAP/train.py:818-820,824-837)
+            return self.logits[:G], None, self.dlogits[:G], None, G
         return self.logits[:G], self.logits[G:], self.dlogits[:G], self.dlogits[G:], G

@@ -38,9 +38,10 @@ class _Block(Holder):
 
 
 class _CABlock(Holder):
-    """map.CABlock with ClassAttention / GroupConvMlp (map.py:147-169, 69-98, 43-54): in_dim == dim, no `interactive`"""
+    """map.CABlock with ClassAttention / GroupConvMlp (map.py:147-169, 69-98, 43-54): in_dim == dim; `interactive` adds the two
+    head-mixing linears w1 / w2 (:96-98)"""
 
-    def __init__(self, dim, ca_dim, mlp_ratio, mlp_groups):
+    def __init__(self, dim, ca_dim, mlp_ratio, mlp_groups, num_heads=0, interactive=False):
         super().__init__()
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = Holder()
@@ -48,6 +49,9 @@ class _CABlock(Holder):
         self.attn.q = nn.Linear(dim, ca_dim, bias=True)
         self.attn.k = nn.Linear(dim, ca_dim, bias=True)
         self.attn.v = nn.Linear(dim, ca_dim, bias=True)
+        if interactive:
+            self.attn.w1 = nn.Linear(num_heads, num_heads)
+            self.attn.w2 = nn.Linear(num_heads, num_heads)
         hid = int(dim * mlp_ratio)
         self.mlp = Holder()
         self.mlp.fc1 = nn.Conv2d(dim, hid, kernel_size=1, groups=mlp_groups)
@@ -72,7 +76,8 @@ class _GramToken(Holder):
 class _CAP(Holder):
     def __init__(self, cfg):
         super().__init__()
-        self.attention = nn.Sequential(_CABlock(cfg['last_dim'], cfg['ca_dim'], cfg['mlp_ratio'], cfg['mlp_groups']))
+        self.attention = nn.Sequential(_CABlock(cfg['last_dim'], cfg['ca_dim'], cfg['mlp_ratio'], cfg['mlp_groups'], cfg['num_heads'],
+                                                cfg.get('interactive', False)))
         self.gram_token_extraction = _GramToken(cfg['last_dim'], cfg['gram_group'], cfg['n_tokens'], cfg['bp_groups'],
                                                 cfg['bp_dim'], cfg['gram_dim'])
 
@@ -82,6 +87,15 @@ class _NormHead(Holder):
         super().__init__()
         self.norm = nn.LayerNorm(ch)
         self.head = nn.Linear(ch, num_classes)
+
+
+class _SplitNormHead(Holder):
+    """map.SplitNormHead (:415-441): per token its own LayerNorm + Linear, outputs summed"""
+
+    def __init__(self, ch, num_classes, nt):
+        super().__init__()
+        self.norm = nn.ModuleList([nn.LayerNorm(ch // nt) for _ in range(nt)])
+        self.head = nn.ModuleList([nn.Linear(ch // nt, num_classes) for _ in range(nt)])
 
 
 class _MAPHead(Holder):
@@ -95,8 +109,15 @@ class _MAPHead(Holder):
         ms = Holder()
         ms.concat_conv = nn.Sequential(nn.Conv2d(sum(channels), L, 1, bias=False), nn.BatchNorm2d(L))
         self.mmcap.multi_scale = ms
-        self.heads = nn.ModuleList([_NormHead(L * T, cfg['num_classes']) for _ in range(G)])
-        self.self_dt_heads = nn.ModuleList([_NormHead(L, cfg['num_classes']) for _ in range(G)])
+        hfn = cfg.get('head_fn', 'norm')
+        if hfn == 'split':
+            self.heads = nn.ModuleList([_SplitNormHead(L * T, cfg['num_classes'], T) for _ in range(G)])
+        elif hfn == 'linear':        # head_fn = nn.Linear through the try / except of map.py:485-489
+            self.heads = nn.ModuleList([nn.Linear(L * T, cfg['num_classes']) for _ in range(G)])
+        else:
+            self.heads = nn.ModuleList([_NormHead(L * T, cfg['num_classes']) for _ in range(G)])
+        if cfg.get('self_distill_token', True):
+            self.self_dt_heads = nn.ModuleList([_NormHead(L, cfg['num_classes']) for _ in range(G)])
 
 
 def _init_weights(m):
@@ -112,12 +133,13 @@ class MAP_ConvNeXt(FlatModel):
                  layer_scale_init_value=1e-6, head_init_scale=1., global_pool='mmcap', last_dim=384, n_groups=4, n_tokens=3,
                  gram_group=8, ch_reduce=1, bp_dim=192, bp_groups=1, gram_layer=None, gram_dim=None, ca_dim=128, num_heads=8,
                  gram=True, split_norm=False, self_distill_token=True, head_drop=0.05, head_attn_drop=0.05, math_mode=None,
-                 **kwargs):
+                 head_fn=None, interactive=False, **kwargs):
         """head_drop / head_attn_drop: the dropout probabilities CABlock hard-codes (map.py:149: drop=0.05 -> proj / MLP
         dropout; MAPHead attn_drop=0.05, :464) -- exposed so that parity tests can switch the (irreproducible) masks off"""
         super().__init__()
-        assert global_pool == 'mmcap' and gram and not split_norm and self_distill_token and in_chans == 3, \
-            'only the MAP configuration of the registered map_convnext_* models'
+        # split_norm (map_convnext.py:97-100) selects SplitNormHead; head_fn = 'linear' (nn.Linear heads), self_distill_token = False and
+        # interactive = True are the MAPHead options the other reference backbones use (SURVEY Appendix C): same head code
+        assert global_pool == 'mmcap' and gram and in_chans == 3, 'only the MAP head (global_pool="mmcap") with Gram tokens'
         assert gram_layer is None and bp_groups == 1 and layer_scale_init_value > 0
         depths, dims = tuple(depths), tuple(dims)
         self.num_classes = num_classes
@@ -125,7 +147,10 @@ class MAP_ConvNeXt(FlatModel):
         self.cfg = dict(family='map_convnext', depths=depths, dims=dims, num_classes=num_classes, drop_path_rate=drop_path_rate,
                         last_dim=last_dim, n_groups=n_groups, n_tokens=n_tokens, gram_group=gram_group, bp_dim=bp_dim,
                         bp_groups=bp_groups, gram_dim=gram_dim or last_dim, ca_dim=ca_dim, num_heads=num_heads, mlp_ratio=4,
-                        mlp_groups=2, multi_scale_level=3, naggre=0, head_drop=head_drop, head_attn_drop=head_attn_drop)
+                        mlp_groups=2, multi_scale_level=3, naggre=0, head_drop=head_drop, head_attn_drop=head_attn_drop,
+                        self_distill_token=bool(self_distill_token), head_fn=head_fn or ('split' if split_norm else 'norm'),
+                        interactive=bool(interactive))
+        assert self.cfg['head_fn'] in ('norm', 'split', 'linear')
         assert self.cfg['gram_dim'] == last_dim, 'dim_mismatch CABlocks are not on the map_convnext path'
         self.downsample_layers = nn.ModuleList()
         self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4), _LN(dims[0])))
@@ -150,8 +175,8 @@ class MAP_ConvNeXt(FlatModel):
         """eval: list of n_groups logits; train: list of [org_out, avg_out] (map.py:519-537)"""
         assert not pre_logits, 'pre_logits (MAP/validate.py --logit-extract) is not on the hot path'
         outs = super().forward(x)     # train: the engine's logits buffer is [2 * n_groups][B][NC] = org heads, then avg heads
-        if not self.training:
-            return outs
+        if not self.training or not self.cfg['self_distill_token']:
+            return outs          # (without the self-distillation token MAPHead returns plain logits in both modes, map.py:536-537)
         K = self.cfg['n_groups']
         return [[outs[k], outs[K + k]] for k in range(K)]
 

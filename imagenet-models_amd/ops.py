@@ -699,6 +699,18 @@ class Plan:
                                            _ptr(dkv_cls), _ptr(dkv_tok), dtok_ld, B, T, N, heads, hd, scale, dtype), label,
                   keep=(dout, q, kv_cls, kv_tok, P, mask, dq, dkv_cls, dkv_tok))
 
+    def class_attn_mt_ia_fwd(self, q, kv_cls, kv_tok, tok_ld, out, P, mask, W1, b1, W2, b2, B, T, N, heads, hd, scale, dtype, label=None):
+        self._add('ga_class_attn_mt_ia_fwd', (_ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(out), _ptr(P), _ptr(mask), _ptr(W1), _ptr(b1),
+                                              _ptr(W2), _ptr(b2), B, T, N, heads, hd, scale, dtype), label,
+                  keep=(q, kv_cls, kv_tok, out, P, mask, W1, b1, W2, b2))
+
+    def class_attn_mt_ia_bwd(self, dout, q, kv_cls, kv_tok, tok_ld, P, mask, W1, W2, b2, dq, dkv_cls, dkv_tok, dtok_ld, dW1, db1, dW2, db2,
+                             B, T, N, heads, hd, scale, dtype, label=None):
+        self._add('ga_class_attn_mt_ia_bwd', (_ptr(dout), _ptr(q), _ptr(kv_cls), _ptr(kv_tok), tok_ld, _ptr(P), _ptr(mask), _ptr(W1), _ptr(W2),
+                                              _ptr(b2), _ptr(dq), _ptr(dkv_cls), _ptr(dkv_tok), dtok_ld, _ptr(dW1), _ptr(db1), _ptr(dW2),
+                                              _ptr(db2), B, T, N, heads, hd, scale, dtype), label,
+                  keep=(dout, q, kv_cls, kv_tok, P, mask, W1, W2, b2, dq, dkv_cls, dkv_tok, dW1, db1, dW2, db2))
+
     def map_loss_fwd_bwd(self, org, avg, target, loss, dorg, davg, K, B, NC, lam, kind, smoothing, grad_scale, dtype, label=None):
         self._add('ga_map_loss_fwd_bwd', (_ptr(org), _ptr(avg), _ptr(target), _ptr(loss), _ptr(dorg), _ptr(davg), K, B, NC, lam, kind,
                                           smoothing, grad_scale, dtype), label, keep=(org, avg, target, loss, dorg, davg))

@@ -433,6 +433,16 @@ int ga_class_attn_mt_fwd(const void* q, const void* kv_cls, const void* kv_tok, 
 int ga_class_attn_mt_bwd(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, const float* P,
                          const float* mask, void* dq, void* dkv_cls, void* dkv_tok, int64_t dtok_ld, int B, int T, int N,
                          int heads, int hd, float scale, int dtype, ga_stream_t stream);
+/* ClassAttention with `interactive` = True (map.py:96-98,130-136): W1, W2 [heads][heads] + b1, b2 [heads] fp32 mix the HEADS of
+ * the scores before and of the probabilities after the softmax: U = S + W1 S + b1, A = softmax(U), Pm = A + W2 A + b2.
+ * Same operand layouts as ga_class_attn_mt_*; P saves A.  _bwd also ACCUMULATES dW1, db1, dW2, db2 (fp32). */
+int ga_class_attn_mt_ia_fwd(const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, void* out, float* P,
+                            const float* mask, const float* W1, const float* b1, const float* W2, const float* b2, int B, int T, int N,
+                            int heads, int hd, float scale, int dtype, ga_stream_t stream);
+int ga_class_attn_mt_ia_bwd(const void* dout, const void* q, const void* kv_cls, const void* kv_tok, int64_t tok_ld, const float* P,
+                            const float* mask, const float* W1, const float* W2, const float* b2, void* dq, void* dkv_cls,
+                            void* dkv_tok, int64_t dtok_ld, float* dW1, float* db1, float* dW2, float* db2, int B, int T, int N,
+                            int heads, int hd, float scale, int dtype, ga_stream_t stream);
 int ga_map_loss_fwd_bwd(const float* org, const float* avg, const int64_t* target, float* loss, void* dorg, void* davg, int K,
                         int B, int NC, float lam, int kind, float smoothing, float grad_scale, int dtype, ga_stream_t stream);
 /* the same losses on DENSE targets [B][NC] fp32 (mixup / cutmix, GA/train.py:616-621: SoftTargetCrossEntropy for kind 0 --

@@ -39,7 +39,8 @@ def make_cfg(name=None, **over):
     """ConvNeXt(...) defaults of map_convnext.py:58-66 + the MAPHead arguments it hard-codes (:102-109)"""
     cfg = dict(in_chans=3, num_classes=1000, depths=(3, 3, 9, 3), dims=(96, 192, 384, 768), drop_path_rate=0.0, last_dim=384,
                n_groups=4, n_tokens=3, gram_group=8, bp_dim=192, bp_groups=1, gram_dim=None, ca_dim=128, num_heads=8,
-               self_distill_token=True, multi_scale_level=3, mlp_ratio=4, mlp_groups=2, interactive=False)
+               self_distill_token=True, multi_scale_level=3, mlp_ratio=4, mlp_groups=2, interactive=False,
+               head_fn='norm')       # 'norm' NormHead | 'split' SplitNormHead (map_convnext split_norm=True) | 'linear' nn.Linear
     if name is not None:
         cfg.update(VARIANTS[name])
     cfg.update(over)
@@ -106,10 +107,21 @@ def head_shapes(pre, cfg, channels, o):
     mp = f'{pre}mmcap.multi_scale.concat_conv.'
     o[mp + '0.weight'] = (L, sum(channels), 1, 1)
     _bn_shapes(mp + '1.', L, o)
+    hfn = cfg.get('head_fn', 'norm')
     for i in range(G):
-        _ln_shapes(f'{pre}heads.{i}.norm.', L * T, o)
-        o[f'{pre}heads.{i}.head.weight'] = (cfg['num_classes'], L * T)
-        o[f'{pre}heads.{i}.head.bias'] = (cfg['num_classes'],)
+        if hfn == 'split':           # SplitNormHead (map.py:415-425): ModuleList norm, then ModuleList head
+            for t in range(T):
+                _ln_shapes(f'{pre}heads.{i}.norm.{t}.', L, o)
+            for t in range(T):
+                o[f'{pre}heads.{i}.head.{t}.weight'] = (cfg['num_classes'], L)
+                o[f'{pre}heads.{i}.head.{t}.bias'] = (cfg['num_classes'],)
+        elif hfn == 'linear':        # head_fn = nn.Linear (map.py:485-489)
+            o[f'{pre}heads.{i}.weight'] = (cfg['num_classes'], L * T)
+            o[f'{pre}heads.{i}.bias'] = (cfg['num_classes'],)
+        else:
+            _ln_shapes(f'{pre}heads.{i}.norm.', L * T, o)
+            o[f'{pre}heads.{i}.head.weight'] = (cfg['num_classes'], L * T)
+            o[f'{pre}heads.{i}.head.bias'] = (cfg['num_classes'],)
     if cfg['self_distill_token']:
         for i in range(G):
             _ln_shapes(f'{pre}self_dt_heads.{i}.norm.', L, o)
@@ -320,6 +332,22 @@ def norm_head(sd, pre, x):
     return F.linear(x, sd[pre + 'head.weight'], sd[pre + 'head.bias'])
 
 
+def group_head(sd, pre, x, cfg):
+    """heads[i] of MAPHead: NormHead, SplitNormHead (map.py:427-441: per-token LayerNorm + Linear, summed) or nn.Linear"""
+    hfn = cfg.get('head_fn', 'norm')
+    if hfn == 'linear':
+        return F.linear(x, sd[pre + 'weight'], sd[pre + 'bias'])
+    if hfn == 'split':
+        T = cfg['n_tokens']
+        xs = x.reshape(x.shape[0], T, -1)
+        out = 0
+        for t in range(T):
+            s = F.layer_norm(xs[:, t], (xs.shape[2],), sd[pre + f'norm.{t}.weight'], sd[pre + f'norm.{t}.bias'], 1e-5)
+            out = out + F.linear(s, sd[pre + f'head.{t}.weight'], sd[pre + f'head.{t}.bias'])
+        return out
+    return norm_head(sd, pre, x)
+
+
 def map_head(sd, pre, feats, cfg, training, new_stats=None, masks=None):
     """MAPHead.forward (map.py:514-539): train -> [[org_out, avg_out]] per group, eval -> [org_out] per group"""
     masks = masks or {}
@@ -331,10 +359,10 @@ def map_head(sd, pre, feats, cfg, training, new_stats=None, masks=None):
         pool = cap(sd, f'{pre}mmcap.mmcap.{i}.', x, cfg, training, new_stats, masks.get(i))
         if cfg['self_distill_token']:
             org, avg = pool[:, :out_ch], pool[:, out_ch:]
-            org_out = norm_head(sd, f'{pre}heads.{i}.', org)
+            org_out = group_head(sd, f'{pre}heads.{i}.', org, cfg)
             outs.append([org_out, norm_head(sd, f'{pre}self_dt_heads.{i}.', avg)] if training else org_out)
         else:
-            outs.append(norm_head(sd, f'{pre}heads.{i}.', pool))
+            outs.append(group_head(sd, f'{pre}heads.{i}.', pool, cfg))
     return outs
 
 
@@ -390,4 +418,5 @@ def train_step_grads(sd, x, target, cfg, dec_lam=-0.8, kind='ce', smoothing=0.0,
     outs = forward(leaf, x, cfg, training=True, new_stats=new_stats, dp_masks=dp_masks, drop_masks=drop_masks)
     loss = multi_group_loss(outs, target, dec_lam, kind, smoothing)
     gs = torch.autograd.grad(loss, [leaf[n] for n in names])
-    return loss.detach(), [[a.detach() for a in o] for o in outs], OrderedDict(zip(names, gs)), new_stats
+    return (loss.detach(), [[a.detach() for a in o] if isinstance(o, (list, tuple)) else o.detach() for o in outs],
+            OrderedDict(zip(names, gs)), new_stats)
