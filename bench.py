@@ -332,7 +332,7 @@ def main():
         # HBM bytes per launch of the family from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE over one step of THIS
         # workload, tools/pmc_step_traffic.py): a PMC run cannot be nested inside the timed bench
         traffic, traffic_src = None, None
-        for tj in ('r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json'):
+        for tj in ('r03_pmc_step_traffic.json', 'r02_pmc_step_traffic.json', 'r01_pmc_step_traffic.json'):
             tp = os.path.join(ROOT, 'profiles', tj)
             if name == 'gemm_nt' and a.model == MODEL and a.batch == 256 and a.math == 'bf16' and os.path.exists(tp):
                 with open(tp) as fh:

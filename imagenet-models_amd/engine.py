@@ -77,6 +77,7 @@ class GAEngine:
         self._bwd_seq = 0        # trunk blocks recorded on the backward plan so far
         self._pre_dyz = {}       # block prefix -> DropPath-scaled dy already written by the block before it (backward order)
         self.fuse_dp = os.environ.get('GAEXT_FUSE_DP', '1') != '0'
+        self.sync_bn = getattr(model, 'sync_bn_comm', None)      # FlatModel.convert_sync_batchnorm(comm): --sync-bn (GA/train.py:449-455)
         self.W = {}
         self.weights_dirty = True
         self.anchor = torch.zeros((), device=self.dev, requires_grad=True)
@@ -592,7 +593,17 @@ class GAEngine:
                     mean=self.buf(pre + 'bmean', (C,), torch.float32, zero=zero), rstd=self.buf(pre + 'brstd', (C,), torch.float32, zero=zero),
                     scale=self.buf(pre + 'scale', (C,), torch.float32, zero=zero), shift=self.buf(pre + 'shift', (C,), torch.float32, zero=zero))
 
+    def _sync_allreduce(self, plan, t, label):
+        """SyncBatchNorm (GA/train.py:449-455, --sync-bn): sum a small fp32 statistics vector over the ranks, enqueued on the lane the
+        plan call runs on (ga_allreduce_bucket through the communicator convert_sync_batchnorm() attached to the model)"""
+        c = self.sync_bn
+        plan._add('ga_allreduce_bucket', (c.handle, ops._ptr(t), t.numel(), GA_F32, 1.0, None, 0), label, keep=(t, c))
+
     def _bn_finalize(self, pre, bn, n, C):
+        if self.sync_bn is not None and self.training:       # batch statistics over the GLOBAL batch: sums of all ranks, n x world
+            self._sync_allreduce(self.fwd, bn['s'], pre + 'sync.s')
+            self._sync_allreduce(self.fwd, bn['q'], pre + 'sync.q')
+            n = n * self.sync_bn.world
         self.fwd.bn_finalize(bn['s'], bn['q'], n, self.P[pre + 'weight'], self.P[pre + 'bias'], 1e-5, 0.1,
                              self.Bf[pre + 'running_mean'], self.Bf[pre + 'running_var'], bn['mean'], bn['rstd'],
                              bn['scale'], bn['shift'], C, self.training, label=pre + 'fin')
@@ -603,10 +614,21 @@ class GAEngine:
         s1, s2 = self.gbuf((C,)), self.gbuf((C,))
         Bk.bn_bwd_reduce(dy, y_relu, x, bn['mean'], bn['rstd'], s1, s2, rows, C, self.dt, rowscale=rowscale,
                          rows_per_scale=rps, ldx=ldx, label=pre + 'bnr')
-        Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'] if weight is None else weight, s1, s2, rows, dx,
+        n = rows
+        if self.sync_bn is not None:
+            # torch.nn.SyncBatchNorm's backward: the parameter gradients take the LOCAL column sums (the gradient all-reduce averages
+            # them later), so they are accumulated right here -- not deferred to the stage flush --; then the two sums that enter dx
+            # are summed over the ranks in place
+            Bk._add('ga_axpy_f32', (ops._ptr(self.grad(pre + 'weight')), ops._ptr(s2), 1.0, c_real or C), pre + 'dgamma', keep=(s2,))
+            Bk._add('ga_axpy_f32', (ops._ptr(self.grad(pre + 'bias')), ops._ptr(s1), 1.0, c_real or C), pre + 'dbeta', keep=(s1,))
+            self._sync_allreduce(Bk, s1, pre + 'sync.s1')
+            self._sync_allreduce(Bk, s2, pre + 'sync.s2')
+            n = rows * self.sync_bn.world
+        Bk.bn_bwd_apply(dy, y_relu, x, bn['mean'], bn['rstd'], self.P[pre + 'weight'] if weight is None else weight, s1, s2, n, dx,
                         rows, C, self.dt, rowscale=rowscale, rows_per_scale=rps, ldx=ldx, lddx=lddx, label=pre + 'bna')
-        Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, c_real or C)
-        Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, c_real or C)
+        if self.sync_bn is None:
+            Bk.axpy_f32(self.grad(pre + 'weight'), s2, 1.0, c_real or C)
+            Bk.axpy_f32(self.grad(pre + 'bias'), s1, 1.0, c_real or C)
 
     # ------------------------------------------------------------------------------------------
     # Bottleneck (ga_convnext.py:294-318)

@@ -134,6 +134,15 @@ class FlatModel(nn.Module):
         self.flush_counters()
         return super().state_dict(*args, **kwargs)
 
+    def convert_sync_batchnorm(self, comm):
+        """--sync-bn (GA/train.py:449-455, torch.nn.SyncBatchNorm.convert_sync_batchnorm): every train-mode BatchNorm of the engines
+        built FROM NOW ON takes its batch statistics over all ranks -- the column sums the producing GEMM's epilogue left are
+        all-reduced through `comm` (an imagenet_models_amd.NativeComm) before the finalisation, the two sums of the backward
+        pass likewise.  comm = None switches it off again.  Cached engines are dropped."""
+        self.sync_bn_comm = comm
+        self._engines = {}
+        return self
+
     def grad_groups(self):
         """[(backward-plan mark, parameter-name prefixes whose gradients are final at that mark)] in backward-completion
         order; parameters matched by no group are final at the end of backward.  Used to cut the flat gradient buffer into

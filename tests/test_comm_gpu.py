@@ -104,6 +104,37 @@ def _assert_same_update(pa, pb, p0, slices, tol):
         assert d <= tol * ref + 1e-4 * umax, f'{n}: updates differ by {d:.3e} (slice max {ref:.3e}, global max {umax:.3e})'
 
 
+def test_sync_batchnorm_single_rank_is_the_identity_and_runs_collectives():
+    """--sync-bn (GA/train.py:449-455): with convert_sync_batchnorm(comm) every train-mode BatchNorm all-reduces its statistics
+    sums (forward: sum / sum of squares; backward: the two column sums entering dx) through RCCL inside the launch plans.  With
+    one rank the collectives are the identity: the step must equal the plain step, and the plans must really contain them."""
+    import imagenet_models_amd as A
+    B = 8
+    res = {}
+    for tag in ('plain', 'sync'):
+        m, O = _small_model()
+        if tag == 'sync':
+            comm = A.NativeComm()
+            m.convert_sync_batchnorm(comm)
+        opt = A.create_optimizer_v2(m, opt='sgd', lr=1e-2, momentum=0.9, weight_decay=0.05)
+        x = O.gen_input(B, seed=2).cuda()
+        y = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+        step = A.TrainStep(m, opt, B, lam=-0.8)
+        p0 = m.flat_state()['params'].clone()
+        loss = step(x, y)
+        torch.cuda.synchronize()
+        res[tag] = (float(loss), m.flat_state()['params'].clone(), m.flat_state()['buffers'].clone())
+        slices = m.flat_state()['slices']
+        if tag == 'sync':
+            nf = sum(1 for fn, _, lab in step.eng.fwd.calls if 'sync.' in str(lab))
+            nb = sum(1 for fn, _, lab in step.eng.bwd.calls if 'sync.' in str(lab))
+            assert nf >= 2 * 14 and nb >= 2 * 14, (nf, nb)      # 14 BatchNorm layers in GA-ConvNeXt (SURVEY 2.5), two sums each way
+    assert abs(res['plain'][0] - res['sync'][0]) < 1e-6 * abs(res['plain'][0])
+    _assert_same_update(res['plain'][1], res['sync'][1], p0, slices, 1e-3)
+    assert float((res['plain'][2] - res['sync'][2]).abs().max()) <= 1e-5 * float(res['plain'][2].abs().max())   # running statistics
+    comm.close()
+
+
 def test_trainstep_buckets_through_torch_nccl_world1():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_ws1_check.py')], env=env, cwd=ROOT, capture_output=True,

@@ -51,7 +51,7 @@ for k in f:
     out.append(dict(kernel=k, launches=f[k][0], fetch_mb=round(f[k][1] * 2 / 1e3, 1), write_mb=round(w.get(k, [0, 0.0])[1] / 1e3, 1)))
 out.sort(key=lambda r: -(r['fetch_mb'] + r['write_mb']))
 tot_f, tot_w = sum(r['fetch_mb'] for r in out), sum(r['write_mb'] for r in out)
-nt = [r for r in out if 'gemm_nt_kernel' in r['kernel']]
+nt = [r for r in out if 'gemm_nt_' in r['kernel']]      # gemm_nt_kernel, gemm_nt_pp_kernel, gemm_nt_r3_kernel
 summary = dict(step_fetch_gb=round(tot_f / 1e3, 2), step_write_gb=round(tot_w / 1e3, 2),
                gemm_nt=dict(launches=sum(r['launches'] for r in nt), fetch_mb=round(sum(r['fetch_mb'] for r in nt), 1),
                             write_mb=round(sum(r['write_mb'] for r in nt), 1)), kernels=out)
