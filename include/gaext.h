@@ -413,7 +413,7 @@ int ga_conv3s2_dgrad_prep(const float* w, void* out, int Co, int Ci, int64_t ldo
  *       entry t is stored at (t % ntok) * (ntri / ntok) + t / ntok before the grouped layout is applied (ntok = 1: identity).
  *   ga_map_tokens_fwd: e [B][C*T] (channel c*T + t, the bp_reduction output, map.py:231-232) -> tok [B][T (+1)][C];
  *       add_mean: the extra row is the mean over the T tokens (CAP's self-distillation token, map.py:273-275).  _bwd: its transpose.
- *   ga_class_attn_mt_*: ClassAttention with T <= 4 query tokens (map.py:118-144, in_dim == dim branch, no `interactive`):
+ *   ga_class_attn_mt_*: ClassAttention with T <= 4 query tokens (map.py:118-144, in_dim == dim branch; `interactive`: ga_class_attn_mt_ia_* below):
  *       q [B][T][E], kv_cls [B][T][2E] (k | v of the class rows), kv_tok = k | v rows of the N - T image tokens (row stride
  *       tok_ld); P [B][T][heads][N] fp32 = softmax, saved; mask (fp32, same shape, or NULL) = attention dropout mask
  *       (already divided by keep); out [B][T][E].  bwd overwrites dq, dkv_cls and the dkv_tok rows (stride dtok_ld).

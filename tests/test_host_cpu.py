@@ -270,3 +270,25 @@ def test_second_cuda_call_keeps_flat_buffers_and_stale_holders_raise():
     m._flatten()                                  # what a parameter move does
     with pytest.raises(RuntimeError, match='re-created'):
         m.check_flat_generation(gen, 'test')
+
+
+def test_asm_load_audit_flags_a_touched_destination(tmp_path):
+    """tools/asm_load_audit.py (run by the Makefile on every rebuild of gemm.hip): an instruction that touches the destination
+    registers of an inline-asm buffer load before the s_waitcnt that retires it is a finding; the same code with the wait first is not."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'asm_load_audit.py')
+    bad = """_Z9my_kernelv:                           ; @_Z9my_kernelv
+\tbuffer_load_dwordx4 v[4:7], v1, s[8:11], 0 offen
+\tv_add_u32_e32 v5, v2, v3
+\ts_waitcnt vmcnt(0)
+\ts_endpgm
+.Lfunc_end0:
+"""
+    good = bad.replace('\tv_add_u32_e32 v5, v2, v3\n\ts_waitcnt vmcnt(0)\n', '\ts_waitcnt vmcnt(0)\n\tv_add_u32_e32 v5, v2, v3\n')
+    lds = bad.replace('buffer_load_dwordx4 v[4:7], v1, s[8:11], 0 offen', 'buffer_load_dwordx4 v1, s[8:11], 0 offen lds')
+    for text, rc in ((bad, 1), (good, 0), (lds, 0)):
+        f = tmp_path / 'k.s'
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f), 'my_kernel'], capture_output=True, text=True)
+        assert r.returncode == rc, (text, r.stdout, r.stderr)

@@ -59,6 +59,10 @@ parser.add_argument('--dec-lam', type=float, default=None, help='MAP: weight of 
                     '(MAP/train_with_script.py:39, multi_group_loss); alias of --GA_lam for the map_* models')
 parser.add_argument('--no-ddp-bb', action='store_true', help='no per-forward broadcast of the BatchNorm buffers from rank 0 '
                     '(GA/train.py:283,514)')
+parser.add_argument('--sync-bn', action='store_true', help='BatchNorm statistics over the global batch (GA/train.py:247,449-455): the '
+                    'per-channel sums go through the native RCCL communicator; implies --comm native')
+parser.add_argument('--comm', default='torch', choices=['torch', 'native', 'native-bf16'], help='transport of the gradient buckets: '
+                    'torch.distributed, or libgaext\'s own RCCL communicator (ga_allreduce_bucket) with an fp32 / bf16 wire')
 parser.add_argument('--dist-bn', default='reduce', help='"reduce" | "broadcast" | "": distribute the BatchNorm running '
                     'statistics between ranks after every epoch (timm distribute_bn, GA/train.py:665-674)')
 parser.add_argument('--model-ema', action='store_true', help='track an EMA of the weights (timm ModelEmaV2)')
@@ -182,6 +186,13 @@ def main():
     if world > 1:
         dist.broadcast(model.flat_state()['params'], 0)
         dist.broadcast(model.flat_state()['buffers'], 0)
+    comm = None
+    if world > 1 and (args.sync_bn or args.comm != 'torch'):
+        if backend != 'nccl':
+            raise SystemExit('train.py: --comm native / --sync-bn need one GPU per rank (the RCCL communicator of libgaext)')
+        comm = A.NativeComm(wire='bf16' if args.comm == 'native-bf16' else 'fp32')
+        if args.sync_bn:
+            model.convert_sync_batchnorm(comm)
     if rank == 0:
         _logger.info('Model %s created, param count: %d', args.model, sum(p.numel() for p in model.parameters()))
     opt = A.create_optimizer_v2(model, opt=args.opt, lr=args.lr, weight_decay=args.weight_decay, momentum=args.momentum,
@@ -199,7 +210,7 @@ def main():
     step_fn = A.TrainStep(model, opt, args.batch_size, lam=lam, loss='bce' if args.bce_loss else 'ce',
                           smoothing=args.smoothing, grad_accumulation=args.grad_accumulation,
                           clip_grad=args.clip_grad, clip_mode=args.clip_mode, broadcast_buffers=not args.no_ddp_bb,
-                          mixup_fn=mixup_fn, bce_target_thresh=args.bce_target_thresh)
+                          mixup_fn=mixup_fn, bce_target_thresh=args.bce_target_thresh, comm=comm)
     model_ema = A.ModelEma(model, args.model_ema_decay) if args.model_ema else None
     img = getattr(model, 'cfg', {}).get('img_size', 224)
     loader = SyntheticLoader(args.batch_size, args.steps_per_epoch, model.num_classes, args.seed + rank, 'cuda', img)
