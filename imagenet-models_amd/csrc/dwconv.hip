@@ -10,6 +10,7 @@
 //    workgroup walks over many tiles, so only nblocks x 49 x 64 fp32 atomics reach memory.
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -891,10 +892,356 @@ __global__ __launch_bounds__(512) void dwconv7_mfma_kernel(const bf16_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 forward / backward-data, register-sliding NHWC form (no transposition, no workgroup barriers).
+//   lane = one CHANNEL PAIR (one dword of the NHWC row) of a strip of 4 output columns; the wave marches down the rows
+//   of its segment.  Per input row it takes 10 dwords (one per input column; columns outside the image read 0),
+//   converts them to 2 x fp32 once, and feeds them to the SEVEN output rows the input row belongs to: 196 v_pk_fma_f32
+//   (2 channels each) per row, with the weights (49 x 2 fp32) and the 7 x 4 x 2 accumulators of the output rows in
+//   flight in registers.  The accumulator slot of output row q is q % 7: the march is unrolled by 7 rows, so every slot
+//   index is a compile-time constant; R (rows per segment) is a multiple of 7, so the march is head (rows 0 .. 6: tap
+//   rows 0 .. r), steady blocks of 7 rows (all seven tap rows, no checks at all) and tail (rows R .. R + 5: tap rows
+//   t + 1 .. 6) -- straight-line code around one loop, exactly the 49 multiply-adds per output element of the
+//   convolution (plus zero columns at the left / right edge of the image).
+//   Bound: packed-fp32 VALU rate -- the kernel with every memory operation removed runs 87 us for 256 x 56 x 56 x 96
+//   (220 VALU instructions per row and wave; two waves per SIMD at 236 VGPRs) next to an HBM time of 62 us.
+//   Data movement is shaped by the cost of a vector-memory INSTRUCTION (address path: ~16 clocks per 64 lanes whatever
+//   the width; the dword-per-lane version of this kernel spent 40 % of its time there):
+//     * input rows reach the lanes through a per-wave LDS ring filled by `buffer_load_dwordx4 ... lds` THREE rows ahead
+//       of their use (two waves per SIMD cannot hide HBM latency with registers one row ahead).  One instruction
+//       moves 4 columns x 16 channel-pair quads: lane L of instruction k fetches the 16 bytes of quad L % 16 at
+//       column 4 k + L / 16, which land at ring offset 256 (4 k + L / 16) + 16 (L % 16): the [column][lane] dword
+//       image the lanes read back.  3 instructions per row instead of 10 (+ 1 for the residual row);
+//     * output rows leave through a 1 KiB per-wave staging piece ([column][lane] dwords in, 16 bytes per lane out):
+//       ONE 16-byte store per lane and row (+ 1 for the second output).
+//   Every row issues the same number of vector-memory operations (rows outside the image / segment and output rows
+//   not yet complete use a buffer resource of zero records: they fetch zeros / drop the store but still count), so
+//   the counted s_waitcnt in front of the ring read is exact.
+//   Addressing: voffset = per-lane offset (constant down the march), soffset = row base (scalar).
+//   Work unit = (image, segment of R output rows); lanes of a unit = strips x channel pairs, padded to whole waves.
+// ------------------------------------------------------------------------------------------------
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((ext_vector_type(4))) unsigned dw_u4;
+
+__device__ __forceinline__ dw_u4 dw_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    dw_u4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int N> __device__ __forceinline__ void dw_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ring row = 3 x 1 KiB (input columns 0 .. 11, 10 used) [+ 1 KiB: the 4 residual columns].  c0..c2 / cr are the lane offsets
+// minus the instruction offset (which is added to the memory address as well as to the LDS address).
+__device__ __forceinline__ void dw_dma_x(dw_u4 rs, unsigned so, unsigned dst, unsigned c0, unsigned c1, unsigned c2) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c0], %[rs], %[so] offen lds\n\t"
+                 "buffer_load_dwordx4 %[c1], %[rs], %[so] offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %[c2], %[rs], %[so] offen offset:2048 lds\n\t"
+                 "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [c0] "v"(c0), [c1] "v"(c1), [c2] "v"(c2), [rs] "s"(rs), [so] "s"(so), [d] "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void dw_dma_res(dw_u4 rs, unsigned so, unsigned dst, unsigned cr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c], %[rs], %[so] offen offset:3072 lds\n\t"
+                 "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [c] "v"(cr), [rs] "s"(rs), [so] "s"(so), [d] "s"(dst)
+                 : "memory");
+}
+
+#ifndef DW_DBG
+#define DW_DBG 0                                              // timing variants (results wrong): 1 no DMA, 2 no stores, 4 no ring reads
+#endif
+
+template <bool RES, bool Y2> struct DWR {
+    static constexpr int TW = 4, NC = TW + 6;
+    static constexpr int P = 3, D = 4;                        // rows ahead, ring depth
+    static constexpr int GC = 3 + (RES ? 1 : 0);              // DMA operations per row group
+    static constexpr int ROWB = GC * 1024;
+    static constexpr int ST = (DW_DBG & 8) ? 4 : (Y2 ? 2 : 1); // stores per row
+    static constexpr int STAGE = D * ROWB;                    // 1 KiB output staging piece behind the ring
+    static constexpr int WAVE_LDS = D * ROWB + 1024, LDS = 4 * WAVE_LDS;
+    static constexpr int N_STEADY = (P - 1) * GC + P * ST;    // operations younger than row group r + 1 at the wait of row r >= P
+};
+
+
+template <bool RES, bool Y2>
+__global__ __launch_bounds__(256, 2) void dwconv7_rs_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w49,
+                                                            const float* __restrict__ bias, const bf16_t* __restrict__ res,
+                                                            bf16_t* __restrict__ y, int H, int W, int C, int flip,
+                                                            bf16_t* __restrict__ y2, const float* __restrict__ y2scale,
+                                                            int R, int nseg, int nstrips, int wpu, int total_waves,
+                                                            unsigned bytes) {
+    using G = DWR<RES, Y2>;
+    constexpr int TW = G::TW, NC = G::NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (gw >= total_waves) return;
+    const int CP = C >> 1;
+    const int unit = gw / wpu, wi = gw - unit * wpu;
+    const int img = unit / nseg, seg = unit - img * nseg;
+    const int item = wi * 64 + lane;
+    const int strip = item / CP;
+    const bool active = strip < nstrips;
+    const int cp = active ? item - strip * CP : 0;
+    const int oy0 = seg * R;
+
+    unsigned char* wsm = smem + wv * G::WAVE_LDS;
+    const unsigned wring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + wv * G::WAVE_LDS;
+    const unsigned* ring = reinterpret_cast<const unsigned*>(wsm) + lane;
+    unsigned* stage_w = reinterpret_cast<unsigned*>(wsm + G::STAGE) + lane;                  // [column][lane] dwords in
+    const uint4* stage_r = reinterpret_cast<const uint4*>(wsm + G::STAGE) + lane;            // 16 bytes per lane out
+    const dw_u4 rx = dw_make_rsrc(x, bytes), rres = dw_make_rsrc(RES ? res : x, bytes);
+    const __amdgpu_buffer_rsrc_t ry = dw_rsrc(y, bytes), ry_off = dw_rsrc(y, 0), ry2 = dw_rsrc(Y2 ? y2 : y, bytes),
+                                 ry2_off = dw_rsrc(Y2 ? y2 : y, 0);
+    // the 16-byte pieces this lane moves: channel-pair quad lane % 16 of the wave (4 consecutive lanes: C % 8 == 0 keeps a
+    // quad inside one strip), at column (lane / 16) + 4 k relative to the strip's first input column
+    unsigned cx[3], cr, cs;
+    {
+        const int qitem = wi * 64 + 4 * (lane & 15);
+        const int qstrip = qitem / CP;
+        const int qcp = qitem - qstrip * CP;
+        const bool qa = qstrip < nstrips;
+        auto off = [&](int col) {                  // col: image column
+            return (qa && (unsigned)col < (unsigned)W) ? (unsigned)(col * C + 2 * qcp) * 2u : 0x80000000u;
+        };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = 4 * k + (lane >> 4);
+            cx[k] = (j < NC ? off(qstrip * TW + j - 3) : 0x80000000u) - 1024u * k;
+        }
+        cs = off(qstrip * TW + (lane >> 4));       // output / residual column (lane / 16) of the quad's strip
+        cr = cs - 3072u;
+    }
+    dw_f2 w[49];
+#pragma unroll
+    for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const dw_f2*>(w49 + (long)(flip ? 48 - t : t) * C + 2 * cp);
+    dw_f2 bv = {0.f, 0.f};
+    if (bias) bv = *reinterpret_cast<const dw_f2*>(bias + 2 * cp);
+    const float sc2 = Y2 ? y2scale[img] : 0.f;
+    // every register load of the kernel is complete before the first DMA: from here on the compiler has nothing to wait for
+    // on the vector-memory counter, and the hand-counted waits below see only the ring's DMA and the stores
+#pragma unroll
+    for (int t = 0; t < 49; ++t) asm volatile("" : "+v"(w[t]));
+    asm volatile("" : "+v"(bv));
+    dw_wait_vm<0>();
+
+    const unsigned rowb = (unsigned)W * C * 2u;
+    const unsigned img_base = (unsigned)img * H * rowb;
+    const int iy0 = oy0 - 3, nr = R + 6;
+    auto issue = [&](int r) {                      // row group r: input row iy0 + r (and the residual of output row r - 6)
+        const int iy = iy0 + r;
+        const bool v = r < nr && (unsigned)iy < (unsigned)H;
+        dw_u4 rs = rx;
+        rs[2] = v ? bytes : 0u;
+        const unsigned dst = wring + (unsigned)(r & (G::D - 1)) * G::ROWB;
+        dw_dma_x(rs, v ? img_base + iy * rowb : 0u, dst, cx[0], cx[1], cx[2]);
+        if constexpr (RES) {
+            const int qd = r - 6;
+            const bool vr = qd >= 0 && qd < R;
+            dw_u4 rq = rres;
+            rq[2] = vr ? bytes : 0u;
+            dw_dma_res(rq, vr ? img_base + (oy0 + qd) * rowb : 0u, dst, cr);
+        }
+    };
+    unsigned raw[NC] = {}, rsd[TW] = {};           // ring row r + 1 (and its residual columns), read while row r is multiplied
+    auto read_row = [&](int r) {
+        const unsigned* rowp = ring + (r & (G::D - 1)) * (G::ROWB / 4);
+#pragma unroll
+        for (int j = 0; j < NC; ++j) raw[j] = rowp[j * 64];
+        if constexpr (RES) {
+#pragma unroll
+            for (int o = 0; o < TW; ++o) rsd[o] = rowp[(12 + o) * 64];
+        }
+    };
+    dw_f2 in[NC];
+    unsigned rs[TW];
+    auto unpack_row = [&]() {
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            in[j].x = __uint_as_float(raw[j] << 16);
+            in[j].y = __uint_as_float(raw[j] & 0xffff0000u);
+        }
+        if constexpr (RES) {
+#pragma unroll
+            for (int o = 0; o < TW; ++o) rs[o] = rsd[o];
+        }
+    };
+#pragma unroll
+    for (int r = 0; r <= G::P; ++r) issue(r);
+    dw_wait_vm<G::P * G::GC>();
+    read_row(0);
+    unpack_row();
+
+    dw_f2 acc[7][TW];
+#pragma unroll
+    for (int s = 0; s < 7; ++s)
+#pragma unroll
+        for (int o = 0; o < TW; ++o) acc[s][o] = bv;
+
+    // One input row r of the march (slot base RR = r % 7, compile-time): tap rows KLO .. KHI are the ones whose output row lies
+    // in the segment.  Operations younger than group r + 1 at its wait: P - 1 groups and min(r, P) store sets.
+    auto row_iter = [&](int r, auto rr_c, auto klo_c, auto khi_c, auto early_c, auto edge_c) {
+        constexpr int RR = decltype(rr_c)::value, KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value;
+        constexpr int EARLY = decltype(early_c)::value;         // r if r < P (head), else -1
+        constexpr bool EDGE = decltype(edge_c)::value;          // head / tail row: the input row may lie outside the image
+        if (!(DW_DBG & 1)) dw_wait_vm<(EARLY >= 0 ? (G::P - 1) * G::GC + EARLY * G::ST : G::N_STEADY)>();
+        if (!(DW_DBG & 4)) read_row(r + 1);
+        else {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) asm volatile("" : "+v"(raw[j]));      // keep the unpacking work
+        }
+        if (!(DW_DBG & 1)) issue(r + 1 + G::P);                // into the slot of row r, whose dwords are in `in` already
+#pragma unroll
+        for (int o = 0; o < TW; ++o) acc[RR][o] = bv;          // output row q = r starts in slot r % 7
+        if (!EDGE || (unsigned)(iy0 + r) < (unsigned)H) {
+#pragma unroll
+            for (int ky = KLO; ky <= KHI; ++ky) {
+                const int slot = (RR - ky + 7) % 7;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+                    for (int o = 0; o < TW; ++o)
+                        acc[slot][o] = __builtin_elementwise_fma(in[o + kx], w[ky * 7 + kx], acc[slot][o]);
+            }
+        }
+        {                                                       // output row r - 6 is complete (a dropped store while r < 6)
+            const int qd = r - 6;
+            const bool st = qd >= 0;
+            constexpr int slot = (RR + 1) % 7;
+            const unsigned so = st ? img_base + (oy0 + qd) * rowb : 0u;
+            const __amdgpu_buffer_rsrc_t r1 = st ? ry : ry_off, r2 = st ? ry2 : ry2_off;
+            unsigned pk[TW];
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {
+                dw_f2 a = acc[slot][o];
+                if constexpr (RES) {
+                    a.x += __uint_as_float(rs[o] << 16);
+                    a.y += __uint_as_float(rs[o] & 0xffff0000u);
+                }
+                pk[o] = pack2bf(a.x, a.y);
+                if (DW_DBG & 8) {                                   // dword stores straight from the lanes (no staging)
+                    const int ix = strip * TW + o;
+                    const unsigned co = (active && ix < W) ? (unsigned)(ix * C + 2 * cp) * 2u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b32(pk[o], r1, co, so, 0);
+                } else
+                    stage_w[o * 64] = pk[o];
+            }
+            if (DW_DBG & 8) {
+                unpack_row();
+                return;
+            }
+            asm volatile("" ::: "memory");                      // (compiler: the 16-byte read below aliases the dword writes above)
+            uint4 v = *stage_r;                                 // LDS operations of one wave execute in order: no barrier
+            // The staged dwords stay in their registers until the read-back has RETURNED.  Measured on gfx950: with LDS-DMA
+            // in flight, a ds_write fetches the data of its last lanes late, and the VALU instruction hipcc schedules right
+            // behind it (the next row's unpacking, into the same registers) reached lanes 48-63 of the staged row first.
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(pk[0]), "+v"(pk[1]), "+v"(pk[2]), "+v"(pk[3])::"memory");
+            if (DW_DBG & 2) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+            else {
+                // a 16-byte store fetches its data over several cycles: nothing may overwrite the registers in the two wait
+                // states behind it (hipcc pads this hazard only for stores without an SGPR offset; on gfx950 a v_pk_mul it
+                // scheduled right behind such a store reached dwords 2-3 of some lanes first)
+                dw_u4 d1 = {v.x, v.y, v.z, v.w};
+                __builtin_amdgcn_raw_buffer_store_b128(d1, r1, cs, so, 0);
+                asm volatile("s_nop 1" ::"v"(d1) : "memory");
+                if constexpr (Y2) {
+                    float f[8];
+                    unpack8(v, f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] *= sc2;
+                    dw_u4 d2 = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(d2, r2, cs, so, 0);
+                    asm volatile("s_nop 1" ::"v"(d2) : "memory");
+                }
+            }
+        }
+        unpack_row();                                           // ring row r + 1 -> registers of the next iteration
+    };
+#define DW_IC(v) std::integral_constant<int, (v)>{}
+#define DW_HEAD(r) row_iter(r, DW_IC(r), DW_IC(0), DW_IC(r), DW_IC((r) < G::P ? (r) : -1), std::true_type{})
+#define DW_BODY(rr) row_iter(r0 + rr, DW_IC(rr), DW_IC(0), DW_IC(6), DW_IC(-1), std::false_type{})
+#define DW_TAIL(t) row_iter(R + t, DW_IC(t), DW_IC(t + 1), DW_IC(6), DW_IC(-1), std::true_type{})
+    DW_HEAD(0); DW_HEAD(1); DW_HEAD(2); DW_HEAD(3); DW_HEAD(4); DW_HEAD(5); DW_HEAD(6);
+    for (int r0 = 7; r0 < R; r0 += 7) {
+        DW_BODY(0); DW_BODY(1); DW_BODY(2); DW_BODY(3); DW_BODY(4); DW_BODY(5); DW_BODY(6);
+    }
+    DW_TAIL(0); DW_TAIL(1); DW_TAIL(2); DW_TAIL(3); DW_TAIL(4); DW_TAIL(5);
+#undef DW_HEAD
+#undef DW_BODY
+#undef DW_TAIL
+#undef DW_IC
+    dw_wait_vm<0>();                               // no DMA may still be landing when the LDS is handed to the next workgroup
+}
+
+template <bool RES, bool Y2>
+int launch_dwconv_rs_t(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W, int C,
+                       int flip, hipStream_t s, void* y2, const float* y2scale) {
+    using G = DWR<RES, Y2>;
+    auto k = dwconv7_rs_kernel<RES, Y2>;
+    static const bool attr_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) == hipSuccess;
+    if (!attr_ok) {
+        ga_set_error("dwconv7: cannot reserve %d B of LDS", G::LDS);
+        return GA_ERR_HIP;
+    }
+    const int nstrips = cdiv(W, G::TW);
+    const int wpu = cdiv(nstrips * (C / 2), 64);
+    // rows per segment: a multiple of 7 that divides H -- the longest march (least halo re-reading, fewest wave starts) that
+    // still gives every SIMD its two waves (measured at 256 x 56 x 56 x 96: R = 56 0.101 ms, 28 0.118, 14 0.130)
+    int R = GA_KNOB("DW_RS_ROWS", 0);
+    if (R <= 0 || R % 7 != 0 || H % R != 0) {
+        const long slots = 8L * num_cus();
+        R = 7;
+        for (int d = 1; d <= H / 7; ++d) {
+            if ((H / 7) % d != 0) continue;
+            const int r = H / d;                   // candidates from the longest down
+            if (r % 7 == 0 && (long)B * d * wpu >= slots) {
+                R = r;
+                break;
+            }
+        }
+    }
+    const int nseg = H / R;
+    const long waves = (long)B * nseg * wpu;
+    const unsigned bytes = (unsigned)((long)B * H * W * C * 2);
+    hipLaunchKernelGGL(k, dim3((unsigned)cdiv(waves, 4L)), dim3(256), G::LDS, s, (const bf16_t*)x, w49, bias, (const bf16_t*)res,
+                       (bf16_t*)y, H, W, C, flip, (bf16_t*)y2, y2scale, R, nseg, nstrips, wpu, (int)waves, bytes);
+    return ga_check_launch("ga_dwconv7");
+}
+
+int launch_dwconv_rs(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W, int C,
+                     int flip, hipStream_t s, void* y2, const float* y2scale) {
+#define DW_RS_GO(RES, Y2) return launch_dwconv_rs_t<RES, Y2>(x, w49, bias, res, y, B, H, W, C, flip, s, y2, y2scale)
+    const bool r = res != nullptr, t = y2 != nullptr;
+    if (r && t) DW_RS_GO(true, true);
+    if (r) DW_RS_GO(true, false);
+    if (t) DW_RS_GO(false, true);
+    DW_RS_GO(false, false);
+#undef DW_RS_GO
+}
+
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s, void* y2 = nullptr, const float* y2scale = nullptr) {
     if constexpr (sizeof(T) == 2) {
+        // register-sliding form (default): C a multiple of 8, H a multiple of 7, any W, tensors below 2 GiB (32-bit buffer offsets)
+        if (C % 8 == 0 && H % 7 == 0 && (long)B * H * W * C * 2 < (1L << 31) && (long)B * (H / 7) * cdiv(W, 4) * C < (1L << 31) &&
+            GA_KNOB("DW_RS", 1))
+            return launch_dwconv_rs(x, w49, bias, res, y, B, H, W, C, flip, s, y2, y2scale);
         if (C % 8 == 0) {
             using G14 = DWF<14, 14>;
             using G7 = DWF<7, 7>;
