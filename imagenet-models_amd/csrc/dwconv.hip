@@ -1234,6 +1234,261 @@ int launch_dwconv_rs(const void* x, const float* w49, const float* bias, const v
 #undef DW_RS_GO
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 backward-weight, the same register-sliding march: dW[ky][kx][c] = sum dy[oy][ox][c] x[oy + ky - 3][ox + kx - 3][c].
+//   lane = channel pair of a strip of 4 output columns; it keeps its 49 x 2 partial sums (and the bias sums) in registers
+//   over EVERY unit (image, row segment) it walks; per input row: the row's 10 dwords and the dy row that starts there come
+//   from the LDS-DMA ring (4 instructions per row), dy rows of the 7 output rows in flight stay unpacked in registers
+//   (slot q % 7), 196 v_pk_fma_f32 per row -- the forward kernel's arithmetic with the roles of weights and accumulators
+//   swapped, no stores in the loop.
+//   Grid: persistent, workgroup b serves wave position wi = b % wpu of the units (all four waves of a workgroup share the
+//   lane -> (strip, channel pair) map, each walks its own units); at the end the four waves meet in LDS and the
+//   workgroup writes ONE partial of 100 x 64 floats; dwconv7_wgrad_rs_reduce adds the partials of all workgroups and
+//   strips in a fixed order (deterministic).
+// ------------------------------------------------------------------------------------------------
+struct DWW {
+    static constexpr int TW = 4, NC = 10;
+    static constexpr int P = 3, D = 4, GC = 4;                // rows ahead, ring depth, DMA operations per row (3 x + 1 dy)
+    static constexpr int ROWB = GC * 1024, WAVE_LDS = D * ROWB, LDS = 4 * WAVE_LDS;     // 64 KiB per workgroup
+    static constexpr int NV = 100;                            // values per lane: 49 taps x 2 channels + 2 bias sums
+};
+
+__global__ __launch_bounds__(256, 2) void dwconv7_wgrad_rs_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                  float* __restrict__ part, int H, int W, int C, int R, int nseg,
+                                                                  int nstrips, int wpu, int nunits, unsigned bytes) {
+    using G = DWW;
+    constexpr int TW = G::TW, NC = G::NC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wi = blockIdx.x % wpu, kb = blockIdx.x / wpu, nbw = gridDim.x / wpu;      // gridDim.x is a multiple of wpu
+    const int CP = C >> 1;
+
+    unsigned char* wsm = smem + wv * G::WAVE_LDS;
+    const unsigned wring = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem + wv * G::WAVE_LDS;
+    const unsigned* ring = reinterpret_cast<const unsigned*>(wsm) + lane;
+    const dw_u4 rx = dw_make_rsrc(x, bytes), rdy = dw_make_rsrc(dy, bytes);
+    unsigned cx[3], cd;
+    {
+        const int qitem = wi * 64 + 4 * (lane & 15);
+        const int qstrip = qitem / CP;
+        const int qcp = qitem - qstrip * CP;
+        const bool qa = qstrip < nstrips;
+        auto off = [&](int col) {
+            return (qa && (unsigned)col < (unsigned)W) ? (unsigned)(col * C + 2 * qcp) * 2u : 0x80000000u;
+        };
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = 4 * k + (lane >> 4);
+            cx[k] = (j < NC ? off(qstrip * TW + j - 3) : 0x80000000u) - 1024u * k;
+        }
+        cd = off(qstrip * TW + (lane >> 4)) - 3072u;
+    }
+    dw_f2 acc[49], bs = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 49; ++t) acc[t] = dw_f2{0.f, 0.f};
+
+    const unsigned rowb = (unsigned)W * C * 2u;
+    const int nr = R + 6;
+    for (int unit = kb * 4 + wv; unit < nunits; unit += 4 * nbw) {
+        const int img = unit / nseg, seg = unit - img * nseg;
+        const int oy0 = seg * R, iy0 = oy0 - 3;
+        const unsigned img_base = (unsigned)img * H * rowb;
+        auto issue = [&](int r) {                  // row group r: input row iy0 + r and dy row oy0 + r
+            const int iy = iy0 + r;
+            const bool v = r < nr && (unsigned)iy < (unsigned)H;
+            dw_u4 rs = rx;
+            rs[2] = v ? bytes : 0u;
+            const unsigned dst = wring + (unsigned)(r & (G::D - 1)) * G::ROWB;
+            dw_dma_x(rs, v ? img_base + iy * rowb : 0u, dst, cx[0], cx[1], cx[2]);
+            const bool vd = r < R;
+            dw_u4 rq = rdy;
+            rq[2] = vd ? bytes : 0u;
+            dw_dma_res(rq, vd ? img_base + (oy0 + r) * rowb : 0u, dst, cd);
+        };
+        unsigned raw[NC] = {}, rawd[TW] = {};
+        auto read_row = [&](int r) {
+            const unsigned* rowp = ring + (r & (G::D - 1)) * (G::ROWB / 4);
+#pragma unroll
+            for (int j = 0; j < NC; ++j) raw[j] = rowp[j * 64];
+#pragma unroll
+            for (int o = 0; o < TW; ++o) rawd[o] = rowp[(12 + o) * 64];
+        };
+        dw_f2 in[NC], g[7][TW];                    // input row r; dy rows of the 7 output rows in flight (slot q % 7)
+#pragma unroll
+        for (int q = 0; q < 7; ++q)
+#pragma unroll
+            for (int o = 0; o < TW; ++o) g[q][o] = dw_f2{0.f, 0.f};
+        unsigned gd[TW];
+        auto unpack_row = [&]() {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                in[j].x = __uint_as_float(raw[j] << 16);
+                in[j].y = __uint_as_float(raw[j] & 0xffff0000u);
+            }
+#pragma unroll
+            for (int o = 0; o < TW; ++o) gd[o] = rawd[o];
+        };
+#pragma unroll
+        for (int r = 0; r <= G::P; ++r) issue(r);
+        dw_wait_vm<G::P * G::GC>();
+        read_row(0);
+        unpack_row();
+
+        auto row_iter = [&](int r, auto rr_c, auto klo_c, auto khi_c, auto edge_c) {
+            constexpr int RR = decltype(rr_c)::value, KLO = decltype(klo_c)::value, KHI = decltype(khi_c)::value;
+            constexpr bool EDGE = decltype(edge_c)::value;
+            dw_wait_vm<(G::P - 1) * G::GC>();                  // ring row r + 1 has landed (the loop has no other memory operation)
+            read_row(r + 1);
+            issue(r + 1 + G::P);
+#pragma unroll
+            for (int o = 0; o < TW; ++o) {                      // dy row q = r enters slot r % 7 (zeros beyond the segment)
+                g[RR][o].x = __uint_as_float(gd[o] << 16);
+                g[RR][o].y = __uint_as_float(gd[o] & 0xffff0000u);
+                if (KLO == 0) bs += g[RR][o];
+            }
+            if (!EDGE || (unsigned)(iy0 + r) < (unsigned)H) {
+#pragma unroll
+                for (int ky = KLO; ky <= KHI; ++ky) {
+                    const int slot = (RR - ky + 7) % 7;
+#pragma unroll
+                    for (int o = 0; o < TW; ++o)               // column outermost: consecutive FMAs hit different accumulators
+#pragma unroll
+                        for (int kx = 0; kx < 7; ++kx)
+                            acc[ky * 7 + kx] = __builtin_elementwise_fma(g[slot][o], in[o + kx], acc[ky * 7 + kx]);
+                }
+            }
+            unpack_row();
+        };
+#define DW_IC(v) std::integral_constant<int, (v)>{}
+#define DW_HEAD(r) row_iter(r, DW_IC(r), DW_IC(0), DW_IC(r), std::true_type{})
+#define DW_BODY(rr) row_iter(r0 + rr, DW_IC(rr), DW_IC(0), DW_IC(6), std::false_type{})
+#define DW_TAIL(t) row_iter(R + t, DW_IC(t), DW_IC(t + 1), DW_IC(6), std::true_type{})
+        DW_HEAD(0); DW_HEAD(1); DW_HEAD(2); DW_HEAD(3); DW_HEAD(4); DW_HEAD(5); DW_HEAD(6);
+        for (int r0 = 7; r0 < R; r0 += 7) {
+            DW_BODY(0); DW_BODY(1); DW_BODY(2); DW_BODY(3); DW_BODY(4); DW_BODY(5); DW_BODY(6);
+        }
+        DW_TAIL(0); DW_TAIL(1); DW_TAIL(2); DW_TAIL(3); DW_TAIL(4); DW_TAIL(5);
+#undef DW_HEAD
+#undef DW_BODY
+#undef DW_TAIL
+#undef DW_IC
+        dw_wait_vm<0>();                           // the ring is re-used by the next unit / by the reduction below
+    }
+    // the four waves meet in LDS ([value][lane] floats, 25 KiB per wave image): 2 + 3 -> 0 + 1, then 1 -> 0
+    float* red = reinterpret_cast<float*>(smem);
+    auto dump = [&](int slot) {
+        float* p = red + slot * (G::NV * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 49; ++t) {
+            p[(2 * t) * 64] = acc[t].x;
+            p[(2 * t + 1) * 64] = acc[t].y;
+        }
+        p[98 * 64] = bs.x;
+        p[99 * 64] = bs.y;
+    };
+    auto add = [&](int slot) {
+        const float* p = red + slot * (G::NV * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 49; ++t) {
+            acc[t].x += p[(2 * t) * 64];
+            acc[t].y += p[(2 * t + 1) * 64];
+        }
+        bs.x += p[98 * 64];
+        bs.y += p[99 * 64];
+    };
+    __syncthreads();
+    if (wv >= 2) dump(wv - 2);
+    __syncthreads();
+    if (wv < 2) add(wv);
+    __syncthreads();
+    if (wv == 1) dump(0);
+    __syncthreads();
+    if (wv == 0) {
+        add(0);
+        float* pp = part + (long)blockIdx.x * (G::NV * 64) + lane;
+#pragma unroll
+        for (int t = 0; t < 49; ++t) {
+            pp[(2 * t) * 64] = acc[t].x;
+            pp[(2 * t + 1) * 64] = acc[t].y;
+        }
+        pp[98 * 64] = bs.x;
+        pp[99 * 64] = bs.y;
+    }
+}
+
+// dw49[tap][c] += sum over strips and workgroups of the partials; dbias[c] likewise.  workgroup = (64 channel pairs, value v of
+// the 100) x 4 groups of workgroups; fixed summation order (deterministic)
+__global__ __launch_bounds__(256) void dwconv7_wgrad_rs_reduce(const float* __restrict__ part, int nbw, int wpu, int nstrips, int C,
+                                                               float* __restrict__ dw49, float* __restrict__ dbias) {
+    __shared__ float red[4][64];
+    const int CP = C >> 1;
+    const int cpl = threadIdx.x & 63, kg = threadIdx.x >> 6;
+    const int cp = blockIdx.x * 64 + cpl, v = blockIdx.y;
+    float sum = 0.f;
+    if (cp < CP) {
+        const int per = (nbw + 3) / 4, k0 = kg * per, k1 = min(nbw, k0 + per);
+        for (int st = 0; st < nstrips; ++st) {
+            const int item = st * CP + cp, wi = item >> 6, l = item & 63;
+            const float* p = part + (long)wi * (DWW::NV * 64) + v * 64 + l;
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) sum += p[(long)k * wpu * (DWW::NV * 64)];
+        }
+    }
+    red[kg][cpl] = sum;
+    __syncthreads();
+    if (kg == 0 && cp < CP) {
+        sum = (red[0][cpl] + red[1][cpl]) + (red[2][cpl] + red[3][cpl]);
+        const int tap = v >> 1, e = v & 1;
+        if (tap < 49) dw49[(long)tap * C + 2 * cp + e] += sum;
+        else if (dbias) dbias[2 * cp + e] += sum;
+    }
+}
+
+// geometry of the register-sliding backward-weight form: rows per segment, workgroups (a multiple of wpu), or 0 if it does not apply
+inline bool dww_rs_geometry(int B, int H, int W, int C, int* R_out, int* wpu_out, int* nb_out) {
+    if (C % 8 != 0 || H % 7 != 0 || (long)B * H * W * C * 2 >= (1L << 31)) return false;
+    const int nstrips = cdiv(W, DWW::TW);
+    const int wpu = cdiv(nstrips * (C / 2), 64);
+    const int nbw = std::max(1, 2 * num_cus() / wpu);          // two workgroups per CU
+    // rows per segment: the longest march that still gives each of the 4 * nbw waves of a lane map about two units
+    int R = GA_KNOB("DWW_RS_ROWS", 0);
+    if (R <= 0 || R % 7 != 0 || H % R != 0) {
+        R = 7;
+        for (int d = 1; d <= H / 7; ++d) {
+            if ((H / 7) % d != 0) continue;
+            const int r = H / d;
+            if (r % 7 == 0 && (long)B * d >= 8L * nbw) {
+                R = r;
+                break;
+            }
+        }
+    }
+    *R_out = R;
+    *wpu_out = wpu;
+    *nb_out = nbw * wpu;
+    return true;
+}
+
+int launch_dwconv_wgrad_rs(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C, float* part,
+                           hipStream_t s) {
+    int R, wpu, nb;
+    dww_rs_geometry(B, H, W, C, &R, &wpu, &nb);
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_wgrad_rs_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, DWW::LDS) == hipSuccess;
+    if (!attr_ok) {
+        ga_set_error("dwconv7_wgrad: cannot reserve %d B of LDS", DWW::LDS);
+        return GA_ERR_HIP;
+    }
+    const int nseg = H / R, nstrips = cdiv(W, DWW::TW);
+    const unsigned bytes = (unsigned)((long)B * H * W * C * 2);
+    hipLaunchKernelGGL(dwconv7_wgrad_rs_kernel, dim3(nb), dim3(256), DWW::LDS, s, (const bf16_t*)dy, (const bf16_t*)x, part, H, W, C, R,
+                       nseg, nstrips, wpu, B * nseg, bytes);
+    hipLaunchKernelGGL(dwconv7_wgrad_rs_reduce, dim3(cdiv(C / 2, 64), DWW::NV), dim3(256), 0, s, part, nb / wpu, wpu, nstrips, C, dw49,
+                       dbias);
+    return ga_check_launch("ga_dwconv7_bwd_weight");
+}
+
 template <typename T>
 int launch_dwconv(const void* x, const float* w49, const float* bias, const void* res, void* y, int B, int H, int W,
                   int C, int flip, hipStream_t s, void* y2 = nullptr, const float* y2scale = nullptr) {
@@ -1318,6 +1573,16 @@ void dwconv_wgrad_geometry(int B, int H, int W, int C, bool bf16, int* gx_out, i
     *nparts_out = gx * (big ? 2 : 1);          // one partial per (workgroup, group of 7 output rows)
 }
 
+// bytes of partial sums the backward-weight launch of this geometry needs (the larger of the forms that may serve it)
+size_t dwconv_wgrad_ws_bytes(int B, int H, int W, int C, bool bf16) {
+    int gx, nparts;
+    dwconv_wgrad_geometry(B, H, W, C, bf16, &gx, &nparts);
+    size_t need = (size_t)nparts * 50 * C * sizeof(float);
+    int R, wpu, nb;
+    if (bf16 && dww_rs_geometry(B, H, W, C, &R, &wpu, &nb)) need = std::max(need, (size_t)nb * DWW::NV * 64 * sizeof(float));
+    return need;
+}
+
 template <typename T>
 int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W, int C,
                         float* part, size_t ws_bytes, hipStream_t s) {
@@ -1326,12 +1591,20 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
     const bool dot2 = sizeof(T) == 2 && C % 8 == 0;
     int gx, nparts;
     dwconv_wgrad_geometry(B, H, W, C, sizeof(T) == 2, &gx, &nparts);
-    if (!part || ws_bytes < (size_t)nparts * 50 * C * sizeof(float)) {
+    const size_t need = dwconv_wgrad_ws_bytes(B, H, W, C, sizeof(T) == 2);
+    if (!part || ws_bytes < need) {
         ga_set_error("ga_dwconv7_bwd_weight: needs %zu B of caller-provided workspace (ga_dwconv7_bwd_weight_workspace), got %zu",
-                     (size_t)nparts * 50 * C * sizeof(float), part ? ws_bytes : (size_t)0);
+                     need, part ? ws_bytes : (size_t)0);
         return GA_ERR_BAD_ARG;
     }
     if constexpr (sizeof(T) == 2) {
+        int rsR, rsW, rsN;
+        // register-sliding form: 0 never, 1 (default) on 56 x 56 maps and larger (256 x 56 x 56 x 96: 0.127 vs 0.187 ms; on the
+        // smaller maps its per-unit start-up and the 13 MB of partials eat the gain: 28 x 28 0.074 vs 0.076, 14 x 14 0.049 vs 0.043),
+        // 2 wherever it applies
+        const int use_rs = GA_KNOB("DWW_RS", 1);
+        if (use_rs && (use_rs == 2 || H * W >= 56 * 56) && dww_rs_geometry(B, H, W, C, &rsR, &rsW, &rsN))
+            return launch_dwconv_wgrad_rs(dy, x, dw49, dbias, B, H, W, C, part, s);
         if (dot2) {
             auto k14 = dwconv7_wgrad_dot2_kernel<14, 14>;
             auto k7 = dwconv7_wgrad_dot2_kernel<7, 7>;
@@ -1408,9 +1681,7 @@ extern "C" int ga_dwconv7_bwd_data2(const void* dy, const float* w49, const void
 
 extern "C" size_t ga_dwconv7_bwd_weight_workspace(int B, int H, int W, int C, int dtype) {
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-    int gx, nparts;
-    dwconv_wgrad_geometry(B, H, W, C, dtype == GA_BF16, &gx, &nparts);
-    return (size_t)nparts * 50 * C * sizeof(float);
+    return dwconv_wgrad_ws_bytes(B, H, W, C, dtype == GA_BF16);
 }
 
 extern "C" int ga_dwconv7_bwd_weight(const void* dy, const void* x, float* dw49, float* dbias, int B, int H, int W,

@@ -462,11 +462,17 @@ def test_weight_prep_fold_unfold(dt):
 # ----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('dt', DT)
 @pytest.mark.parametrize('geom', [(2, 14, 14, 96), (1, 28, 28, 72), (3, 7, 7, 128), (2, 10, 9, 16), (1, 56, 56, 32),
-                                  (2, 28, 28, 40, 'mfma')])
+                                  (2, 28, 28, 40, 'mfma'), (2, 14, 14, 96, 'lds'), (1, 56, 56, 32, 'lds'), (3, 28, 21, 48, 'rs'),
+                                  (5, 14, 14, 192, 'rs'), (2, 7, 7, 768, 'rs')])
 def test_dwconv7(dt, geom, knobs):
     ops = _imp()
-    if len(geom) == 5:     # force the matrix-core (Toeplitz) form of the bf16 forward / backward-data kernel
-        knobs(DW_MFMA=2)
+    if len(geom) == 5:
+        if geom[4] == 'mfma':     # force the matrix-core (Toeplitz) form of the bf16 forward / backward-data kernel
+            knobs(DW_RS=0, DW_MFMA=2)
+        elif geom[4] == 'lds':    # the LDS-staged dot2 forms (what serves maps whose height is not a multiple of 7)
+            knobs(DW_RS=0, DWW_RS=0)
+        else:                     # the register-sliding forms everywhere they apply (backward-weight: also on small maps)
+            knobs(DWW_RS=2)
         geom = geom[:4]
     Bn, H, W, Cc = geom
     g = gen(11)
@@ -490,7 +496,7 @@ def test_dwconv7(dt, geom, knobs):
     assert_close(DX, xx.grad.permute(0, 2, 3, 1) + r, tol(dt), 'dwconv bwd data')
     # second output: the stored dx times a per-image factor (the next block's DropPath scale), bit-identical to a
     # separate ga_rowscale pass over dx
-    sc = torch.tensor([0.0, 1.25, 2.0, 1.0][:Bn], device='cuda')
+    sc = torch.tensor(([0.0, 1.25, 2.0, 1.0, 0.5] * 2)[:Bn], device='cuda')
     DXa, DX2, REF2 = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
     P.dwconv7_bwd_data(DY, w49, R, DXa, Bn, H, W, Cc, ops.ga_dtype(dt), dx2=DX2, scale2=sc)
     P.rowscale(DXa, sc, REF2, DXa.numel(), H * W * Cc, ops.ga_dtype(dt))
