@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--no-measured-peaks', action='store_true')
     ap.add_argument('--no-ddp-bb', action='store_true', help='no per-forward BatchNorm buffer broadcast (GA/train.py:283)')
     ap.add_argument('--kernel-table', default='', help='write the per-kernel-family table (json) here')
+    ap.add_argument('--overlap-optimizer', action='store_true', help='optimizer update behind each gradient bucket instead of '
+                    'after the whole backward (A/B: slower on one GPU)')
     ap.add_argument('--comm', default='torch', choices=['torch', 'native', 'native-bf16'],
                     help="gradient exchange for N > 1: torch.distributed's nccl (= RCCL) backend, or the library's own RCCL entry points "
                          '(ga_allreduce_bucket; native-bf16: bf16 wire)')
@@ -275,7 +277,7 @@ def main():
     if a.comm != 'torch' and (world > 1 or a.force_buckets):
         comm = A.NativeComm(wire='bf16' if a.comm == 'native-bf16' else 'fp32')
     step = A.TrainStep(model, opt, a.batch, lam=-0.8, loss='ce', broadcast_buffers=not a.no_ddp_bb, comm=comm,
-                       force_buckets=a.force_buckets)
+                       force_buckets=a.force_buckets, overlap_optimizer=a.overlap_optimizer)
     g = torch.Generator().manual_seed(42 + rank)
     img = getattr(model, 'cfg', {}).get('img_size', 224)
     x = torch.randn(a.batch, 3, img, img, generator=g).cuda()

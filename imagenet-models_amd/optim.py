@@ -19,6 +19,7 @@ class _FlatOptimizer:
         self.gen = st['gen']
         self.steps = 0
         self._hp_host = None
+        self._range_plans = {}
 
     @property
     def lr(self):
@@ -44,6 +45,40 @@ class _FlatOptimizer:
         for e in self.model._engines.values():
             e.weights_dirty = True
 
+    # ---- update by slices of the flat buffers (TrainStep: a gradient bucket is updated, and zeroed, as soon as backward has
+    # completed it, on a side stream, while the rest of backward runs).  step_begin / step_range* / step_end == step.
+    supports_ranges = False
+
+    def _range_launch(self, plan, off, n, mult):  # pragma: no cover
+        raise NotImplementedError
+
+    def _begin(self):  # pragma: no cover
+        raise NotImplementedError
+
+    def range_plan(self, lo, hi):
+        key = (lo, hi)
+        pl = self._range_plans.get(key)
+        if pl is None:
+            pl = Plan(name=f'{type(self).__name__.lower()}[{lo}:{hi}]')
+            for off, n, mult in self._segments():
+                a, b = max(lo, off), min(hi, off + n)
+                if b > a:
+                    self._range_launch(pl, a, b - a, mult)
+            pl.zero(self.g[lo:hi])
+            self._range_plans[key] = pl
+        return pl
+
+    def step_begin(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
+        self._begin()
+
+    def step_range(self, lo, hi, stream=None):
+        """update parameters [lo, hi) from their (final) gradients and zero the gradients, on `stream`"""
+        self.range_plan(lo, hi).run(stream)
+
+    def step_end(self):
+        self._mark_dirty()
+
 
 class FusedSGD(_FlatOptimizer):
     def __init__(self, model, lr=0.1, momentum=0.9, weight_decay=0.0, nesterov=True):
@@ -54,12 +89,20 @@ class FusedSGD(_FlatOptimizer):
         for off, n, mult in self._segments():
             self.plan.sgd_step(self.p[off:], self.g[off:], self.buf[off:], self.hp, n, nesterov, mult)
 
-    def step(self):
-        self.model.check_flat_generation(self.gen, type(self).__name__)
+    supports_ranges = True
+
+    def _range_launch(self, plan, off, n, mult):
+        plan.sgd_step(self.p[off:], self.g[off:], self.buf[off:], self.hp, n, self.nesterov, mult)
+
+    def _begin(self):
         g = self.param_groups[0]
         self._push_hp([g['lr'], g['weight_decay'], self.momentum, 0.0, 0.0, 0.0, 0.0, 1.0 if self.steps == 0 else 0.0])
-        self.plan.run()
         self.steps += 1
+
+    def step(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
+        self._begin()
+        self.plan.run()
         self._mark_dirty()
 
     def state_dict(self):
@@ -81,14 +124,22 @@ class FusedAdamW(_FlatOptimizer):
         for off, n, mult in self._segments():
             self.plan.adamw_step(self.p[off:], self.g[off:], self.m[off:], self.v[off:], self.hp, n, mult)
 
-    def step(self):
-        self.model.check_flat_generation(self.gen, type(self).__name__)
+    supports_ranges = True
+
+    def _range_launch(self, plan, off, n, mult):
+        plan.adamw_step(self.p[off:], self.g[off:], self.m[off:], self.v[off:], self.hp, n, mult)
+
+    def _begin(self):
         g = self.param_groups[0]
         t = self.steps + 1
         b1, b2 = self.betas
         self._push_hp([g['lr'], g['weight_decay'], b1, b2, self.eps, 1 - b1 ** t, 1 - b2 ** t, 0.0])
-        self.plan.run()
         self.steps = t
+
+    def step(self):
+        self.model.check_flat_generation(self.gen, type(self).__name__)
+        self._begin()
+        self.plan.run()
         self._mark_dirty()
 
     def state_dict(self):

@@ -78,7 +78,7 @@ def test_trainstep_buckets_through_native_comm_equal_plain_step(wire):
             step = A.TrainStep(m, opt, B, lam=-0.8, comm=comm, force_buckets=True, bucket_elems=50_000, nan_guard=True)
             assert len(step.buckets) >= 4
         else:
-            step = A.TrainStep(m, opt, B, lam=-0.8)
+            step = A.TrainStep(m, opt, B, lam=-0.8, overlap_optimizer=False)
         p0 = m.flat_state()['params'].clone()
         loss = step(x, y)
         torch.cuda.synchronize()
@@ -140,3 +140,70 @@ def test_trainstep_buckets_through_torch_nccl_world1():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'nccl_ws1_check.py')], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and 'NCCL_WS1_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize('opt_name', ['adamw', 'sgd'])
+def test_optimizer_update_by_slices_is_bit_identical_to_the_whole_step(opt_name):
+    """step_begin / step_range(lo, hi)* / step_end over an exact partition of the flat buffers == step() + zero_grad(),
+    bit for bit (same kernels on the same values), for two consecutive steps (bias corrections / first-step momentum)."""
+    import imagenet_models_amd as A
+    from imagenet_models_amd.trainer import make_buckets
+    res = {}
+    for tag in ('whole', 'slices'):
+        m, O = _small_model()
+        opt = A.create_optimizer_v2(m, opt=opt_name, lr=1e-2, momentum=0.9, weight_decay=0.05)
+        st = m.flat_state()
+        buckets = make_buckets(st, m.grad_groups(), 50_000)
+        assert len(buckets) >= 4 and sum(b - a for _, a, b in buckets) == st['total']
+        for it in range(2):
+            st['grads'].copy_(torch.randn(st['total'], generator=torch.Generator().manual_seed(it)).cuda())
+            if tag == 'whole':
+                opt.step()
+                opt.zero_grad()
+            else:
+                opt.step_begin()
+                for _, a, b in buckets:
+                    opt.step_range(a, b)
+                opt.step_end()
+            torch.cuda.synchronize()
+            assert float(st['grads'].abs().max()) == 0.0
+        res[tag] = [st['params'].clone()] + ([opt.m.clone(), opt.v.clone()] if opt_name == 'adamw' else [opt.buf.clone()])
+        assert opt.steps == 2
+    for a, b in zip(res['whole'], res['slices']):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('transport', ['none', 'native'])
+def test_optimizer_update_behind_each_bucket_equals_the_update_after_backward(transport):
+    """TrainStep(overlap_optimizer=True): the optimizer update of a bucket (and the zeroing of its gradients) is
+    issued on a side stream as soon as backward has completed the bucket -- alone, and behind the bucket's RCCL all-reduce
+    (world size 1: the identity).  SGD, one step, the per-slice criterion of _assert_same_update (two backward passes never agree
+    bit for bit: atomics); a second step then runs on the zeroed gradients."""
+    import imagenet_models_amd as A
+    B = 8
+    res = {}
+    for tag in ('after', 'behind'):
+        m, O = _small_model()
+        opt = A.create_optimizer_v2(m, opt='sgd', lr=1e-2, momentum=0.9, weight_decay=0.05)
+        comm = A.NativeComm() if (transport == 'native' and tag == 'behind') else None
+        step = A.TrainStep(m, opt, B, lam=-0.8, overlap_optimizer=(tag == 'behind'), comm=comm, force_buckets=comm is not None,
+                           bucket_elems=50_000)
+        assert step.overlap_opt == (tag == 'behind')
+        if tag == 'behind':
+            assert len(step.buckets) >= 4
+        x = O.gen_input(B, seed=2).cuda()
+        y = torch.randint(0, 40, (B,), generator=torch.Generator().manual_seed(2)).cuda()
+        p0 = m.flat_state()['params'].clone()
+        loss = float(step(x, y))
+        torch.cuda.synchronize()
+        p1 = m.flat_state()['params'].clone()
+        assert float(m.flat_state()['grads'].abs().max()) == 0.0           # zeroed (bucket by bucket on the overlapped path)
+        loss2 = float(step(x, y))
+        torch.cuda.synchronize()
+        res[tag] = (loss, p1, loss2)
+        slices = m.flat_state()['slices']
+        if comm is not None:
+            comm.close()
+    assert abs(res['after'][0] - res['behind'][0]) <= 1e-6 * abs(res['after'][0])
+    _assert_same_update(res['after'][1], res['behind'][1], p0, slices, 1e-3)
+    assert abs(res['after'][2] - res['behind'][2]) <= 1e-3 * abs(res['after'][2])
