@@ -292,3 +292,25 @@ def test_asm_load_audit_flags_a_touched_destination(tmp_path):
         f.write_text(text)
         r = subprocess.run([sys.executable, tool, str(f), 'my_kernel'], capture_output=True, text=True)
         assert r.returncode == rc, (text, r.stdout, r.stderr)
+
+
+def test_asm_store_audit_flags_a_write_behind_a_16_byte_buffer_store(tmp_path):
+    """tools/asm_load_audit.py --stores (run by the Makefile on every rebuild of dwconv.hip): a VALU write of a 16-byte buffer
+    store's data registers inside the 2 wait states behind the store is a finding (hipcc does not pad this pair when
+    the store has an SGPR offset); behind `s_nop 1`, or on other registers, it is not."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'asm_load_audit.py')
+    bad = """_Z9my_kernelv:                           ; @_Z9my_kernelv
+\tbuffer_store_dwordx4 v[4:7], v1, s[8:11], s2 offen
+\tv_pk_mul_f32 v[6:7], s[34:35], v[16:17]
+\ts_endpgm
+.Lfunc_end0:
+"""
+    padded = bad.replace('\tv_pk_mul_f32', '\ts_nop 1\n\tv_pk_mul_f32')
+    other = bad.replace('v_pk_mul_f32 v[6:7]', 'v_pk_mul_f32 v[8:9]')
+    for text, rc in ((bad, 1), (padded, 0), (other, 0)):
+        f = tmp_path / 'k.s'
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, '--stores', str(f), 'my_kernel'], capture_output=True, text=True)
+        assert r.returncode == rc, (text, r.stdout, r.stderr)
