@@ -116,14 +116,19 @@ class MAPEngine(GAEngine):
         tk['W'] = self.buf('w.ca.kv_all', (G * E2, L))
         tk['WT'] = self.buf('wT.ca.kv_all', (L, G * E2)) if T else None
         tk['b'] = self.buf('w.ca.bkv_all', (G * E2,), torch.float32)
+        # dim_mismatch (gram_dim != last_dim, map.py:85-90,165-177): the image rows have their own projections k2 | v2 and norm1_2,
+        # the class rows (width gram_dim) q | k1 | v1 and norm1_1, and the attention output REPLACES the class rows
+        mm = self.mm = cfg['gram_dim'] != L
+        self.kv_img, self.n1_img = ('attn.k2', 'norm1_2') if mm else ('attn.k', 'norm1')
         for k in range(G):
             ap = f'head.mmcap.mmcap.{k}.attention.0.'
-            pk, pv, bk, bv = P[ap + 'attn.k.weight'], P[ap + 'attn.v.weight'], P[ap + 'attn.k.bias'], P[ap + 'attn.v.bias']
+            kn, vn = ap + self.kv_img, ap + self.kv_img.replace('.k', '.v')
+            pk, pv, bk, bv = P[kn + '.weight'], P[vn + '.weight'], P[kn + '.bias'], P[vn + '.bias']
             assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4 and bv.data_ptr() == bk.data_ptr() + bk.numel() * 4, \
                 'k / v weights (and biases) must be adjacent in the flat buffer'
             self.prep.weight_prep(pk, 1, E2, L, 1, 1, dt, out=tk['W'][k * E2:], ldo=L, outT=tk['WT'][:, k * E2:] if T else None,
-                                  ldt=G * E2 if T else 0, cs=P[ap + 'norm1.weight'], t_cols=E2, label='prep.' + ap + 'kv')
-            self.prep.bias_fold(pk, bk, None, P[ap + 'norm1.bias'], tk['b'][k * E2:], E2, L)
+                                  ldt=G * E2 if T else 0, cs=P[ap + self.n1_img + '.weight'], t_cols=E2, label='prep.' + ap + 'kv')
+            self.prep.bias_fold(pk, bk, None, P[ap + self.n1_img + '.bias'], tk['b'][k * E2:], E2, L)
         tk['kv'] = self.act('ca.kv_all', (M4, G * E2))
         F.gemm(tk['xn'], tk['W'], tk['kv'], M4, G * E2, L, dt, bias=tk['b'], label='ca.kv_all')
         # ---- ch_reduction (conv1x1, no bias) of all groups: ONE stacked GEMM; group k owns columns [k*bp, (k+1)*bp)
@@ -238,23 +243,37 @@ class MAPEngine(GAEngine):
         self._bn_finalize(gp + 'bp_reduction.1.', h['bn_e'], B, gd * Tn)
         e2 = self.tmp('e2', (B, gd * Tn))
         F.affine_act(h['e'], h['bn_e']['scale'], h['bn_e']['shift'], None, e2, B, gd * Tn, False, dt, label=gp + 'bpr.bn')
-        h['cls0'] = self.buf(ap + 'cls0', (R, L))                  # [B][Tq][L]: gram tokens, then their mean
-        F.map_tokens_fwd(e2, h['cls0'], B, L, Tn, self.sdt, dt, label=gp + 'tokens')
-        # --- CABlock: class rows normalised on their own (norm1's affine part folded into q / k|v)
-        g1, b1 = P[ap + 'norm1.weight'], P[ap + 'norm1.bias']
-        h['cn'] = self.act(ap + 'cn', (R, L))
+        mm = self.mm
+        h['cls0'] = self.buf(ap + 'cls0', (R, gd))                 # [B][Tq][gram_dim]: gram tokens, then their mean
+        F.map_tokens_fwd(e2, h['cls0'], B, gd, Tn, self.sdt, dt, label=gp + 'tokens')
+        # --- CABlock: class rows normalised on their own (the norm's affine part folded into q / k|v)
+        n1c = ap + ('norm1_1' if mm else 'norm1')
+        g1, b1 = P[n1c + '.weight'], P[n1c + '.bias']
+        h['cn'] = self.act(ap + 'cn', (R, gd))
         h['rc'] = self.act(ap + 'rc', (R,), torch.float32)
-        F.layernorm_fwd(h['cls0'], None, None, h['cn'], None, h['rc'], R, L, 1e-6, dt, label=ap + 'ln1c')
+        F.layernorm_fwd(h['cls0'], None, None, h['cn'], None, h['rc'], R, gd, 1e-6, dt, label=ap + 'ln1c')
         tk = self.tok
         E2 = tk['E2']
         h['kvt'] = tk['kv'][:, k * E2:]
         h['kvc'] = self.act(ap + 'kvc', (R, E2))
-        F.gemm(h['cn'], tk['W'][k * E2:], h['kvc'], R, E2, L, dt, bias=tk['b'][k * E2:], label=ap + 'kvc')
-        Wq = self._w_plain(ap + 'attn.q.weight', E, L, 1, 1, cs=g1)
+        if mm:       # class rows: k1 | v1 (adjacent in the flat buffer) with norm1_1 folded
+            pk, bk = P[ap + 'attn.k1.weight'], P[ap + 'attn.k1.bias']
+            assert P[ap + 'attn.v1.weight'].data_ptr() == pk.data_ptr() + pk.numel() * 4
+            assert P[ap + 'attn.v1.bias'].data_ptr() == bk.data_ptr() + bk.numel() * 4
+            h['Wkvc'] = self.buf('w.' + ap + 'kv1', (E2, gd))
+            h['WkvcT'] = self.buf('wT.' + ap + 'kv1', (gd, E2)) if T else None
+            h['bkvc'] = self.buf('w.' + ap + 'bkv1', (E2,), torch.float32)
+            self.prep.weight_prep(pk, 1, E2, gd, 1, 1, dt, out=h['Wkvc'], ldo=gd, outT=h['WkvcT'], ldt=E2 if T else 0, cs=g1,
+                                  t_cols=E2, label='prep.' + ap + 'kv1')
+            self.prep.bias_fold(pk, bk, None, b1, h['bkvc'], E2, gd)
+            F.gemm(h['cn'], h['Wkvc'], h['kvc'], R, E2, gd, dt, bias=h['bkvc'], label=ap + 'kvc')
+        else:
+            F.gemm(h['cn'], tk['W'][k * E2:], h['kvc'], R, E2, L, dt, bias=tk['b'][k * E2:], label=ap + 'kvc')
+        Wq = self._w_plain(ap + 'attn.q.weight', E, gd, 1, 1, cs=g1)
         bq = self.buf('w.' + ap + 'bq', (E,), torch.float32)
-        self.prep.bias_fold(P[ap + 'attn.q.weight'], P[ap + 'attn.q.bias'], None, b1, bq, E, L)
+        self.prep.bias_fold(P[ap + 'attn.q.weight'], P[ap + 'attn.q.bias'], None, b1, bq, E, gd)
         h['q'] = self.act(ap + 'q', (R, E))
-        F.gemm(h['cn'], Wq, h['q'], R, E, L, dt, bias=bq, label=ap + 'q')
+        F.gemm(h['cn'], Wq, h['q'], R, E, gd, dt, bias=bq, label=ap + 'q')
         h['ao'] = self.act(ap + 'ao', (R, E))
         h['P'] = self.act(ap + 'P', (B, Tq, nh, Tq + HW), torch.float32)
         h['scale'] = hd ** -0.5
@@ -267,12 +286,14 @@ class MAPEngine(GAEngine):
                                 label=ap + 'attn')
         Wpr = self._w_plain(ap + 'attn.proj.weight', L, E, 1, 1)
         h['cls1'] = self.buf(ap + 'cls1', (R, L))
+        res0 = None if mm else h['cls0']         # (dim_mismatch: x_cls = attn(...), no residual, map.py:177)
         if 'proj' in dm:
             pr = self.tmp('proj', (R, L))
             F.gemm(h['ao'], Wpr, pr, R, L, E, dt, bias=P[ap + 'attn.proj.bias'], label=ap + 'proj')
-            F.mask_mul(pr, dm['proj'], h['cls0'], h['cls1'], R * L, dt, label=ap + 'proj.drop')
+            F.mask_mul(pr, dm['proj'], res0, h['cls1'], R * L, dt, label=ap + 'proj.drop')
         else:
-            F.gemm(h['ao'], Wpr, h['cls1'], R, L, E, dt, bias=P[ap + 'attn.proj.bias'], R=h['cls0'], ldr=L, label=ap + 'proj')
+            F.gemm(h['ao'], Wpr, h['cls1'], R, L, E, dt, bias=P[ap + 'attn.proj.bias'], R=res0, ldr=L if res0 is not None else 0,
+                   label=ap + 'proj')
         h['t'] = self.act(ap + 't', (R, L))
         h['m2'] = self.act(ap + 'm2', (R,), torch.float32)
         h['r2'] = self.act(ap + 'r2', (R,), torch.float32)
@@ -362,22 +383,36 @@ class MAPEngine(GAEngine):
         else:
             Bk.class_attn_mt_bwd(dao, h['q'], h['kvc'], h['kvt'], tk['ld'], h['P'], dm.get('attn'), dq, dkvc, tk['dkv'][:, k * E2:], tk['ld'],
                                  B, Tq, Tq + HW, nh, hd, h['scale'], dt, label=ap + 'attnb')
-        g1, b1 = P[ap + 'norm1.weight'], P[ap + 'norm1.bias']
-        # class rows' share of the effective k|v weight gradient (the image rows' share: one wgrad after the loop)
-        Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], R, E2, L, dt, dbias=tk['gb'][k * E2:], label=ap + 'kvc.wg')
-        Gq, gbq = self.gbuf((E, L)), self.gbuf((E,))
-        Bk.wgrad(dq, h['cn'], Gq, R, E, L, dt, dbias=gbq, label=ap + 'q.wg')
-        Bk.weight_unfold(Gq, L, E, L, gb=gbq, W=P[ap + 'attn.q.weight'], b=P[ap + 'attn.q.bias'], cs=g1, v=b1,
-                         dW=self.grad(ap + 'attn.q.weight'), db=self.grad(ap + 'attn.q.bias'), d_cs=self.grad(ap + 'norm1.weight'),
-                         d_v=self.grad(ap + 'norm1.bias'), label=ap + 'q.unf')
-        dcn = self.tmp('dcn', (R, L))
-        Bk.gemm(dkvc, tk['WT'][:, k * E2:], dcn, R, L, E2, dt, ldb=tk['ld'], label=ap + 'kvc.dg')
-        Bk.gemm(dq, W[ap + 'attn.q.weight.T'], dcn, R, L, E, dt, ldb=pad8(E), R=dcn, ldr=L, label=ap + 'q.dg')
-        # dcls0 = dcls1 + LN'(dcn)
-        Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, dcls1, dcls1, None, None, R, L, True, dt, label=ap + 'ln1cb')
+        mm = self.mm
+        n1c = ap + ('norm1_1' if mm else 'norm1')
+        g1, b1 = P[n1c + '.weight'], P[n1c + '.bias']
+        dcn = self.tmp('dcn', (R, gd))
+        if mm:       # class rows own k1 | v1: their weight gradient with the norm1_1 fold undone (both unfolds add into d norm1_1: atomics)
+            Gkv, gbkv = self.gbuf((E2, gd)), self.gbuf((E2,))
+            Bk.wgrad(dkvc, h['cn'], Gkv, R, E2, gd, dt, dbias=gbkv, label=ap + 'kvc.wg')
+            Bk.weight_unfold(Gkv, gd, E2, gd, gb=gbkv, W=P[ap + 'attn.k1.weight'], b=P[ap + 'attn.k1.bias'], cs=g1, v=b1,
+                             dW=self.grad(ap + 'attn.k1.weight'), db=self.grad(ap + 'attn.k1.bias'), d_cs=self.grad(n1c + '.weight'),
+                             d_v=self.grad(n1c + '.bias'), label=ap + 'kv1.unf')
+            Bk.gemm(dkvc, h['WkvcT'], dcn, R, gd, E2, dt, ldb=E2, label=ap + 'kvc.dg')
+        else:
+            # class rows' share of the effective k|v weight gradient (the image rows' share: one wgrad after the loop)
+            Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], R, E2, L, dt, dbias=tk['gb'][k * E2:], label=ap + 'kvc.wg')
+            Bk.gemm(dkvc, tk['WT'][:, k * E2:], dcn, R, L, E2, dt, ldb=tk['ld'], label=ap + 'kvc.dg')
+        Gq, gbq = self.gbuf((E, gd)), self.gbuf((E,))
+        Bk.wgrad(dq, h['cn'], Gq, R, E, gd, dt, dbias=gbq, label=ap + 'q.wg')
+        Bk.weight_unfold(Gq, gd, E, gd, gb=gbq, W=P[ap + 'attn.q.weight'], b=P[ap + 'attn.q.bias'], cs=g1, v=b1,
+                         dW=self.grad(ap + 'attn.q.weight'), db=self.grad(ap + 'attn.q.bias'), d_cs=self.grad(n1c + '.weight'),
+                         d_v=self.grad(n1c + '.bias'), label=ap + 'q.unf')
+        Bk.gemm(dq, W[ap + 'attn.q.weight.T'], dcn, R, gd, E, dt, ldb=pad8(E), R=dcn, ldr=gd, label=ap + 'q.dg')
+        if mm:       # dcls0 = LN'(dcn): the class rows entered the block through norm1_1 only
+            dcls0 = self.tmp('dcls0', (R, gd))
+            Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, None, dcls0, None, None, R, gd, True, dt, label=ap + 'ln1cb')
+        else:        # dcls0 = dcls1 + LN'(dcn)
+            dcls0 = dcls1
+            Bk.layernorm_bwd(dcn, h['cn'], None, h['rc'], None, dcls1, dcls1, None, None, R, L, True, dt, label=ap + 'ln1cb')
         # --- tokens -> bp_reduction BN + grouped conv
         de2 = self.tmp('de2', (B, gd * Tn))
-        Bk.map_tokens_bwd(dcls1, de2, B, L, Tn, self.sdt, dt, label=gp + 'tokensb')
+        Bk.map_tokens_bwd(dcls0, de2, B, gd, Tn, self.sdt, dt, label=gp + 'tokensb')
         de = self.tmp('de', (B, gd * Tn))
         self._bn_bwd(gp + 'bp_reduction.1.', h['bn_e'], de2, None, h['e'], de, B, gd * Tn)
         Kg, Kp, cg = h['Kg'], h['Kp'], h['cg']
@@ -461,9 +496,10 @@ class MAPEngine(GAEngine):
             Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], L, dt, dbias=tk['gb'], label='ca.kv_all.wg')
         for k in range(G):
             ap = f'head.mmcap.mmcap.{k}.attention.0.'
-            Bk.weight_unfold(tk['G'][k * E2:], L, E2, L, gb=tk['gb'][k * E2:], W=P[ap + 'attn.k.weight'], b=P[ap + 'attn.k.bias'],
-                             cs=P[ap + 'norm1.weight'], v=P[ap + 'norm1.bias'], dW=self.grad(ap + 'attn.k.weight'),
-                             db=self.grad(ap + 'attn.k.bias'), d_cs=self.grad(ap + 'norm1.weight'), d_v=self.grad(ap + 'norm1.bias'),
+            kn, nn_ = ap + self.kv_img, ap + self.n1_img
+            Bk.weight_unfold(tk['G'][k * E2:], L, E2, L, gb=tk['gb'][k * E2:], W=P[kn + '.weight'], b=P[kn + '.bias'],
+                             cs=P[nn_ + '.weight'], v=P[nn_ + '.bias'], dW=self.grad(kn + '.weight'),
+                             db=self.grad(kn + '.bias'), d_cs=self.grad(nn_ + '.weight'), d_v=self.grad(nn_ + '.bias'),
                              label=ap + 'kv.unf')
         dxt = self.tmp('dxn_tok', (M4, L))
         Bk.gemm(tk['dkv'], tk['WT'], dxt, M4, L, tk['ld'], dt, label='ca.kv_all.dg')

@@ -38,17 +38,26 @@ class _Block(Holder):
 
 
 class _CABlock(Holder):
-    """map.CABlock with ClassAttention / GroupConvMlp (map.py:147-169, 69-98, 43-54): in_dim == dim; `interactive` adds the two
-    head-mixing linears w1 / w2 (:96-98)"""
+    """map.CABlock with ClassAttention / GroupConvMlp (map.py:147-169, 69-98, 43-54); `interactive` adds the two head-mixing
+    linears w1 / w2 (:96-98); in_dim != dim (`dim_mismatch`, :85-90, 165-167): class rows of width in_dim with their own q / k1 / v1
+    and norm1_1, image rows k2 / v2 and norm1_2"""
 
-    def __init__(self, dim, ca_dim, mlp_ratio, mlp_groups, num_heads=0, interactive=False):
+    def __init__(self, dim, ca_dim, mlp_ratio, mlp_groups, num_heads=0, interactive=False, in_dim=None):
         super().__init__()
+        in_dim = in_dim or dim
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = Holder()
         self.attn.proj = nn.Linear(ca_dim, dim)
-        self.attn.q = nn.Linear(dim, ca_dim, bias=True)
-        self.attn.k = nn.Linear(dim, ca_dim, bias=True)
-        self.attn.v = nn.Linear(dim, ca_dim, bias=True)
+        if in_dim != dim:
+            self.attn.q = nn.Linear(in_dim, ca_dim, bias=True)
+            self.attn.k1 = nn.Linear(in_dim, ca_dim, bias=True)
+            self.attn.v1 = nn.Linear(in_dim, ca_dim, bias=True)
+            self.attn.k2 = nn.Linear(dim, ca_dim, bias=True)
+            self.attn.v2 = nn.Linear(dim, ca_dim, bias=True)
+        else:
+            self.attn.q = nn.Linear(dim, ca_dim, bias=True)
+            self.attn.k = nn.Linear(dim, ca_dim, bias=True)
+            self.attn.v = nn.Linear(dim, ca_dim, bias=True)
         if interactive:
             self.attn.w1 = nn.Linear(num_heads, num_heads)
             self.attn.w2 = nn.Linear(num_heads, num_heads)
@@ -56,7 +65,11 @@ class _CABlock(Holder):
         self.mlp = Holder()
         self.mlp.fc1 = nn.Conv2d(dim, hid, kernel_size=1, groups=mlp_groups)
         self.mlp.fc2 = nn.Conv2d(hid, dim, kernel_size=1, groups=mlp_groups)
-        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        if in_dim != dim:
+            self.norm1_1 = nn.LayerNorm(in_dim, eps=1e-6)
+            self.norm1_2 = nn.LayerNorm(dim, eps=1e-6)
+        else:
+            self.norm1 = nn.LayerNorm(dim, eps=1e-6)
 
 
 class _GramToken(Holder):
@@ -77,7 +90,7 @@ class _CAP(Holder):
     def __init__(self, cfg):
         super().__init__()
         self.attention = nn.Sequential(_CABlock(cfg['last_dim'], cfg['ca_dim'], cfg['mlp_ratio'], cfg['mlp_groups'], cfg['num_heads'],
-                                                cfg.get('interactive', False)))
+                                                cfg.get('interactive', False), in_dim=cfg['gram_dim']))
         self.gram_token_extraction = _GramToken(cfg['last_dim'], cfg['gram_group'], cfg['n_tokens'], cfg['bp_groups'],
                                                 cfg['bp_dim'], cfg['gram_dim'])
 
@@ -137,8 +150,9 @@ class MAP_ConvNeXt(FlatModel):
         """head_drop / head_attn_drop: the dropout probabilities CABlock hard-codes (map.py:149: drop=0.05 -> proj / MLP
         dropout; MAPHead attn_drop=0.05, :464) -- exposed so that parity tests can switch the (irreproducible) masks off"""
         super().__init__()
-        # split_norm (map_convnext.py:97-100) selects SplitNormHead; head_fn = 'linear' (nn.Linear heads), self_distill_token = False and
-        # interactive = True are the MAPHead options the other reference backbones use (SURVEY Appendix C): same head code
+        # split_norm (map_convnext.py:97-100) selects SplitNormHead; head_fn = 'linear' (nn.Linear heads), self_distill_token = False,
+        # interactive = True and gram_dim != last_dim are the MAPHead options the other reference backbones use (SURVEY Appendix C):
+        # same head code
         assert global_pool == 'mmcap' and gram and in_chans == 3, 'only the MAP head (global_pool="mmcap") with Gram tokens'
         assert gram_layer is None and bp_groups == 1 and layer_scale_init_value > 0
         depths, dims = tuple(depths), tuple(dims)
@@ -151,7 +165,7 @@ class MAP_ConvNeXt(FlatModel):
                         self_distill_token=bool(self_distill_token), head_fn=head_fn or ('split' if split_norm else 'norm'),
                         interactive=bool(interactive))
         assert self.cfg['head_fn'] in ('norm', 'split', 'linear')
-        assert self.cfg['gram_dim'] == last_dim, 'dim_mismatch CABlocks are not on the map_convnext path'
+        assert self.cfg['gram_dim'] % 8 == 0      # gram_dim != last_dim: the dim_mismatch CABlock (map.py:85-90,165-177)
         self.downsample_layers = nn.ModuleList()
         self.downsample_layers.append(nn.Sequential(nn.Conv2d(in_chans, dims[0], kernel_size=4, stride=4), _LN(dims[0])))
         for i in range(3):

@@ -5,12 +5,15 @@
   linear  head_fn = nn.Linear, no self-distillation token, ONE group  (the map_mobilenet_v1 head options, map_mobilenet.py:67-83)
   inter   interactive = True                (ClassAttention's head-mixing linears w1 / w2, map.py:96-98,130-136; map_resnet50 /
                                              map_faster_vit_3_224 use it)
+  mismatch gram_dim != last_dim             (CABlock / ClassAttention dim_mismatch, map.py:85-90,101-116,165-177: class rows of
+                                             width gram_dim, own q / k1 / v1 and norm1_1, image rows k2 / v2 and norm1_2, the
+                                             attention output replaces the class rows)
 
 split / nosdt are constructor arguments of the reference's ConvNeXt.  `linear` and `inter` are MAPHead arguments the reference's
 ConvNeXt does not expose: the fixture model is the reference ConvNeXt with its `.head` replaced by a reference MAPHead built
 with the same arguments plus the variant (so every class in the fixture is the reference's own).  Dropouts set to p = 0.
 
-Run:  python oracle/gen_golden_map_variants.py        -> tests/golden/mapvar_{split,nosdt,linear,inter}_{eval,train_b4}.npz"""
+Run:  python oracle/gen_golden_map_variants.py        -> tests/golden/mapvar_{split,nosdt,linear,inter,mismatch}_{eval,train_b4}.npz"""
 import json
 import os
 import sys
@@ -38,6 +41,7 @@ VARIANTS = {
     'nosdt': dict(self_distill_token=False),
     'linear': dict(head_fn='linear', self_distill_token=False, n_groups=1),
     'inter': dict(interactive=True),
+    'mismatch': dict(gram_dim=96),     # (32 puts one ReLU unit of the head MLP on its kink: an ill-conditioned test point)
 }
 
 
@@ -46,13 +50,14 @@ def build_ref(cfg):
                      global_pool='mmcap', last_dim=cfg['last_dim'], n_groups=cfg['n_groups'], n_tokens=cfg['n_tokens'],
                      gram_group=cfg['gram_group'], bp_dim=cfg['bp_dim'], bp_groups=cfg['bp_groups'], ca_dim=cfg['ca_dim'],
                      num_heads=cfg['num_heads'], split_norm=cfg['head_fn'] == 'split', self_distill_token=cfg['self_distill_token'])
-    if cfg['head_fn'] == 'linear' or cfg['interactive']:
+    if cfg['head_fn'] == 'linear' or cfg['interactive'] or cfg['gram_dim'] != cfg['last_dim']:
         dims = list(cfg['dims'])
         head_fn = {'norm': refmap.NormHead, 'split': refmap.SplitNormHead, 'linear': nn.Linear}[cfg['head_fn']]
         m.head = refmap.MAPHead(multi_scale_level=3, channels=[dims[0]] + dims, last_dim=cfg['last_dim'], n_tokens=cfg['n_tokens'],
                                 n_groups=cfg['n_groups'], self_distill_token=cfg['self_distill_token'], mlp_ratio=4, mlp_groups=2,
                                 head_fn=head_fn, fc_drop=0, num_classes=cfg['num_classes'], non_linearity=nn.GELU, gram=True,
-                                bp_dim=cfg['bp_dim'], bp_groups=cfg['bp_groups'], gram_group=cfg['gram_group'], gram_dim=None,
+                                bp_dim=cfg['bp_dim'], bp_groups=cfg['bp_groups'], gram_group=cfg['gram_group'],
+                                gram_dim=cfg['gram_dim'] if cfg['gram_dim'] != cfg['last_dim'] else None,
                                 concat_blk=None, gram_blk=nn.Identity, ca_dim=cfg['ca_dim'], num_heads=cfg['num_heads'],
                                 interactive=cfg['interactive'])
     for mod in m.modules():
@@ -132,5 +137,8 @@ def run(tag, cfg):
 
 if __name__ == '__main__':
     torch.manual_seed(0)
+    only = sys.argv[1:]
     for tag, over in VARIANTS.items():
+        if only and tag not in only:
+            continue
         run(tag, O.make_cfg(**dict(BASE, **over)))

@@ -76,7 +76,7 @@ def head_shapes(pre, cfg, channels, o):
     """MAPHead (map.py:462-492): mmcap (MAP: mmcap list of CAP, then multi_scale), heads, self_dt_heads"""
     L, G, T = cfg['last_dim'], cfg['n_groups'], cfg['n_tokens']
     gd, bp, E, nh = cfg['gram_dim'], cfg['bp_dim'], cfg['ca_dim'], cfg['num_heads']
-    assert gd == L, 'dim_mismatch CABlocks (gram_dim != last_dim) are not on the map_convnext path'
+    mm = gd != L          # CABlock / ClassAttention dim_mismatch (map.py:77,153): separate projections and norms for class and image rows
     mg = cfg['mlp_groups']
     hid = int(L * cfg['mlp_ratio'])
     for i in range(G):
@@ -86,8 +86,8 @@ def head_shapes(pre, cfg, channels, o):
         _ln_shapes(ap + 'norm2.', L, o)
         o[ap + 'attn.proj.weight'] = (L, E)
         o[ap + 'attn.proj.bias'] = (L,)
-        for n in ('q', 'k', 'v'):
-            o[ap + f'attn.{n}.weight'] = (E, L)
+        for n, cin in ((('q', gd), ('k1', gd), ('v1', gd), ('k2', L), ('v2', L)) if mm else (('q', L), ('k', L), ('v', L))):
+            o[ap + f'attn.{n}.weight'] = (E, cin)
             o[ap + f'attn.{n}.bias'] = (E,)
         if cfg['interactive']:
             for n in ('w1', 'w2'):
@@ -97,7 +97,11 @@ def head_shapes(pre, cfg, channels, o):
         o[ap + 'mlp.fc1.bias'] = (hid,)
         o[ap + 'mlp.fc2.weight'] = (L, hid // mg, 1, 1)
         o[ap + 'mlp.fc2.bias'] = (L,)
-        _ln_shapes(ap + 'norm1.', L, o)
+        if mm:
+            _ln_shapes(ap + 'norm1_1.', gd, o)
+            _ln_shapes(ap + 'norm1_2.', L, o)
+        else:
+            _ln_shapes(ap + 'norm1.', L, o)
         gp = cp + 'gram_token_extraction.'
         o[gp + 'bp_index'] = (bp * (bp + 1) // 2,)
         o[gp + 'ch_reduction.0.weight'] = (bp, L // cfg['bp_groups'], 1, 1)
@@ -277,15 +281,28 @@ def _drop(x, mask):
 
 
 def class_attention(sd, pre, x, n_tokens, cfg, attn_mask=None, proj_mask=None):
-    """ClassAttention.forward, in_dim == dim branch (map.py:118-144)"""
+    """ClassAttention.forward (map.py:100-144): x = the normalised cat(cls, img) rows (in_dim == dim), or the pair
+    (normalised cls rows, normalised img rows) of the dim_mismatch branch (:101-116: k = cat(k1(cls), k2(img)), v likewise)"""
     nh, E = cfg['num_heads'], cfg['ca_dim']
-    cls, img = x[:, :n_tokens], x
-    b, n, _ = img.shape
     hd = E // nh
-    q = F.linear(cls, sd[pre + 'q.weight'], sd.get(pre + 'q.bias')).reshape(b, n_tokens, nh, hd).permute(0, 2, 1, 3)
-    k = F.linear(img, sd[pre + 'k.weight'], sd.get(pre + 'k.bias')).reshape(b, n, nh, hd).permute(0, 2, 1, 3)
-    q = q * hd ** -0.5
-    v = F.linear(img, sd[pre + 'v.weight'], sd.get(pre + 'v.bias')).reshape(b, n, nh, hd).permute(0, 2, 1, 3)
+    if isinstance(x, tuple):
+        cls, img = x
+        b, n1, _ = cls.shape
+        n2 = img.shape[1]
+        n = n1 + n2
+        q = F.linear(cls, sd[pre + 'q.weight'], sd.get(pre + 'q.bias')).reshape(b, n_tokens, nh, hd).permute(0, 2, 1, 3)
+        q = q * hd ** -0.5
+        k = torch.cat([F.linear(cls, sd[pre + 'k1.weight'], sd.get(pre + 'k1.bias')).reshape(b, n1, nh, hd).permute(0, 2, 1, 3),
+                       F.linear(img, sd[pre + 'k2.weight'], sd.get(pre + 'k2.bias')).reshape(b, n2, nh, hd).permute(0, 2, 1, 3)], dim=-2)
+        v = torch.cat([F.linear(cls, sd[pre + 'v1.weight'], sd.get(pre + 'v1.bias')).reshape(b, n1, nh, hd).permute(0, 2, 1, 3),
+                       F.linear(img, sd[pre + 'v2.weight'], sd.get(pre + 'v2.bias')).reshape(b, n2, nh, hd).permute(0, 2, 1, 3)], dim=-2)
+    else:
+        cls, img = x[:, :n_tokens], x
+        b, n, _ = img.shape
+        q = F.linear(cls, sd[pre + 'q.weight'], sd.get(pre + 'q.bias')).reshape(b, n_tokens, nh, hd).permute(0, 2, 1, 3)
+        k = F.linear(img, sd[pre + 'k.weight'], sd.get(pre + 'k.bias')).reshape(b, n, nh, hd).permute(0, 2, 1, 3)
+        q = q * hd ** -0.5
+        v = F.linear(img, sd[pre + 'v.weight'], sd.get(pre + 'v.bias')).reshape(b, n, nh, hd).permute(0, 2, 1, 3)
     attn = q @ k.transpose(-2, -1).contiguous()
     if cfg['interactive']:
         attn = attn + F.linear(attn.permute(0, 2, 3, 1), sd[pre + 'w1.weight'], sd[pre + 'w1.bias']).permute(0, 3, 1, 2)
@@ -318,9 +335,14 @@ def cap(sd, pre, x, cfg, training, new_stats, masks=None):
         x_cls = torch.cat([x_cls, x_cls.mean(dim=1, keepdim=True)], dim=1)
     nt = x_cls.shape[1]
     ap = pre + 'attention.0.'
-    u = torch.cat((x_cls, img), dim=1)
-    un = F.layer_norm(u, (c,), sd[ap + 'norm1.weight'], sd[ap + 'norm1.bias'], 1e-6)
-    x_cls = x_cls + class_attention(sd, ap + 'attn.', un, nt, cfg, masks.get('attn'), masks.get('proj'))
+    if cfg['gram_dim'] != c:        # dim_mismatch (map.py:174-177): own norms, and the attention output REPLACES the class rows
+        cn = F.layer_norm(x_cls, (cfg['gram_dim'],), sd[ap + 'norm1_1.weight'], sd[ap + 'norm1_1.bias'], 1e-6)
+        im = F.layer_norm(img, (c,), sd[ap + 'norm1_2.weight'], sd[ap + 'norm1_2.bias'], 1e-6)
+        x_cls = class_attention(sd, ap + 'attn.', (cn, im), nt, cfg, masks.get('attn'), masks.get('proj'))
+    else:
+        u = torch.cat((x_cls, img), dim=1)
+        un = F.layer_norm(u, (c,), sd[ap + 'norm1.weight'], sd[ap + 'norm1.bias'], 1e-6)
+        x_cls = x_cls + class_attention(sd, ap + 'attn.', un, nt, cfg, masks.get('attn'), masks.get('proj'))
     t = F.layer_norm(x_cls, (c,), sd[ap + 'norm2.weight'], sd[ap + 'norm2.bias'], 1e-6)
     x_cls = x_cls + group_conv_mlp(sd, ap + 'mlp.', t, cfg['mlp_groups'], masks.get('mlp'))
     return x_cls.reshape(b, -1)

@@ -4,11 +4,13 @@
   nosdt   self_distill_token = False: no mean token, no self_dt_heads, plain logits in train mode (map.py:273-275,490-491,536-537)
   linear  head_fn = nn.Linear + no self-distillation token + ONE group (the head options of map_mobilenet_v1)
   inter   ClassAttention(interactive=True): head-mixing linears w1 / w2 around the softmax (map.py:96-98,130-136)
+  mismatch gram_dim != last_dim: the dim_mismatch CABlock / ClassAttention (map.py:85-90,101-116,165-177): class rows of width
+          gram_dim with their own q / k1 / v1 and norm1_1, image rows k2 / v2 and norm1_2, attention output replaces the class rows
 
 against tests/golden/mapvar_*.npz, written by oracle/gen_golden_map_variants.py from the REAL reference classes (logits, loss,
 top-5, per-parameter gradient norms), and against the oracle restatement for every gradient tensor.
 fp32 mode: logits / loss 1e-3, gradients 2e-2, top-5 bit-exact; bf16 mode: logits 6e-2, loss 2e-2, whole-tensor gradient gates.
-(`dim_mismatch`, gram_dim != last_dim, is not reachable from any registered model of the reference and stays unbuilt.)"""
+"""
 import json
 import os
 
@@ -20,7 +22,7 @@ from _gradcheck import assert_grads_close, BF16_REL, BF16_COS
 from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
-TAGS = ['split', 'nosdt', 'linear', 'inter']
+TAGS = ['split', 'nosdt', 'linear', 'inter', 'mismatch']
 
 
 def _cfg(tag, kind):
@@ -36,7 +38,8 @@ def _build(cfg, mode, O):
     m = A.MAP_ConvNeXt(num_classes=cfg['num_classes'], depths=cfg['depths'], dims=cfg['dims'], last_dim=cfg['last_dim'],
                        n_groups=cfg['n_groups'], n_tokens=cfg['n_tokens'], gram_group=cfg['gram_group'], bp_dim=cfg['bp_dim'],
                        ca_dim=cfg['ca_dim'], num_heads=cfg['num_heads'], head_drop=0.0, head_attn_drop=0.0, math_mode=mode,
-                       head_fn=cfg['head_fn'], self_distill_token=cfg['self_distill_token'], interactive=cfg['interactive'])
+                       head_fn=cfg['head_fn'], self_distill_token=cfg['self_distill_token'], interactive=cfg['interactive'],
+                       gram_dim=cfg['gram_dim'])
     sd = O.fill_state(cfg)
     assert list(m.state_dict().keys()) == list(sd.keys())
     m.load_state_dict(sd)
