@@ -80,6 +80,23 @@ def main():
     gathered = [torch.zeros_like(chk) for _ in range(world)]
     dist.all_gather(gathered, chk)
     assert all(torch.equal(gathered[0], t) for t in gathered), gathered
+    # (4) the same step with the optimizer update (and the gradient zeroing) issued behind each bucket's all-reduce
+    # (TrainStep(overlap_optimizer=True)): every rank again ends with the same parameters, the gradients are zero, and the update is
+    # the one of (3) up to the atomics noise of a second backward pass (AdamW: compared where the gradient is not noise)
+    m3, o3 = make()
+    step3 = A.TrainStep(m3, o3, B, lam=-0.8, overlap_optimizer=True)
+    assert step3.overlap_opt and step3.world == world
+    step3(x, y)
+    torch.cuda.synchronize()
+    p3 = m3.flat_state()['params']
+    assert float(m3.flat_state()['grads'].abs().max()) == 0.0
+    chk3 = torch.stack([p3.double().sum(), p3.double().abs().sum()]).cpu()
+    gathered = [torch.zeros_like(chk3) for _ in range(world)]
+    dist.all_gather(gathered, chk3)
+    assert all(torch.equal(gathered[0], t) for t in gathered), gathered
+    big = g_ref.abs() > 1e-3 * gmax                      # elements whose gradient is well above the noise: same AdamW step
+    dpar = float((p3 - p_ddp)[big].abs().max())
+    assert dpar <= 2e-3 * 1e-2 + 1e-6, dpar              # lr 1e-2: the two updates agree to a fraction of one step
     if rank == 0:
         print(f'DDP_CHECK_OK max rel grad diff {err:.2e} buckets {[(m, b - a) for m, a, b in step.buckets]}', flush=True)
     dist.destroy_process_group()
