@@ -58,49 +58,63 @@ class CSWinEngine(GAEngine):
     # CSWinBlock
     # ------------------------------------------------------------------------------------------
     def _cs_block_fwd(self, pre, x, mod):
-        """x [B*reso*reso, C] -> block output (same shape); mod = the block's parameter holder (geometry)"""
+        """x [B*reso*reso, C] -> block output (same shape); mod = the block's parameter holder (geometry).  Inside a forward chain
+        (GAEngine._chains: the trunk recorded once per batch part, each part on its own lane) the launches cover the chain's rows of
+        the same full-batch buffers; weight preparation and the saved state are recorded by the first pass only"""
         F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
         C, reso, heads, mg = mod.dim, mod.reso, mod.num_heads, mod.mlp_groups
         HW = reso * reso
         M = B * HW
         assert C % 8 == 0
+        (lane, r0, r1, b0, b1), = self._fsplits(HW)
+        first = pre not in self.blocks
+        assert mg == 1 or (r0 == 0 and r1 == M), 'grouped-MLP blocks are recorded for the whole batch'
+        if getattr(self, '_chain', None) is not None:      # (outside a chain the caller's lane stands: the heads' gram_layer blocks)
+            F.lane = lane
         dp1, dp2 = self.dp_scale.get(pre + '#1'), self.dp_scale.get(pre + '#2')
-        st = self.blocks[pre] = dict(x=x, mod=mod, M=M)
+        dp1c = dp1[b0:b1] if dp1 is not None else None
+        dp2c = dp2[b0:b1] if dp2 is not None else None
+        st = self.blocks.setdefault(pre, dict(x=x, mod=mod, M=M))
         # --- attention branch
         st['xn1'] = self.blk_act(pre + 'xn1', (M, C))
         st['r1'] = self.blk_act(pre + 'r1', (M,), torch.float32)
-        F.layernorm_fwd(x, None, None, st['xn1'], None, st['r1'], M, C, 1e-5, dt, label=pre + 'ln1')
+        F.layernorm_fwd(x[r0:r1], None, None, st['xn1'][r0:r1], None, st['r1'][r0:r1], r1 - r0, C, 1e-5, dt, label=pre + 'ln1')
         Wqkv = self._w_plain(pre + 'qkv.weight', 3 * C, C, 1, 1, cs=P[pre + 'norm1.weight'])
         bq = self.buf('w.' + pre + 'bqkv', (3 * C,), torch.float32)
-        self.prep.bias_fold(P[pre + 'qkv.weight'], P.get(pre + 'qkv.bias'), None, P[pre + 'norm1.bias'], bq, 3 * C, C)
+        if first:
+            self.prep.bias_fold(P[pre + 'qkv.weight'], P.get(pre + 'qkv.bias'), None, P[pre + 'norm1.bias'], bq, 3 * C, C)
         st['qkv'] = self.blk_act(pre + 'qkv', (M, 3 * C))
-        F.gemm(st['xn1'], Wqkv, st['qkv'], M, 3 * C, C, dt, bias=bq, label=pre + 'qkv')
+        F.gemm(st['xn1'][r0:r1], Wqkv, st['qkv'][r0:r1], r1 - r0, 3 * C, C, dt, bias=bq, label=pre + 'qkv')
         st['att'] = self.blk_act(pre + 'att', (M, C))
         lepe = [(P[pre + f'attns.{i}.get_v.weight'], P[pre + f'attns.{i}.get_v.bias']) for i in range(mod.branch_num)]
-        st['desc'] = F.cswin_desc(st['qkv'], st['att'], B, reso, C, heads, mod.stripes(), lepe, (C // heads) ** -0.5, dt)
-        self._lepe_ws_elems = max(getattr(self, '_lepe_ws_elems', 0), ops.cswin_attn_bwd_workspace(st['desc']) // 4)
-        F.cswin_attn_fwd(st['desc'], label=pre + 'attn')
+        if first:      # the backward's descriptor: the whole batch
+            st['desc'] = F.cswin_desc(st['qkv'], st['att'], B, reso, C, heads, mod.stripes(), lepe, (C // heads) ** -0.5, dt)
+            self._lepe_ws_elems = max(getattr(self, '_lepe_ws_elems', 0), ops.cswin_attn_bwd_workspace(st['desc']) // 4)
+        dfw = st['desc'] if (r0 == 0 and r1 == M) else F.cswin_desc(st['qkv'][r0:r1], st['att'][r0:r1], b1 - b0, reso, C, heads,
+                                                                       mod.stripes(), lepe, (C // heads) ** -0.5, dt)
+        F.cswin_attn_fwd(dfw, label=pre + 'attn')
         Wp = self._w_plain(pre + 'proj.weight', C, C, 1, 1)
         # x1 is re-read by the affine LayerNorm backward of the grouped-MLP form only
         x1 = st['x1'] = self.buf(pre + 'x1', (M, C)) if (mg > 1 and T) else self.tmp('x1', (M, C))
-        F.gemm(st['att'], Wp, x1, M, C, C, dt, bias=P[pre + 'proj.bias'], rowscale=dp1, rows_per_scale=HW, R=x, ldr=C,
-               label=pre + 'proj')
+        F.gemm(st['att'][r0:r1], Wp, x1[r0:r1], r1 - r0, C, C, dt, bias=P[pre + 'proj.bias'], rowscale=dp1c, rows_per_scale=HW,
+               R=x[r0:r1], ldr=C, label=pre + 'proj')
         # --- MLP branch
         y = st['y'] = self.buf(pre + 'y', (M, C))
         if mg == 1:
             st['xn2'] = self.blk_act(pre + 'xn2', (M, C))
             st['r2'] = self.blk_act(pre + 'r2', (M,), torch.float32)
-            F.layernorm_fwd(x1, None, None, st['xn2'], None, st['r2'], M, C, 1e-5, dt, label=pre + 'ln2')
+            F.layernorm_fwd(x1[r0:r1], None, None, st['xn2'][r0:r1], None, st['r2'][r0:r1], r1 - r0, C, 1e-5, dt, label=pre + 'ln2')
             W1 = self._w_plain(pre + 'mlp.fc1.weight', 4 * C, C, 1, 1, cs=P[pre + 'norm2.weight'])
             b1e = self.buf('w.' + pre + 'b1e', (4 * C,), torch.float32)
-            self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm2.bias'], b1e, 4 * C, C)
+            if first:
+                self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm2.bias'], b1e, 4 * C, C)
             st['a'] = self.blk_act(pre + 'a', (M, 4 * C))
             st['g'] = self.buf(pre + 'g', (M, 4 * C)) if T else None
-            F.gemm(st['xn2'], W1, st['a'], M, 4 * C, C, dt, bias=b1e, act=ACT_GELU, C2=st['g'], c2_mode=2 if T else 0,
-                   label=pre + 'fc1')
+            F.gemm(st['xn2'][r0:r1], W1, st['a'][r0:r1], r1 - r0, 4 * C, C, dt, bias=b1e, act=ACT_GELU,
+                   C2=st['g'][r0:r1] if T else None, c2_mode=2 if T else 0, label=pre + 'fc1')
             W2 = self._w_plain(pre + 'mlp.fc2.weight', C, 4 * C, 1, 1)
-            F.gemm(st['a'], W2, y, M, C, 4 * C, dt, bias=P[pre + 'mlp.fc2.bias'], rowscale=dp2, rows_per_scale=HW, R=x1, ldr=C,
-                   label=pre + 'fc2')
+            F.gemm(st['a'][r0:r1], W2, y[r0:r1], r1 - r0, C, 4 * C, dt, bias=P[pre + 'mlp.fc2.bias'], rowscale=dp2c, rows_per_scale=HW,
+                   R=x1[r0:r1], ldr=C, label=pre + 'fc2')
         else:
             st['t'] = self.blk_act(pre + 't', (M, C))
             st['m2'] = self.blk_act(pre + 'm2', (M,), torch.float32)
@@ -217,19 +231,25 @@ class CSWinEngine(GAEngine):
         F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
         Ho = Hin // 2
         Mo = B * Ho * Ho
+        (lane, r0, r1, b0, b1), = self._fsplits(Ho * Ho)           # output rows of this forward chain (whole images)
+        i0, i1 = b0 * Hin * Hin, b1 * Hin * Hin
+        if getattr(self, '_chain', None) is not None:
+            F.lane = lane
         Wf = self._w_plain(cname + 'weight', Cout, Cin, 3, 3, need_T=False)
         st = dict(x=x, Hin=Hin, Cin=Cin, Cout=Cout, cname=cname, nname=nname, bias=bias)
         if T:
+            first = ('wD.' + cname) not in self.bufs
             st['Bt'] = self.buf('wD.' + cname, (4 * Cin, pad8(4 * Cout)))
-            self.prep.conv3s2_dgrad_prep(P[cname + 'weight'], st['Bt'], Cout, Cin, pad8(4 * Cout), dt, label='prep.' + cname + 'dgrad')
+            if first:
+                self.prep.conv3s2_dgrad_prep(P[cname + 'weight'], st['Bt'], Cout, Cin, pad8(4 * Cout), dt, label='prep.' + cname + 'dgrad')
         st['c'] = self.act(cname + 'out', (Mo, Cout))
-        F.gemm(x, Wf, st['c'], Mo, Cout, 9 * Cin, dt, ldb=pad8(9 * Cin), a_kind=A_CONV3S2, a_dims=(Hin, Hin, Cin),
+        F.gemm(x[i0:i1], Wf, st['c'][r0:r1], r1 - r0, Cout, 9 * Cin, dt, ldb=pad8(9 * Cin), a_kind=A_CONV3S2, a_dims=(Hin, Hin, Cin),
                bias=P[cname + 'bias'] if bias else None, label=cname + 'conv')
         st['mean'] = self.act(nname + 'mean', (Mo,), torch.float32)
         st['rstd'] = self.act(nname + 'rstd', (Mo,), torch.float32)
         y = self.buf(nname + 'out', (Mo, Cout))
-        F.layernorm_fwd(st['c'], P[nname + 'weight'], P[nname + 'bias'], y, st['mean'], st['rstd'], Mo, Cout, 1e-5, dt,
-                        label=nname + 'ln')
+        F.layernorm_fwd(st['c'][r0:r1], P[nname + 'weight'], P[nname + 'bias'], y[r0:r1], st['mean'][r0:r1], st['rstd'][r0:r1], r1 - r0,
+                        Cout, 1e-5, dt, label=nname + 'ln')
         return y, st
 
     def _conv3s2_ln_bwd(self, st, dy, dprev, seed=None):
@@ -272,34 +292,48 @@ class CSWinEngine(GAEngine):
         self.pack_call = len(F.calls) - 1
         W0 = self.buf('w.' + sp + '0', (e, 72))
         self.prep.convw_pack(P[sp + '0.weight'], W0, e, 3, 9, 8, 72, dt, label='prep.' + sp + '0')
+        W1 = self._w_plain(sp + '5.weight', e, e, 3, 3, flip=True)
         S = self.stem = {}
         S['c0'] = self.act(sp + 'c0', (M1, e))
-        F.gemm(self.x8, W0, S['c0'], M1, e, 72, dt, a_kind=A_CONV3S2, a_dims=(img, img, 8), label=sp + 'conv0')
         S['a0'] = self.act(sp + 'a0', (M1, e))
         S['m0'], S['r0'] = self.act(sp + 'm0', (M1,), torch.float32), self.act(sp + 'r0', (M1,), torch.float32)
-        F.layernorm_gelu_fwd(S['c0'], P[sp + '2.weight'], P[sp + '2.bias'], S['a0'], S['m0'], S['r0'], M1, e, 1e-5, dt,
-                             label=sp + 'ln0')
-        W1 = self._w_plain(sp + '5.weight', e, e, 3, 3, flip=True)
         S['c1'] = self.act(sp + 'c1', (M1, e))
-        F.gemm(S['a0'], W1, S['c1'], M1, e, 9 * e, dt, ldb=pad8(9 * e), a_kind=A_CONV3, a_dims=(H1, H1, e), label=sp + 'conv1')
         S['a1'] = self.act(sp + 'a1', (M1, e))
         S['m1'], S['r1'] = self.act(sp + 'm1', (M1,), torch.float32), self.act(sp + 'r1', (M1,), torch.float32)
-        F.layernorm_gelu_fwd(S['c1'], P[sp + '7.weight'], P[sp + '7.bias'], S['a1'], S['m1'], S['r1'], M1, e, 1e-5, dt,
-                             label=sp + 'ln1')
-        x, S['conv2'] = self._conv3s2_ln_fwd(sp + '10.', sp + '12.', S['a1'], H1, e, d[0], bias=False)
-        # ---------------- stages 1..4 ----------------
         stages = [m.stage1, m.stage2, m.stage3, m.stage4]
         taps_at = tap_after(dep[2], cfg['naggre'])
-        feats, taps, self.merges = [], [], {}
-        for si in range(4):
-            if si > 0:
-                x, self.merges[si] = self._conv3s2_ln_fwd(f'merge{si}.conv.', f'merge{si}.norm.', x, stages[si - 1][0].reso,
-                                                          d[si - 1], d[si], bias=True)
-            for j, mod in enumerate(stages[si]):
-                x = self._cs_block_fwd(f'stage{si + 1}.{j}.', x, mod)
-                if si == 2 and (j + 1) in taps_at:
-                    taps.append((x, j))
-            feats.append((x, stages[si][0].reso))
+        # one pass per forward chain (batch part, GAEngine._chains): with GAEXT_FWD_SPLIT > 1 the deep stem and the four stages run as
+        # independent chains on side streams -- every op of the trunk is per image, and its launches are too small to fill the chip
+        # alone (the step timeline had one kernel running for 23 of 39 ms); every pass names the same full-batch buffers
+        chains = self._chains()
+        if any(mod.mlp_groups != 1 for st_ in stages for mod in st_):
+            chains = [(0, 0, B)]
+        for chain in chains:
+            self._chain = chain if len(chains) > 1 else None
+            (lane, r0, r1, b0, b1), = self._fsplits(H1 * H1)
+            F.lane = lane
+            F.gemm(self.x8[b0 * img * img:b1 * img * img], W0, S['c0'][r0:r1], r1 - r0, e, 72, dt, a_kind=A_CONV3S2, a_dims=(img, img, 8),
+                   label=sp + 'conv0')
+            F.layernorm_gelu_fwd(S['c0'][r0:r1], P[sp + '2.weight'], P[sp + '2.bias'], S['a0'][r0:r1], S['m0'][r0:r1], S['r0'][r0:r1],
+                                 r1 - r0, e, 1e-5, dt, label=sp + 'ln0')
+            F.gemm(S['a0'][r0:r1], W1, S['c1'][r0:r1], r1 - r0, e, 9 * e, dt, ldb=pad8(9 * e), a_kind=A_CONV3, a_dims=(H1, H1, e),
+                   label=sp + 'conv1')
+            F.layernorm_gelu_fwd(S['c1'][r0:r1], P[sp + '7.weight'], P[sp + '7.bias'], S['a1'][r0:r1], S['m1'][r0:r1], S['r1'][r0:r1],
+                                 r1 - r0, e, 1e-5, dt, label=sp + 'ln1')
+            x, S['conv2'] = self._conv3s2_ln_fwd(sp + '10.', sp + '12.', S['a1'], H1, e, d[0], bias=False)
+            # ---------------- stages 1..4 ----------------
+            feats, taps, self.merges = [], [], {}
+            for si in range(4):
+                if si > 0:
+                    x, self.merges[si] = self._conv3s2_ln_fwd(f'merge{si}.conv.', f'merge{si}.norm.', x, stages[si - 1][0].reso,
+                                                              d[si - 1], d[si], bias=True)
+                for j, mod in enumerate(stages[si]):
+                    x = self._cs_block_fwd(f'stage{si + 1}.{j}.', x, mod)
+                    if si == 2 and (j + 1) in taps_at:
+                        taps.append((x, j))
+                feats.append((x, stages[si][0].reso))
+        self._chain = None
+        F.lane = 0
         # ---------------- aggregate (ga_cswin.py:666-669) ----------------
         Hc = img // 16
         M4 = B * Hc * Hc
