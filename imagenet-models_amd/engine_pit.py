@@ -44,28 +44,37 @@ class MAPPiTEngine(MAPViTEngine):
         self.pack_call = len(F.calls) - 1
         Wpe = self._w_plain('patch_embed.conv.weight', C0, K0, 1, 1, need_T=False)
         tok = self.tmp('patch.tok', (Mp0, C0))
-        F.gemm(patches, Wpe, tok, Mp0, C0, K0, dt, bias=P['patch_embed.conv.bias'], label='patch.proj')
         posT = self.buf('w.posT', (w0 * w0, C0), torch.float32)
         self.prep.transpose_f32(P['pos_embed'], posT, C0, w0 * w0)
-        x = self.buf('embed.x0', (Mp0, C0))
-        F.pos_add_fwd(tok, posT, x, B, w0 * w0, C0, dt, label='embed')
-        # ---------------- stages ----------------
-        feats = [(x, w0, C0)]
-        self.stage_io = []                                # (input map, output map, hw, C) per stage
-        hw = w0
-        for s in range(3):
-            C, Ntok = dims[s], hw * hw
-            xin = x
-            for j in range(depth[s]):
-                x = self._vit_block_fwd(f'transformers.{s}.blocks.{j}.', x, B * Ntok, C, heads[s], Ntok)
-            feats.append((x, hw, C))
-            self.stage_io.append((xin, x, hw, C))
-            if s < 2:
-                ho = (hw - 1) // 2 + 1
-                y = self.buf(f'pool.{s}.y', (B * ho * ho, dims[s + 1]))
-                F.dwpool_fwd(x, P[f'pools.{s}.conv.weight'], P[f'pools.{s}.conv.bias'], y, B, hw, hw, C, dims[s + 1] // C, dt,
-                             label=f'pools.{s}')
-                x, hw = y, ho
+        x0 = self.buf('embed.x0', (Mp0, C0))
+        # ---------------- embedding + stages: one pass per forward chain (batch part on its own lane, GAEngine._chains) ----------------
+        chains = self._chains()
+        for chain in chains:
+            self._chain = chain if len(chains) > 1 else None
+            (lane, r0, r1, b0, b1), = self._fsplits(w0 * w0)
+            F.lane = lane
+            nb = b1 - b0
+            F.gemm(patches[r0:r1], Wpe, tok[r0:r1], r1 - r0, C0, K0, dt, bias=P['patch_embed.conv.bias'], label='patch.proj')
+            F.pos_add_fwd(tok[r0:r1], posT, x0[r0:r1], nb, w0 * w0, C0, dt, label='embed')
+            x = x0
+            feats = [(x, w0, C0)]
+            self.stage_io = []                                # (input map, output map, hw, C) per stage
+            hw = w0
+            for s_ in range(3):
+                C, Ntok = dims[s_], hw * hw
+                xin = x
+                for j in range(depth[s_]):
+                    x = self._vit_block_fwd(f'transformers.{s_}.blocks.{j}.', x, B * Ntok, C, heads[s_], Ntok)
+                feats.append((x, hw, C))
+                self.stage_io.append((xin, x, hw, C))
+                if s_ < 2:
+                    ho = (hw - 1) // 2 + 1
+                    y = self.buf(f'pool.{s_}.y', (B * ho * ho, dims[s_ + 1]))
+                    F.dwpool_fwd(x[b0 * hw * hw:b1 * hw * hw], P[f'pools.{s_}.conv.weight'], P[f'pools.{s_}.conv.bias'],
+                                 y[b0 * ho * ho:b1 * ho * ho], nb, hw, hw, C, dims[s_ + 1] // C, dt, label=f'pools.{s_}')
+                    x, hw = y, ho
+        self._chain = None
+        F.lane = 0
         # ---------------- MultiScale at the size of feature `multi_scale_level` (map.py:322-333) ----------------
         Hc = self.Hc = feats[cfg['multi_scale_level']][1]
         M4 = B * Hc * Hc

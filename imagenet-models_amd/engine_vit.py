@@ -35,38 +35,54 @@ class MAPViTEngine(MAPEngine):
 
     # ------------------------------------------------------------------------------------------
     def _vit_block_fwd(self, pre, x, M, C, heads, Ntok):
+        """inside a forward chain (GAEngine._chains: the trunk recorded once per batch part, each part on its own lane) the launches
+        cover the chain's rows of the same full-batch buffers; weight preparation and the backward's attention descriptor are recorded
+        by the first pass only"""
         F, dt, B, P, T = self.fwd, self.dt, self.B, self.P, self.training
+        (lane, r0, r1, b0, b1), = self._fsplits(Ntok)
+        first = pre not in self.blocks
+        if getattr(self, '_chain', None) is not None:
+            F.lane = lane
+        n = r1 - r0
         dp1, dp2 = self.dp_scale.get(pre + '#1'), self.dp_scale.get(pre + '#2')
-        st = self.blocks[pre] = dict(x=x)
+        dp1c = dp1[b0:b1] if dp1 is not None else None
+        dp2c = dp2[b0:b1] if dp2 is not None else None
+        st = self.blocks.setdefault(pre, dict(x=x))
         st['xn1'] = self.blk_act(pre + 'xn1', (M, C))
         st['r1'] = self.blk_act(pre + 'r1', (M,), torch.float32)
-        F.layernorm_fwd(x, None, None, st['xn1'], None, st['r1'], M, C, 1e-6, dt, label=pre + 'ln1')
+        F.layernorm_fwd(x[r0:r1], None, None, st['xn1'][r0:r1], None, st['r1'][r0:r1], n, C, 1e-6, dt, label=pre + 'ln1')
         Wqkv = self._w_plain(pre + 'attn.qkv.weight', 3 * C, C, 1, 1, cs=P[pre + 'norm1.weight'])
         bq = self.buf('w.' + pre + 'bqkv', (3 * C,), torch.float32)
-        self.prep.bias_fold(P[pre + 'attn.qkv.weight'], P[pre + 'attn.qkv.bias'], None, P[pre + 'norm1.bias'], bq, 3 * C, C)
+        if first:
+            self.prep.bias_fold(P[pre + 'attn.qkv.weight'], P[pre + 'attn.qkv.bias'], None, P[pre + 'norm1.bias'], bq, 3 * C, C)
         st['qkv'] = self.blk_act(pre + 'qkv', (M, 3 * C))
-        F.gemm(st['xn1'], Wqkv, st['qkv'], M, 3 * C, C, dt, bias=bq, label=pre + 'qkv')
+        F.gemm(st['xn1'][r0:r1], Wqkv, st['qkv'][r0:r1], n, 3 * C, C, dt, bias=bq, label=pre + 'qkv')
         st['att'] = self.blk_act(pre + 'att', (M, C))
         st['lse'] = self.blk_act(pre + 'lse', (B, heads, Ntok), torch.float32)
-        st['desc'] = F.attn_desc(st['qkv'], st['att'], st['lse'], B, Ntok, heads, C // heads, (C // heads) ** -0.5, dt)
-        F.attn_fwd(st['desc'], label=pre + 'attn')
+        if first:
+            st['desc'] = F.attn_desc(st['qkv'], st['att'], st['lse'], B, Ntok, heads, C // heads, (C // heads) ** -0.5, dt)
+        dfw = st['desc'] if n == M else F.attn_desc(st['qkv'][r0:r1], st['att'][r0:r1], st['lse'][b0:b1], b1 - b0, Ntok, heads, C // heads,
+                                                      (C // heads) ** -0.5, dt)
+        F.attn_fwd(dfw, label=pre + 'attn')
         Wp = self._w_plain(pre + 'attn.proj.weight', C, C, 1, 1)
         x1 = self.tmp('x1', (M, C))
-        F.gemm(st['att'], Wp, x1, M, C, C, dt, bias=P[pre + 'attn.proj.bias'], rowscale=dp1, rows_per_scale=Ntok, R=x, ldr=C,
-               label=pre + 'proj')
+        F.gemm(st['att'][r0:r1], Wp, x1[r0:r1], n, C, C, dt, bias=P[pre + 'attn.proj.bias'], rowscale=dp1c, rows_per_scale=Ntok,
+               R=x[r0:r1], ldr=C, label=pre + 'proj')
         st['xn2'] = self.blk_act(pre + 'xn2', (M, C))
         st['r2'] = self.blk_act(pre + 'r2', (M,), torch.float32)
-        F.layernorm_fwd(x1, None, None, st['xn2'], None, st['r2'], M, C, 1e-6, dt, label=pre + 'ln2')
+        F.layernorm_fwd(x1[r0:r1], None, None, st['xn2'][r0:r1], None, st['r2'][r0:r1], n, C, 1e-6, dt, label=pre + 'ln2')
         W1 = self._w_plain(pre + 'mlp.fc1.weight', 4 * C, C, 1, 1, cs=P[pre + 'norm2.weight'])
         b1e = self.buf('w.' + pre + 'b1e', (4 * C,), torch.float32)
-        self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm2.bias'], b1e, 4 * C, C)
+        if first:
+            self.prep.bias_fold(P[pre + 'mlp.fc1.weight'], P[pre + 'mlp.fc1.bias'], None, P[pre + 'norm2.bias'], b1e, 4 * C, C)
         st['a'] = self.blk_act(pre + 'a', (M, 4 * C))
         st['g'] = self.buf(pre + 'g', (M, 4 * C)) if T else None
-        F.gemm(st['xn2'], W1, st['a'], M, 4 * C, C, dt, bias=b1e, act=ACT_GELU, C2=st['g'], c2_mode=2 if T else 0, label=pre + 'fc1')
+        F.gemm(st['xn2'][r0:r1], W1, st['a'][r0:r1], n, 4 * C, C, dt, bias=b1e, act=ACT_GELU, C2=st['g'][r0:r1] if T else None,
+               c2_mode=2 if T else 0, label=pre + 'fc1')
         W2 = self._w_plain(pre + 'mlp.fc2.weight', C, 4 * C, 1, 1)
         y = self.buf(pre + 'y', (M, C))
-        F.gemm(st['a'], W2, y, M, C, 4 * C, dt, bias=P[pre + 'mlp.fc2.bias'], rowscale=dp2, rows_per_scale=Ntok, R=x1, ldr=C,
-               label=pre + 'fc2')
+        F.gemm(st['a'][r0:r1], W2, y[r0:r1], n, C, 4 * C, dt, bias=P[pre + 'mlp.fc2.bias'], rowscale=dp2c, rows_per_scale=Ntok,
+               R=x1[r0:r1], ldr=C, label=pre + 'fc2')
         return y
 
     def _vit_block_bwd(self, pre, dy, dx, M, C, Ntok, next_pre=None):
@@ -164,25 +180,34 @@ class MAPViTEngine(MAPEngine):
         self.pack_call = len(F.calls) - 1
         Wpe = self._w_plain('patch_embed.proj.weight', C, K0, 1, 1, need_T=False)
         tok = self.tmp('patch.tok', (Mp, C))
-        F.gemm(patches, Wpe, tok, Mp, C, K0, dt, bias=P['patch_embed.proj.bias'], label='patch.proj')
-        x = self.buf('embed.x0', (M, C))
-        F.vit_embed_fwd(tok, P['cls_token'], P['pos_embed'], x, B, Np, C, dt, label='embed')
-        # ---------------- blocks; feature taps ----------------
+        x0 = self.buf('embed.x0', (M, C))
         taps = cfg['taps']                                   # block counts after which a feature map is taken (the last = depth)
-        feats = [self._tokens_to_map(x, 'f0', B, Np, Ntok, C)]
-        self.tap_at = {}
-        for i in range(depth):
-            x = self._vit_block_fwd(f'blocks.{i}.', x, M, C, heads, Ntok)
-            if i + 1 in taps:
-                self.tap_at[i + 1] = len(feats)
-                fm = self._tokens_to_map(x, f'f{len(feats)}', B, Np, Ntok, C)
-                if i + 1 == depth:       # final norm (timm forward_features) on the map rows: LayerNorm is per token
-                    self.fn = dict(x=fm, y=self.act('norm.out', (Mp, C)), m=self.act('norm.m', (Mp,), torch.float32),
-                                   r=self.act('norm.r', (Mp,), torch.float32))
-                    F.layernorm_fwd(fm, P['norm.weight'], P['norm.bias'], self.fn['y'], self.fn['m'], self.fn['r'], Mp, C, 1e-6, dt,
-                                    label='norm')
-                    fm = self.fn['y']
-                feats.append(fm)
+        # ---------------- embedding, blocks, feature taps: one pass per forward chain (batch part on its own lane) ----------------
+        chains = self._chains()
+        for chain in chains:
+            self._chain = chain if len(chains) > 1 else None
+            (lane, r0, r1, b0, b1), = self._fsplits(Ntok)
+            F.lane = lane
+            p0, p1, nb = b0 * Np, b1 * Np, b1 - b0
+            F.gemm(patches[p0:p1], Wpe, tok[p0:p1], p1 - p0, C, K0, dt, bias=P['patch_embed.proj.bias'], label='patch.proj')
+            F.vit_embed_fwd(tok[p0:p1], P['cls_token'], P['pos_embed'], x0[r0:r1], nb, Np, C, dt, label='embed')
+            x = x0
+            feats = [self._tokens_to_map(x, 'f0', B, Np, Ntok, C)]
+            self.tap_at = {}
+            for i in range(depth):
+                x = self._vit_block_fwd(f'blocks.{i}.', x, M, C, heads, Ntok)
+                if i + 1 in taps:
+                    self.tap_at[i + 1] = len(feats)
+                    fm = self._tokens_to_map(x, f'f{len(feats)}', B, Np, Ntok, C)
+                    if i + 1 == depth:       # final norm (timm forward_features) on the map rows: LayerNorm is per token
+                        self.fn = dict(x=fm, y=self.act('norm.out', (Mp, C)), m=self.act('norm.m', (Mp,), torch.float32),
+                                       r=self.act('norm.r', (Mp,), torch.float32))
+                        F.layernorm_fwd(fm[p0:p1], P['norm.weight'], P['norm.bias'], self.fn['y'][p0:p1], self.fn['m'][p0:p1],
+                                        self.fn['r'][p0:p1], p1 - p0, C, 1e-6, dt, label='norm')
+                        fm = self.fn['y']
+                    feats.append(fm)
+        self._chain = None
+        F.lane = 0
         self.x_last = x
         # ---------------- MultiScale: every map (gw x gw) reduced to gw/2 x gw/2, concat, conv1x1 + BN + GELU ----------------
         Hc = self.Hc = gw // 2
@@ -203,9 +228,10 @@ class MAPViTEngine(MAPEngine):
         self.prep.flush('prep.')
 
     def _tokens_to_map(self, x, name, B, Np, Ntok, C):
-        """drop the class token: rows 1.. of every image -> [B*Np, C]"""
+        """drop the class token: rows 1.. of every image -> [B*Np, C] (the images of the current forward chain)"""
         fm = self.act('feat.' + name, (B * Np, C))
-        self.fwd.copy2d(x[1:], Ntok * C, fm, Np * C, B, Np * C, self.dt, label='feat.' + name)
+        (lane, r0, r1, b0, b1), = self._fsplits(Ntok)
+        self.fwd.copy2d(x[r0 + 1:], Ntok * C, fm[b0 * Np:], Np * C, b1 - b0, Np * C, self.dt, label='feat.' + name)
         return fm
 
     def _build_vit_backward(self, xh, M4, feats, B, Np, Ntok, C, M, Mp, K0):
