@@ -1418,16 +1418,18 @@ __global__ __launch_bounds__(256, 2) void dwconv7_wgrad_rs_kernel(const bf16_t* 
 }
 
 // dw49[tap][c] += sum over strips and workgroups of the partials; dbias[c] likewise.  workgroup = (64 channel pairs, value v of
-// the 100) x 4 groups of workgroups; fixed summation order (deterministic)
-__global__ __launch_bounds__(256) void dwconv7_wgrad_rs_reduce(const float* __restrict__ part, int nbw, int wpu, int nstrips, int C,
-                                                               float* __restrict__ dw49, float* __restrict__ dbias) {
-    __shared__ float red[4][64];
+// the 100) x 16 groups of workgroups; fixed summation order (deterministic).  (4 groups: 20 us for the 13 MB of a 56 x 56 x 96
+// launch -- 168 dependent-latency loads per thread)
+__global__ __launch_bounds__(1024) void dwconv7_wgrad_rs_reduce(const float* __restrict__ part, int nbw, int wpu, int nstrips, int C,
+                                                                float* __restrict__ dw49, float* __restrict__ dbias) {
+    constexpr int NG = 16;
+    __shared__ float red[NG][64];
     const int CP = C >> 1;
     const int cpl = threadIdx.x & 63, kg = threadIdx.x >> 6;
     const int cp = blockIdx.x * 64 + cpl, v = blockIdx.y;
     float sum = 0.f;
     if (cp < CP) {
-        const int per = (nbw + 3) / 4, k0 = kg * per, k1 = min(nbw, k0 + per);
+        const int per = (nbw + NG - 1) / NG, k0 = kg * per, k1 = min(nbw, k0 + per);
         for (int st = 0; st < nstrips; ++st) {
             const int item = st * CP + cp, wi = item >> 6, l = item & 63;
             const float* p = part + (long)wi * (DWW::NV * 64) + v * 64 + l;
@@ -1438,7 +1440,9 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_rs_reduce(const float* __re
     red[kg][cpl] = sum;
     __syncthreads();
     if (kg == 0 && cp < CP) {
-        sum = (red[0][cpl] + red[1][cpl]) + (red[2][cpl] + red[3][cpl]);
+        sum = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) sum += red[g][cpl];
         const int tap = v >> 1, e = v & 1;
         if (tap < 49) dw49[(long)tap * C + 2 * cp + e] += sum;
         else if (dbias) dbias[2 * cp + e] += sum;
@@ -1484,7 +1488,7 @@ int launch_dwconv_wgrad_rs(const void* dy, const void* x, float* dw49, float* db
     const unsigned bytes = (unsigned)((long)B * H * W * C * 2);
     hipLaunchKernelGGL(dwconv7_wgrad_rs_kernel, dim3(nb), dim3(256), DWW::LDS, s, (const bf16_t*)dy, (const bf16_t*)x, part, H, W, C, R,
                        nseg, nstrips, wpu, B * nseg, bytes);
-    hipLaunchKernelGGL(dwconv7_wgrad_rs_reduce, dim3(cdiv(C / 2, 64), DWW::NV), dim3(256), 0, s, part, nb / wpu, wpu, nstrips, C, dw49,
+    hipLaunchKernelGGL(dwconv7_wgrad_rs_reduce, dim3(cdiv(C / 2, 64), DWW::NV), dim3(1024), 0, s, part, nb / wpu, wpu, nstrips, C, dw49,
                        dbias);
     return ga_check_launch("ga_dwconv7_bwd_weight");
 }
@@ -1599,11 +1603,11 @@ int launch_dwconv_wgrad(const void* dy, const void* x, float* dw49, float* dbias
     }
     if constexpr (sizeof(T) == 2) {
         int rsR, rsW, rsN;
-        // register-sliding form: 0 never, 1 (default) on 56 x 56 maps and larger (256 x 56 x 56 x 96: 0.127 vs 0.187 ms; on the
-        // smaller maps its per-unit start-up and the 13 MB of partials eat the gain: 28 x 28 0.074 vs 0.076, 14 x 14 0.049 vs 0.043),
+        // register-sliding form: 0 never, 1 (default) on 28 x 28 maps and larger (256 x 56 x 56 x 96: 0.134 vs 0.182 ms, 28 x 28 x 192:
+        // 0.071 vs 0.078; on the smaller maps its per-unit start-up and the 13 MB of partials eat the gain: 14 x 14 0.047 vs 0.044),
         // 2 wherever it applies
         const int use_rs = GA_KNOB("DWW_RS", 1);
-        if (use_rs && (use_rs == 2 || H * W >= 56 * 56) && dww_rs_geometry(B, H, W, C, &rsR, &rsW, &rsN))
+        if (use_rs && (use_rs == 2 || H * W >= 28 * 28) && dww_rs_geometry(B, H, W, C, &rsR, &rsW, &rsN))
             return launch_dwconv_wgrad_rs(dy, x, dw49, dbias, B, H, W, C, part, s);
         if (dot2) {
             auto k14 = dwconv7_wgrad_dot2_kernel<14, 14>;
