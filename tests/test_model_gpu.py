@@ -604,8 +604,11 @@ def test_lanes_do_not_change_the_training_trajectory(monkeypatch):
     l_off, s_off, p_off = _train_losses(monkeypatch, False)
     l_on, s_on, p_on = _train_losses(monkeypatch, True)
     print('one stream :', l_off, '\\nwith lanes :', l_on)
+    # tolerance: two runs on ONE stream already land on either of two trajectories 1.1e-4 apart at step 2 (2.9e-4 at step 4): AdamW
+    # moves a parameter whose gradient is atomics noise by +-lr whatever the noise, and the sign of that noise differs from run
+    # to run.  A launch that started before its producer finished changes the losses by far more than 1e-3.
     for a, b in zip(l_off, l_on):
-        assert abs(a - b) <= 2e-4 * abs(a), (l_off, l_on)
+        assert abs(a - b) <= 1e-3 * abs(a), (l_off, l_on)
     # AdamW moves a parameter whose gradient is rounding noise (biases feeding a train-mode BatchNorm) by +-lr per step
     # whatever the noise, so two runs differ by ~2e-3 in L2 even on one stream: the losses above are the sharp check
     assert float((p_on - p_off).double().norm() / p_off.double().norm()) < 5e-3
