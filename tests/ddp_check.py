@@ -17,16 +17,33 @@ def main():
     dist.init_process_group(os.environ.get('GA_DIST_BACKEND', 'gloo'), init_method='env://')
     import imagenet_models_amd as A
     from oracle import ga_convnext_oracle as O
-    cfg = O.make_cfg(dims=(16, 32, 64, 128, 128), depths=(1, 1, 6, 1, 1), gram_dim=32, dim_embed=64, num_classes=40, naggre=2)
-    sd = O.fill_state(cfg)
-    B = 8
+    family = os.environ.get('GA_DDP_FAMILY', '')            # '' = the narrow GA-ConvNeXt; else a registered model name (full size, B = 2)
+    if not family:
+        cfg = O.make_cfg(dims=(16, 32, 64, 128, 128), depths=(1, 1, 6, 1, 1), gram_dim=32, dim_embed=64, num_classes=40, naggre=2)
+        sd = O.fill_state(cfg)
+        B, NC, img, kind = 8, 40, 224, 0
+    else:
+        torch.manual_seed(7)                                 # the same initial state on every rank
+        fkw = dict(head_drop=0.0, head_attn_drop=0.0) if family.startswith('map_') else {}   # (dropout masks: random per model instance)
+        m0 = A.create_model(family, math_mode='fp32', **fkw)
+        with torch.no_grad():                                # (layer-scale parameters start at 1e-6: any non-trivial values do)
+            for p_ in m0.parameters():
+                if p_.dim() <= 1 and float(p_.abs().max()) < 1e-3:
+                    p_.fill_(0.1)
+        sd = {k: v.clone() for k, v in m0.state_dict().items()}
+        B, NC, img = 2, m0.num_classes, getattr(m0, 'cfg', {}).get('img_size', 224)
+        kind = 0                                              # TrainStep / forward_loss pick the family's loss (GA / MAP) themselves
+        del m0
     g = torch.Generator().manual_seed(100 + rank)          # every rank sees different data
-    x = torch.randn(B, 3, 224, 224, generator=g).cuda()
-    y = torch.randint(0, 40, (B,), generator=g).cuda()
+    x = torch.randn(B, 3, img, img, generator=g).cuda()
+    y = torch.randint(0, NC, (B,), generator=g).cuda()
 
     def make():
-        m = A.GA_ConvNeXt(num_classes=40, depths=cfg['depths'], dims=cfg['dims'], gram_embedding_gropus=cfg['gram_groups'],
-                          dim_embed=cfg['dim_embed'], stage3_naggre=cfg['naggre'], gram_dim=cfg['gram_dim'], math_mode='fp32')
+        if family:
+            m = A.create_model(family, math_mode='fp32', **fkw)
+        else:
+            m = A.GA_ConvNeXt(num_classes=40, depths=cfg['depths'], dims=cfg['dims'], gram_embedding_gropus=cfg['gram_groups'],
+                              dim_embed=cfg['dim_embed'], stage3_naggre=cfg['naggre'], gram_dim=cfg['gram_dim'], math_mode='fp32')
         m.load_state_dict(sd)
         m = m.cuda().train()
         return m, A.create_optimizer_v2(m, opt='adamw', lr=1e-2, weight_decay=0.05)
@@ -98,7 +115,7 @@ def main():
     dpar = float((p3 - p_ddp)[big].abs().max())
     assert dpar <= 2e-3 * 1e-2 + 1e-6, dpar              # lr 1e-2: the two updates agree to a fraction of one step
     if rank == 0:
-        print(f'DDP_CHECK_OK max rel grad diff {err:.2e} buckets {[(m, b - a) for m, a, b in step.buckets]}', flush=True)
+        print(f'DDP_CHECK_OK {family or "ga_convnext(narrow)"} max rel grad diff {err:.2e} buckets {[(m, b - a) for m, a, b in step.buckets]}', flush=True)
     dist.destroy_process_group()
 
 
