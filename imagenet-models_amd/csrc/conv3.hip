@@ -1,0 +1,208 @@
+// Direct 3 x 3 convolution (pad 1, stride 1) for 64 -> 64 channels, NHWC bf16, on the matrix cores -- the form of ga_gemm's
+// GA_A_CONV3 product that GA-CSWin's deep stem needs (ga_cswin.py:463-477: Conv2d(64, 64, 3, 1, 1) on the 112 x 112 map of every
+// image: 237 GFLOP per pass at batch 256, forward and -- with the flipped / transposed weight image ga_weight_prep already writes --
+// backward-data).  The implicit-GEMM gather fetches every input pixel nine times from L2 and ran these launches at 215-260 TFLOP/s
+// (1.1 / 0.92 ms); their HBM time is 0.2 ms.
+//
+//   workgroup (4 waves, persistent over tiles) = 8 x 16 output pixels x 64 channels; the 10 x 18 input tile with its halo lives in
+//   LDS ([pixel][128 B], the 16-byte chunk c of pixel P at slot c ^ ((P >> 1) & 7): the 16 pixels of a fragment read conflict-
+//   free), double-buffered and filled by `buffer_load_dwordx4 ... lds` one tile ahead (pixels outside the image carry an
+//   out-of-range offset and land as zeros); the whole weight matrix [64][576] stays in LDS (72 KiB, same swizzle by output
+//   channel).  wave = 2 image rows: per k step (one tap, 32 input channels) 4 weight fragments x 2 pixel fragments -> 8
+//   v_mfma_f32_16x16x32_bf16 with the weights as the A operand, so that a lane ends with 4 consecutive output channels of one
+//   pixel; results go through a per-wave staging piece to 16-byte NHWC stores.
+//   Bound: LDS reads (6 ds_read_b128 per 8 MFMAs, one workgroup of 133 KiB per CU).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned c3_u4;
+
+constexpr int TH = 8, TW = 16, HH = TH + 2, HW_ = TW + 2, NPX = HH * HW_;      // 180 halo pixels
+constexpr int W_BYTES = 64 * 1152;                                             // weights: 64 rows x 576 bf16
+constexpr int DMA_PER_WAVE = 6;                                                // 24 x 1 KiB >= 22.5 KiB: the last pieces are out of range
+constexpr int IN_BUF = DMA_PER_WAVE * 4 * 1024;                                // 24576 B per buffer (so every DMA piece has its own KiB)
+constexpr int ST_BYTES = 4096;                                                 // per-wave staging: 32 pixels x 128 B
+constexpr int LDS_TOTAL = W_BYTES + 2 * IN_BUF + 4 * ST_BYTES;                 // 73728 + 49152 + 16384 = 139264
+
+__device__ __forceinline__ c3_u4 c3_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    c3_u4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r[2] = bytes;
+    r[3] = 0x00020000u;
+    return r;
+}
+
+// six 1-KiB pieces of this wave: lane l of piece i writes LDS [dst + 1024 i + 16 l]; v[i] = source offset - 1024 i
+__device__ __forceinline__ void c3_dma6(c3_u4 rs, unsigned dst, const unsigned* v) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c0], %[rs], 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %[c1], %[rs], 0 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %[c2], %[rs], 0 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %[c3], %[rs], 0 offen offset:3072 lds\n\t"
+                 "s_mov_b32 m0, %[d2]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c4], %[rs], 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %[c5], %[rs], 0 offen offset:1024 lds\n\t"
+                 "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [c0] "v"(v[0]), [c1] "v"(v[1]), [c2] "v"(v[2]), [c3] "v"(v[3]), [c4] "v"(v[4]), [c5] "v"(v[5]), [rs] "s"(rs), [d] "s"(dst),
+                   [d2] "s"(dst + 4096u)
+                 : "memory");
+}
+template <int N> __device__ __forceinline__ void c3_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(256, 1) void conv3_c64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wmat, long ldb,
+                                                           bf16_t* __restrict__ y, int nimg, int H, int W, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* wl = smem;
+    unsigned char* inb = smem + W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* stg = smem + W_BYTES + 2 * IN_BUF + wv * ST_BYTES;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---- weights -> LDS: row n (output channel) of 1152 B, its 16-byte chunk q at (q & ~7) + ((q & 7) ^ ((n >> 1) & 7))
+    for (int u = tid; u < 64 * 72; u += 256) {
+        const int n = u / 72, q = u - n * 72;
+        const c3_u4 v = *reinterpret_cast<const c3_u4*>(wmat + (long)n * ldb + q * 8);
+        *reinterpret_cast<c3_u4*>(wl + n * 1152 + (q & ~7) * 16 + (((q & 7) ^ ((n >> 1) & 7)) << 4)) = v;
+    }
+
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int tpi = tiles_x * tiles_y;
+    const long ntiles = (long)nimg * tpi;
+    const c3_u4 rx = c3_rsrc(x, bytes);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, bytes, 0x00020000);
+
+    // DMA piece i of this wave: global piece index d = 4 i' ... pieces are dealt round-robin: piece (wave, i) covers LDS KiB
+    // number wv * 6 + i of the buffer, i.e. chunks u = (wv * 6 + i) * 64 + lane -> halo pixel P = u / 8, physical slot u % 8
+    int hp_y[DMA_PER_WAVE], hp_x[DMA_PER_WAVE], hp_c[DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const int u = (wv * DMA_PER_WAVE + i) * 64 + lane;
+        const int P = u >> 3, slot = u & 7;
+        hp_y[i] = P < NPX ? P / HW_ : -1000000;
+        hp_x[i] = P % HW_;
+        hp_c[i] = slot ^ ((P >> 1) & 7);           // the logical chunk that lives in this physical slot
+    }
+    auto issue = [&](long t, int buf) {
+        unsigned v[DMA_PER_WAVE];
+        const bool live = t < ntiles;
+        const int img = live ? (int)(t / tpi) : 0;
+        const int rem = live ? (int)(t - (long)img * tpi) : 0;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int yy = ty * TH + hp_y[i] - 1, xx = tx * TW + hp_x[i] - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = (unsigned)((((long)img * H + yy) * W + xx) * 128 + hp_c[i] * 16);
+            v[i] = (ok ? off : 0x80000000u) - 1024u * (i & 3);
+        }
+        c3_dma6(rx, lds0 + W_BYTES + buf * IN_BUF + wv * (DMA_PER_WAVE * 1024), v);
+    };
+
+    // fragment addresses that do not depend on the tile
+    const int fr = lane & 15, fk = lane >> 4;
+    unsigned woff[4];                               // weight fragment j (output channels 16 j .. 16 j + 15) at k step 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = (16 * j + fr) * 1152;
+    const int wsw = (fr >> 1) & 7;                  // (n >> 1) & 7 with n = 16 j + fr: j drops out (16 j is a multiple of 16)
+
+    long t = blockIdx.x;
+    issue(t, 0);
+    c3_wait_vm<0>();                                // the first tile's pieces (no stores behind them yet: the counted wait below would be short)
+    __syncthreads();                                // weights in LDS (their global loads were waited for by the compiler)
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        c3_wait_vm<4>();                            // this wave's six pieces of tile t (the four stores of the previous tile may be pending)
+        __builtin_amdgcn_s_barrier();               // every wave's pieces have landed; everyone is done with the other buffer
+        issue(t + gridDim.x, buf ^ 1);
+        const unsigned char* in = inb + buf * IN_BUF;
+        f32x4_t acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int tap = s >> 1, ky = tap / 3, kx = tap - 3 * ky, half = s & 1;
+            bf16x8_t wf[4], pf[2];
+            const int q = s * 4 + fk;               // 16-byte chunk of the weight row
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                wf[j] = *reinterpret_cast<const bf16x8_t*>(wl + woff[j] + (q & ~7) * 16 + (((q & 7) ^ wsw) << 4));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int P = (2 * wv + i + ky) * HW_ + fr + kx;
+                pf[i] = *reinterpret_cast<const bf16x8_t*>(in + P * 128 + (((half * 4 + fk) ^ ((P >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], pf[i], acc[i][j], 0, 0, 0);
+        }
+        // ---- epilogue: lane holds channels 16 j + 4 fk .. + 3 of pixel (row 2 wv + i, column fr): 8-byte pieces -> staging
+        // [32 pixels][128 B] (chunk c of pixel p at slot c ^ (p & 7)) -> 16-byte stores
+        const int img = (int)(t / tpi);
+        const int rem = (int)(t - (long)img * tpi);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        unsigned pk[2][4][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pk[i][j][0] = pack2bf(acc[i][j][0], acc[i][j][1]);
+                pk[i][j][1] = pack2bf(acc[i][j][2], acc[i][j][3]);
+                const int p = i * 16 + fr, c = 2 * j + (fk >> 1);
+                *reinterpret_cast<uint2*>(stg + p * 128 + ((c ^ (p & 7)) << 4) + (fk & 1) * 8) = make_uint2(pk[i][j][0], pk[i][j][1]);
+            }
+        asm volatile("" ::: "memory");
+        c3_u4 ov[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) ov[it] = *reinterpret_cast<const c3_u4*>(stg + (it * 64 + lane) * 16);
+        // (the staged registers stay live until the read-back has returned: a ds_write may fetch its data late behind LDS-DMA)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(pk[i][j][0]), "+v"(pk[i][j][1]), "+v"(ov[0]), "+v"(ov[3])::"memory");
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int p = it * 8 + (lane >> 3), c = (lane & 7) ^ (p & 7);
+            const int yy = ty * TH + 2 * wv + (p >> 4), xx = tx * TW + (p & 15);
+            const unsigned off = (unsigned)((((long)img * H + yy) * W + xx) * 128 + c * 16);
+            __builtin_amdgcn_raw_buffer_store_b128(ov[it], ry, off, 0, 0);
+            asm volatile("s_nop 1" ::"v"(ov[it]) : "memory");
+        }
+    }
+    c3_wait_vm<0>();                                // no DMA may still be landing when the LDS is handed on
+}
+
+}  // namespace
+
+// ga_gemm's GA_A_CONV3 product, plain epilogue, bf16, 64 input channels, N = 64, maps of 8 x 16 tiles: returns 1 if it took the launch
+int ga_conv3_c64_try(const ga_gemm_desc* d, hipStream_t s) {
+    if (!GA_KNOB("CONV3_DIRECT", 1)) return 0;
+    if (d->dtype != GA_BF16 || d->a_kind != GA_A_CONV3 || d->a_C != 64 || d->N != 64 || d->K != 576 || d->batch != 1) return 0;
+    if (d->c_kind != GA_C_PLAIN || d->c_f32 || d->ldc != 64 || d->bias || d->R || d->H || d->C2 || d->rowscale || d->colsum || d->colsumsq ||
+        d->act != GA_ACT_NONE || d->a_act != GA_ACT_NONE || d->relu_after || d->alpha != 1.0f)
+        return 0;
+    if (d->a_H % TH != 0 || d->a_W % TW != 0 || d->ldb % 8 != 0) return 0;
+    const long hw = (long)d->a_H * d->a_W;
+    if (d->M % hw != 0) return 0;
+    const long nimg = d->M / hw;
+    const long bytes = d->M * 128;
+    if (bytes >= (1L << 31)) return 0;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL) == hipSuccess;
+    if (!attr_ok) return 0;
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ntiles = nimg * (d->a_H / TH) * (d->a_W / TW);
+    const int grid = (int)std::min<long>(ntiles, cus);
+    hipLaunchKernelGGL(conv3_c64_kernel, dim3(grid), dim3(256), LDS_TOTAL, s, (const bf16_t*)d->A, (const bf16_t*)d->B, (long)d->ldb,
+                       (bf16_t*)d->C, (int)nimg, d->a_H, d->a_W, (unsigned)bytes);
+    return 1;
+}

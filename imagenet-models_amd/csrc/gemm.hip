@@ -2209,6 +2209,7 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         if (bf) launch_nt<bf16_t, TNW, NWM>(d, s);     \
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
+    if (d->a_kind == GA_A_CONV3 && ga_conv3_c64_try(d, s)) return ga_check_launch("ga_gemm");     // 64 -> 64 channels: direct convolution
     const int epi = classify_epilogue(d);
     if ((d->a_kind == GA_A_PATCH2 || d->c_kind == GA_C_UNPATCH2) && classify_epilogue(d, true) == EPI_PLAIN && want_r3(d, EPI_PLAIN)) {
         launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map / its data gradient

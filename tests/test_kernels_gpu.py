@@ -177,6 +177,40 @@ def test_gemm_patch2_ring3_form_bf16(geom, knobs):
         assert_close(DX, xx.grad.permute(0, 2, 3, 1), 2e-2, 'unpatch2 on the ring form')
 
 
+@pytest.mark.parametrize('geom', [(2, 16, 32), (3, 8, 16), (1, 24, 48), (3, 112, 112)])     # (the last: more tiles than workgroups)
+def test_gemm_conv3_direct_form_64_channels(geom, knobs):
+    """the direct 3 x 3 / 64 -> 64 channel kernel behind ga_gemm's GA_A_CONV3 product (csrc/conv3.hip: GA-CSWin's deep stem):
+    forward and backward-data against F.conv2d, and bit-identical?  no: against the implicit-GEMM form within bf16 rounding"""
+    ops = _imp()
+    dt = torch.bfloat16
+    Bn, H, W = geom
+    Cc = N = 64
+    g = gen(6)
+    x, X = rnd((Bn, H, W, Cc), dt, g)
+    w, _ = rnd((N, Cc, 3, 3), dt, g, 0.05)
+    M = Bn * H * W
+    P = ops.Plan(eager=True)
+    Wf = torch.empty(N, 9 * Cc, dtype=dt, device='cuda')
+    WT = torch.empty(Cc, 9 * N, dtype=dt, device='cuda')
+    P.weight_prep(w.cuda(), 1, N, Cc, 3, 3, ops.ga_dtype(dt), out=Wf, ldo=9 * Cc, outT=WT, ldt=9 * N, flip=True)
+    xx = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = F.conv2d(xx, w, padding=1)
+    dy, DY = rnd((M, N), dt, g)
+    y.backward(dy.reshape(Bn, H, W, N).permute(0, 3, 1, 2))
+    outs = {}
+    for form in (1, 0):
+        knobs(CONV3_DIRECT=form)
+        Cout = torch.full((M, N), 777.0, dtype=dt, device='cuda')
+        P.gemm(X, Wf, Cout, M, N, 9 * Cc, ops.ga_dtype(dt), a_kind=ops.A_CONV3, a_dims=(H, W, Cc))
+        DX = torch.full((M, Cc), 777.0, dtype=dt, device='cuda')
+        P.gemm(DY, WT, DX, M, Cc, 9 * N, ops.ga_dtype(dt), a_kind=ops.A_CONV3, a_dims=(H, W, N))
+        torch.cuda.synchronize()
+        assert_close(Cout, y.permute(0, 2, 3, 1).reshape(M, N), tol(dt), f'conv3 fwd (direct={form})')
+        assert_close(DX, xx.grad.permute(0, 2, 3, 1).reshape(M, Cc), tol(dt), f'conv3 dgrad (direct={form})')
+        outs[form] = (Cout.float(), DX.float())
+    assert float((outs[1][0] - outs[0][0]).abs().max()) <= 2e-2 * float(outs[0][0].abs().max())
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_gemm_conv3_fwd_and_dgrad(dt):
     ops = _imp()
