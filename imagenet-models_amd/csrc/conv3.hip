@@ -180,6 +180,170 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_kernel(const bf16_t* __restr
     c3_wait_vm<0>();                                // no DMA may still be landing when the LDS is handed on
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution: dW[co][tap * 64 + ci] += sum over pixels of dY[p][co] * X[p + tap][ci].
+//   Same tiles (8 x 16 pixels, persistent workgroups); the contraction index is the PIXEL, the memory-slow index of both
+//   operands, so both fragments are `ds_read_b64_tr_b16` reads of the [pixel][128 B] images (the idiom of the TN GEMM).  The X
+//   halo tile is padded to 24 pixels per row: a k step (32 pixels = 2 tile rows) then advances the pixel index by 48, which leaves
+//   the swizzle term (P >> 1) & 7 alone, so the 18 fragment addresses of a lane (9 taps x 2 halves) are tile- and step-invariant
+//   registers + immediates.  wave w owns input channels 16 w .. 16 w + 15: 9 taps x 4 output-channel tiles = 36 accumulator
+//   tiles (144 registers) live through the whole walk; per k step 8 dY + 18 X fragment reads feed 36 MFMAs.
+//   At the end every workgroup stores ONE partial [64][576] fp32; conv3_wgrad_reduce adds them into dW.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short c3_s4;
+constexpr int XW = 24;                                       // padded halo row pitch (pixels)
+constexpr int XBUF = 32 * 1024, DBUF = 16 * 1024;            // 10 x 24 x 128 = 30 KiB in 8 pieces per wave; 128 x 128 B
+constexpr int WG_LDS = 2 * XBUF + 2 * DBUF;                  // 96 KiB
+
+__device__ __forceinline__ void c3_dma4(c3_u4 rs, unsigned dst, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c0], %[rs], 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %[c1], %[rs], 0 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %[c2], %[rs], 0 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %[c3], %[rs], 0 offen offset:3072 lds\n\t"
+                 "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [c0] "v"(v0), [c1] "v"(v1), [c2] "v"(v2), [c3] "v"(v3), [rs] "s"(rs), [d] "s"(dst)
+                 : "memory");
+}
+
+__global__ __launch_bounds__(256, 1) void conv3_c64_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                 float* __restrict__ part, int nimg, int H, int W, unsigned bytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int tpi = tiles_x * tiles_y;
+    const long ntiles = (long)nimg * tpi;
+    const c3_u4 rx = c3_rsrc(x, bytes), rd = c3_rsrc(dy, bytes);
+
+    // DMA: X piece i (8 per wave) covers chunks u = (8 wv + i) * 64 + lane of the padded halo image: pixel P = u / 8 = hy * 24 + hx;
+    // dY piece i (4 per wave): chunks u = (4 wv + i) * 64 + lane, pixel p = u / 8 of the 8 x 16 tile
+    int xy[8], xx_[8], xc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int u = (wv * 8 + i) * 64 + lane;
+        const int P = u >> 3, hy = P / XW, hx = P - hy * XW;
+        xy[i] = (hy < HH && hx < HW_) ? hy : -1000000;
+        xx_[i] = hx;
+        xc[i] = (u & 7) ^ ((P >> 1) & 7);
+    }
+    int dpy[4], dpx[4], dc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = (wv * 4 + i) * 64 + lane;
+        const int p = u >> 3;
+        dpy[i] = p >> 4;
+        dpx[i] = p & 15;
+        dc[i] = (u & 7) ^ ((p >> 1) & 7);
+    }
+    auto issue = [&](long t, int buf) {
+        const bool live = t < ntiles;
+        const int img = live ? (int)(t / tpi) : 0;
+        const int rem = live ? (int)(t - (long)img * tpi) : 0;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        unsigned v[8], q[4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int yy = ty * TH + xy[i] - 1, xx = tx * TW + xx_[i] - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = (unsigned)((((long)img * H + yy) * W + xx) * 128 + xc[i] * 16);
+            v[i] = (ok ? off : 0x80000000u) - 1024u * (i & 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned off = (unsigned)((((long)img * H + ty * TH + dpy[i]) * W + tx * TW + dpx[i]) * 128 + dc[i] * 16);
+            q[i] = (live ? off : 0x80000000u) - 1024u * i;
+        }
+        const unsigned xb = lds0 + buf * XBUF + wv * 8192;
+        c3_dma4(rx, xb, v[0], v[1], v[2], v[3]);
+        c3_dma4(rx, xb + 4096, v[4], v[5], v[6], v[7]);
+        c3_dma4(rd, lds0 + 2 * XBUF + buf * DBUF + wv * 4096, q[0], q[1], q[2], q[3]);
+    };
+
+    // fragment addresses (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns, 8 bytes per lane, and hands lane i column i)
+    const int g = lane >> 4, rlo = (lane & 15) >> 2, csub = (lane & 3) >> 1, bsub = 8 * (lane & 1);
+    unsigned da[4][2];                              // dY fragment of output-channel tile jt, half hf, at k step 0 (+ 4096 per k step)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int p = 8 * g + rlo + 4 * hf;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) da[jt][hf] = p * 128 + (((2 * jt + csub) ^ ((p >> 1) & 7)) << 4) + bsub;
+    }
+    unsigned xa[9][2];                              // X fragment (this wave's 16 input channels) of tap, half, at k step 0 (+ 6144 per k step)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int kk = 8 * g + rlo + 4 * hf;
+            const int P = ((kk >> 4) + tap / 3) * XW + (kk & 15) + tap % 3;
+            xa[tap][hf] = P * 128 + (((2 * wv + csub) ^ ((P >> 1) & 7)) << 4) + bsub;
+        }
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[tap][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    long t = blockIdx.x;
+    issue(t, 0);
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        c3_wait_vm<0>();                            // this wave's pieces of tile t (nothing else is in flight: no stores in the loop)
+        __builtin_amdgcn_s_barrier();               // everyone's pieces have landed; everyone is done with the other buffers
+        issue(t + gridDim.x, buf ^ 1);
+        const unsigned char* xi = smem + buf * XBUF;
+        const unsigned char* di = smem + 2 * XBUF + buf * DBUF;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            c3_s4 df[4][2], xf[9][2];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    df[jt][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(di + da[jt][hf] + ks * 4096));
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    xf[tap][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(xi + xa[tap][hf] + ks * (2 * XW * 128)));
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(&xf[tap][0]);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[tap][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&df[jt][0]), b, acc[tap][jt], 0, 0, 0);
+            }
+        }
+    }
+    c3_wait_vm<0>();
+    // partial of this workgroup: lane holds D[co = 16 jt + 4 (lane >> 4) + r][ci = 16 wv + (lane & 15)] of every tap
+    float* pp = part + (long)blockIdx.x * (64 * 576);
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[(16 * jt + 4 * fk + r) * 576 + tap * 64 + 16 * wv + fr] = acc[tap][jt][r];
+}
+
+// dW[n][k] += alpha * sum_s part[s][n][k]: blockIdx.y sums 16 partials and adds its share with one atomic per element
+__global__ __launch_bounds__(256) void conv3_wgrad_reduce(const float* __restrict__ part, int nparts, float alpha, float* __restrict__ dW,
+                                                          long ldw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // over 64 * 576
+    if (i >= 64 * 576) return;
+    const int s0 = blockIdx.y * 16, s1 = min(nparts, s0 + 16);
+    float a = 0.f;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) a += part[(long)s * (64 * 576) + i];
+    const int n = i / 576, k = i - n * 576;
+    atomicAdd(dW + (long)n * ldw + k, alpha * a);
+}
+
 }  // namespace
 
 // ga_gemm's GA_A_CONV3 product, plain epilogue, bf16, 64 input channels, N = 64, maps of 8 x 16 tiles: returns 1 if it took the launch
@@ -204,5 +368,34 @@ int ga_conv3_c64_try(const ga_gemm_desc* d, hipStream_t s) {
     const int grid = (int)std::min<long>(ntiles, cus);
     hipLaunchKernelGGL(conv3_c64_kernel, dim3(grid), dim3(256), LDS_TOTAL, s, (const bf16_t*)d->A, (const bf16_t*)d->B, (long)d->ldb,
                        (bf16_t*)d->C, (int)nimg, d->a_H, d->a_W, (unsigned)bytes);
+    return 1;
+}
+
+// ga_wgrad's GA_A_CONV3 product for the same layer (bf16, 64 -> 64 channels, accumulate into dW, no bias): workgroups / bytes of
+// partial sums it needs (0: does not apply)
+static int conv3_wgrad_wgs(const ga_wgrad_desc* d) {
+    if (!GA_KNOB("CONV3_DIRECT", 1)) return 0;
+    if (d->dtype != GA_BF16 || d->x_kind != GA_A_CONV3 || d->x_C != 64 || d->N != 64 || d->K != 576 || d->batch != 1 || d->dbias ||
+        d->x_act != GA_ACT_NONE || d->ldy != 64 || !d->accumulate)
+        return 0;
+    if (d->x_H % TH != 0 || d->x_W % TW != 0 || (long)d->M % ((long)d->x_H * d->x_W) != 0 || (long)d->M * 128 >= (1L << 31)) return 0;
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ntiles = (long)d->M / (TH * TW);
+    return (int)std::min<long>(ntiles, cus);
+}
+size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d) { return (size_t)conv3_wgrad_wgs(d) * 64 * 576 * sizeof(float); }
+
+int ga_conv3_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s) {
+    const int wgs = conv3_wgrad_wgs(d);
+    if (!wgs || !d->workspace || (size_t)d->ws_bytes < (size_t)wgs * 64 * 576 * sizeof(float)) return 0;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_c64_wgrad_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) == hipSuccess;
+    if (!attr_ok) return 0;
+    const long hw = (long)d->x_H * d->x_W;
+    float* part = reinterpret_cast<float*>(d->workspace);
+    hipLaunchKernelGGL(conv3_c64_wgrad_kernel, dim3(wgs), dim3(256), WG_LDS, s, (const bf16_t*)d->Y, (const bf16_t*)d->X, part,
+                       (int)(d->M / hw), d->x_H, d->x_W, (unsigned)((long)d->M * 128));
+    hipLaunchKernelGGL(conv3_wgrad_reduce, dim3(cdiv(64 * 576, 256), cdiv(wgs, 16)), dim3(256), 0, s, part, wgs, d->alpha, d->dW, (long)d->ldw);
     return 1;
 }

@@ -2301,6 +2301,7 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
         GA_REQUIRE(false, "ga_wgrad: bad x_kind %d", d->x_kind);
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (d->x_kind == GA_A_CONV3 && ga_conv3_c64_wgrad_try(d, s)) return ga_check_launch("ga_wgrad");   // 64 -> 64 channels: direct form
     if (tn2_eligible(d)) {
         static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kTn2Smem) == hipSuccess;
@@ -2328,7 +2329,9 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
 }
 
 extern "C" size_t ga_wgrad_workspace(const ga_wgrad_desc* d) {
-    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1 || !tn2_eligible(d)) return 0;
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return 0;
+    if (d->x_kind == GA_A_CONV3) return ga_conv3_c64_wgrad_workspace(d);
+    if (!tn2_eligible(d)) return 0;
     int split;
     return tn2_plan(d, &split);
 }

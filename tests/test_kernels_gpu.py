@@ -207,6 +207,14 @@ def test_gemm_conv3_direct_form_64_channels(geom, knobs):
         torch.cuda.synchronize()
         assert_close(Cout, y.permute(0, 2, 3, 1).reshape(M, N), tol(dt), f'conv3 fwd (direct={form})')
         assert_close(DX, xx.grad.permute(0, 2, 3, 1).reshape(M, Cc), tol(dt), f'conv3 dgrad (direct={form})')
+        # weight gradient of the same layer (ga_wgrad's GA_A_CONV3 product: conv3_c64_wgrad_kernel when direct): accumulated into dW
+        dW = torch.full((N, 9 * Cc), 0.5, device='cuda')
+        P.wgrad(DY, X, dW, M, N, 9 * Cc, ops.ga_dtype(dt), x_kind=ops.A_CONV3, x_dims=(H, W, Cc))
+        torch.cuda.synchronize()
+        wg = F.conv2d(x.permute(0, 3, 1, 2), torch.zeros(N, Cc, 3, 3, requires_grad=True), padding=1)
+        ww = torch.zeros(N, Cc, 3, 3, requires_grad=True)
+        F.conv2d(x.permute(0, 3, 1, 2), ww, padding=1).backward(dy.reshape(Bn, H, W, N).permute(0, 3, 1, 2))
+        assert_close(dW, 0.5 + ww.grad.permute(0, 2, 3, 1).reshape(N, 9 * Cc), tol(dt, 2), f'conv3 wgrad (direct={form})')
         outs[form] = (Cout.float(), DX.float())
     assert float((outs[1][0] - outs[0][0]).abs().max()) <= 2e-2 * float(outs[0][0].abs().max())
 

@@ -4,6 +4,7 @@ mkdir -p gpurun_out/r03
 timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "conv3" > gpurun_out/r03/t_c3.log 2>&1 || { tail -40 gpurun_out/r03/t_c3.log; exit 1; }
 tail -2 gpurun_out/r03/t_c3.log
 timeout -k 10 120 python tools/r03/c3_bench.py || exit 1
+timeout -k 10 120 python tools/r03/c3w_bench.py || exit 1
 timeout -k 10 900 python -m pytest tests/test_cswin_model_gpu.py -m gpu -x -q > gpurun_out/r03/t_cs.log 2>&1 || { tail -40 gpurun_out/r03/t_cs.log; exit 1; }
 tail -2 gpurun_out/r03/t_cs.log
 B="--no-cpu-baseline --no-measured-peaks --no-kernel-times --model ga_CSWin_64_12211_tiny_224"
