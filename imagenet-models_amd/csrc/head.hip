@@ -392,6 +392,49 @@ __global__ __launch_bounds__(1024) void gram_pack_bwd_kernel(const T* __restrict
     }
 }
 
+// The same backward with the sample's packed gradient staged in LDS (bf16, C (C + 1) / 2 entries <= 75 K): the gather of the
+// form above reads dvec and vhat element-wise from memory for every one of the C x C outputs -- the lower triangle column-wise,
+// the token interleave strided -- and pays three runtime integer divisions per output (0.22-0.34 ms per launch at C = 384, 13x
+// its bytes).  Here pass 2 computes draw once per packed entry with coalesced reads into LDS [t], and pass 3 fills the C x C
+// matrix from LDS with coalesced stores; bf16(2 x) = 2 bf16(x), so the results are bit-identical.
+template <int NTOK>
+__global__ __launch_bounds__(1024) void gram_pack_bwd_lds_kernel(const bf16_t* __restrict__ dvec, const bf16_t* __restrict__ vhat,
+                                                                 const float* __restrict__ inv_norm, bf16_t* __restrict__ S, int C,
+                                                                 int groups, int Kg, int Kp, int ntok_rt, int per_tok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    bf16_t* packed = reinterpret_cast<bf16_t*>(smem_g);
+    __shared__ float red[16];
+    const int ntok = NTOK > 0 ? NTOK : ntok_rt;
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bf16_t* db = dvec + b * groups * Kp;
+    const bf16_t* vb = vhat + b * groups * Kp;
+    float dot = 0.f;
+    for (int g = 0; g < groups; ++g)
+        for (int k = threadIdx.x; k < Kg; k += 1024) dot = fmaf(bf2f(db[g * Kp + k]), bf2f(vb[g * Kp + k]), dot);
+    dot = wave_sum(dot);
+    if (lane == 0) red[wave] = dot;
+    __syncthreads();
+    dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) dot += red[w];
+    const float inv = inv_norm[b];
+    for (int g = 0; g < groups; ++g)
+        for (int k = threadIdx.x; k < Kg; k += 1024)
+            packed[g * Kg + k] = f2bf(inv * (bf2f(db[g * Kp + k]) - bf2f(vb[g * Kp + k]) * dot));
+    __syncthreads();
+    bf16_t* Sb = S + b * C * C;
+    for (int i = wave; i < C; i += 16) {                 // output row i: entries (i, j) read packed (min, max)
+        for (int j = lane; j < C; j += 64) {
+            const int lo = min(i, j), hi = max(i, j);
+            unsigned t = (unsigned)(lo * C - lo * (lo - 1) / 2 + (hi - lo));
+            if (ntok > 1) t = (t % (unsigned)ntok) * (unsigned)per_tok + t / (unsigned)ntok;
+            const bf16_t v = packed[t];
+            Sb[i * C + j] = i == j ? f2bf(2.f * bf2f(v)) : v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // token concat / split for the class-attention input u = cat(x_cls, tokens)
 // ------------------------------------------------------------------------------------------------
@@ -828,6 +871,24 @@ extern "C" int ga_gram_pack_bwd2(const void* dvec, const void* vhat, const float
     const int ntri = C * (C + 1) / 2;
     GA_REQUIRE(dvec && vhat && inv_norm && S && ntri % groups == 0 && ntok >= 1 && ntri % ntok == 0, "ga_gram_pack_bwd: bad args");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)ntri * 2;
+    if (dtype == GA_BF16 && lds <= 150 * 1024 && GA_KNOB("GRAM_LDS", 1)) {      // every packed entry of a sample fits in LDS
+#define GA_GPB(NT)                                                                                                              \
+    do {                                                                                                                        \
+        auto k = gram_pack_bwd_lds_kernel<NT>;                                                                                  \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   150 * 1024) == hipSuccess;                                                   \
+        GA_REQUIRE(ok, "ga_gram_pack_bwd: cannot reserve LDS");                                                                 \
+        hipLaunchKernelGGL(k, dim3(B), dim3(1024), lds, s, (const bf16_t*)dvec, (const bf16_t*)vhat, inv_norm, (bf16_t*)S, C,   \
+                           groups, ntri / groups, Kp, ntok, ntri / ntok);                                                       \
+    } while (0)
+        if (ntok == 1) GA_GPB(1);
+        else if (ntok == 2) GA_GPB(2);
+        else if (ntok == 3) GA_GPB(3);
+        else GA_GPB(0);
+#undef GA_GPB
+        return ga_check_launch("ga_gram_pack_bwd");
+    }
     DISPATCH_T(dtype, gram_pack_bwd_kernel, dim3(B), dim3(1024), 0, s, (const T*)dvec, (const T*)vhat, inv_norm, (T*)S, C,
                groups, ntri / groups, Kp, ntok, ntri / ntok);
     return ga_check_launch("ga_gram_pack_bwd");
