@@ -1055,7 +1055,9 @@ extern "C" int ga_cswin_lepe_wgrad_reduce(const ga_cswin_attn_desc* d, const voi
     GA_REQUIRE(lepe_ws && dw0 && db0 && (d->nbranch == 1 || (dw1 && db1)), "ga_cswin_lepe_wgrad_reduce: null pointer");
     GA_REQUIRE(use_mfma(d), "ga_cswin_lepe_wgrad_reduce: this shape has no fused partials (ga_cswin_attn_bwd_workspace() == 0)");
     const int T = d->B * (d->reso / d->Hs[0]) * (d->reso / d->Ws[0]);
-    const int splits = std::max(1, std::min(64, T / 256));
+    // a thread sums T / splits / 4 partials one load after the other (latency-bound): 16-32 loads per thread (T / 256 splits: 21 us
+    // per launch for 5 MB of partials, 26 launches per step on the dgrad chain)
+    const int splits = std::max(1, std::min(64, T / 32));
     hipLaunchKernelGGL(lepe_wgrad_reduce_kernel, dim3(d->heads, 5, splits), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const float*>(lepe_ws), T, d->heads, d->heads / d->nbranch, dw0, db0, dw1, db1);
     return ga_check_launch("ga_cswin_lepe_wgrad_reduce");

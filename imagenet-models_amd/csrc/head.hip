@@ -358,6 +358,48 @@ __global__ __launch_bounds__(1024) void gram_pack_kernel(const float* __restrict
     }
 }
 
+// The same pack with the sample's packed vector staged in LDS (bf16, C (C + 1) / 2 entries <= 75 K): the form above pays three
+// runtime integer divisions per entry for the token interleave and the group layout and scatters 2-byte stores; here the scaled
+// upper triangle goes to LDS at its (interleaved) packed position, then [groups][Kp] is written group by group, coalesced.
+template <int NTOK>
+__global__ __launch_bounds__(1024) void gram_pack_lds_kernel(const float* __restrict__ G, bf16_t* __restrict__ out,
+                                                             float* __restrict__ inv_norm, int C, int groups, int Kg, int Kp,
+                                                             int ntok_rt, int per_tok) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_g[];
+    bf16_t* packed = reinterpret_cast<bf16_t*>(smem_g);
+    __shared__ float red[16];
+    const int ntok = NTOK > 0 ? NTOK : ntok_rt;
+    const long b = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float* Gb = G + b * C * C;
+    float ss = 0.f;
+    for (int i = wave; i < C; i += 16)
+        for (int j = i + lane; j < C; j += 64) {
+            const float v = Gb[i * C + j];
+            ss = fmaf(v, v, ss);
+        }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tot += red[w];
+    const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
+    if (threadIdx.x == 0) inv_norm[b] = inv;
+    for (int i = wave; i < C; i += 16) {
+        const unsigned t0 = (unsigned)(i * C - i * (i - 1) / 2);        // packed index of (i, i)
+        for (int j = i + lane; j < C; j += 64) {
+            unsigned t = t0 + (unsigned)(j - i);
+            if (ntok > 1) t = (t % (unsigned)ntok) * (unsigned)per_tok + t / (unsigned)ntok;
+            packed[t] = f2bf(Gb[i * C + j] * inv);
+        }
+    }
+    __syncthreads();
+    bf16_t* ob = out + b * groups * Kp;
+    for (int g = 0; g < groups; ++g)
+        for (int k = threadIdx.x; k < Kp; k += 1024) ob[g * Kp + k] = k < Kg ? packed[g * Kg + k] : (bf16_t)0;
+}
+
 // backward of normalise + pack: S[b][i][j] (T, symmetric; diagonal doubled) = d(raw gram entry)
 //   draw = inv * (dvec - vhat * <vhat, dvec>)
 template <typename T>
@@ -861,6 +903,24 @@ extern "C" int ga_gram_pack_fwd2(const float* G, void* out, float* inv_norm, int
     GA_REQUIRE(G && out && inv_norm && ntri % groups == 0 && Kp >= ntri / groups && ntok >= 1 && ntri % ntok == 0,
                "ga_gram_pack_fwd: bad args (C=%d groups=%d Kp=%d ntok=%d)", C, groups, Kp, ntok);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)ntri * 2;
+    if (dtype == GA_BF16 && lds <= 150 * 1024 && GA_KNOB("GRAM_LDS", 1)) {
+#define GA_GPF(NT)                                                                                                              \
+    do {                                                                                                                        \
+        auto k = gram_pack_lds_kernel<NT>;                                                                                      \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                   150 * 1024) == hipSuccess;                                                   \
+        GA_REQUIRE(ok, "ga_gram_pack_fwd: cannot reserve LDS");                                                                 \
+        hipLaunchKernelGGL(k, dim3(B), dim3(1024), lds, s, G, (bf16_t*)out, inv_norm, C, groups, ntri / groups, Kp, ntok,       \
+                           ntri / ntok);                                                                                        \
+    } while (0)
+        if (ntok == 1) GA_GPF(1);
+        else if (ntok == 2) GA_GPF(2);
+        else if (ntok == 3) GA_GPF(3);
+        else GA_GPF(0);
+#undef GA_GPF
+        return ga_check_launch("ga_gram_pack_fwd");
+    }
     DISPATCH_T(dtype, gram_pack_kernel, dim3(B), dim3(1024), 0, s, G, (T*)out, inv_norm, C, groups, ntri / groups, Kp, ntok,
                ntri / ntok);
     return ga_check_launch("ga_gram_pack_fwd");
