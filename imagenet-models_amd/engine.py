@@ -334,13 +334,34 @@ class GAEngine:
         # k | v | q weights like the ConvNeXt block's LayerNorm into fc1).  One LayerNorm over the tokens instead of five
         # over the concatenation, no concatenated copy, one backward LayerNorm over the summed gradient.
         E_, nh_ = cfg['dim_embed'], cfg['num_heads']
-        self.shared_tok = E_ % nh_ == 0 and (E_ // nh_) % 8 == 0 and E_ <= 512   # what ga_class_attn_*2 supports
+        # ga_class_attn_*2 wants head widths that are multiples of 8 and E <= 512.  Odd head widths (688 / 976 variants:
+        # dim_embed 168 / 240 = 8 heads of 21 / 30) run hd_p = pad8(hd) wide on zero-padded COPIES of the q / k / v rows and the
+        # proj columns (the Bottleneck's scheme, _bott_pad): the extra channels of q, k, v and of the attention output are exact
+        # zeros, so are their gradients; the real part of each padded weight gradient is copied back after the backward pass.
+        hd_ = E_ // max(nh_, 1)
+        self.hd_p = pad8(hd_)
+        self.Ea = nh_ * self.hd_p
+        self.shared_tok = E_ % nh_ == 0 and self.Ea <= 512
+        self.attn_pad = {}
+        if self.shared_tok and self.Ea != E_:
+            for k in range(K):
+                pre = f'ga.{k}.attn.'
+                pk, pv = self.P[pre + 'k.weight'], self.P[pre + 'v.weight']
+                assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
+                # (name, padded shape, rows, cols, source row pitch, padded row pitch)
+                spec = (('k.weight', (2 * self.Ea, cout), 2 * nh_, hd_ * cout, hd_ * cout, self.hd_p * cout),
+                        ('q.weight', (self.Ea, cout), nh_, hd_ * cout, hd_ * cout, self.hd_p * cout),
+                        ('proj.weight', (cout, self.Ea), cout * nh_, hd_, hd_, self.hd_p))
+                for name, shape, rows, cols, lds, ldd in spec:
+                    buf = self.buf('pad.' + pre + name, shape, torch.float32, zero=True)
+                    self.prep.pad_copy_f32(self.P[pre + name], buf, rows, cols, lds, ldd, label='prep.pad.' + pre + name)
+                    self.attn_pad[pre + name] = (buf, rows, cols, lds, ldd)
         if self.shared_tok:
             self.tok = dict(xn=self.act('ga.tok.xn', (M4, cout)), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
             F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, cout, 1e-5, dt, label='ga.tok.ln')
             # the k | v rows of the image tokens of ALL heads from one GEMM over the shared tokens: the heads' effective
             # (norm1-folded) k|v weights are stacked along N; head k reads / writes the column slice [k*2E, (k+1)*2E)
-            E2 = 2 * E_
+            E2 = 2 * self.Ea
             tk = self.tok
             tk['E2'], tk['ld'] = E2, K * E2
             tk['W'] = self.buf('w.ga.kv_all', (K * E2, cout))
@@ -351,6 +372,7 @@ class GAEngine:
                 pre = f'ga.{k}.'
                 pk, pv = P[pre + 'attn.k.weight'], P[pre + 'attn.v.weight']
                 assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
+                pk = self._attn_w(pre + 'attn.k.weight')
                 self.prep.weight_prep(pk, 1, E2, cout, 1, 1, dt, out=tk['W'][k * E2:], ldo=cout,
                                       outT=tk['WT'][:, k * E2:] if T else None, ldt=K * E2 if T else 0,
                                       cs=P[pre + 'norm1.weight'], t_cols=E2, label='prep.' + pre + 'kv')
@@ -378,6 +400,24 @@ class GAEngine:
         F.lane, self.tmp_prefix = 0, ''
         F.gemm(fa['x'], fa['W'], self.logits, B, NC, cout, dt, batch=K, strideA=B * cout, strideB=NC * cout, strideC=B * NC,
                bias=fa['b'], strideBias=NC, c_f32=True, label='fc.all')
+
+    def _attn_w(self, name):
+        """master copy of a class-attention weight: the zero-padded one where the head width is padded"""
+        return self.attn_pad[name][0] if name in self.attn_pad else self.P[name]
+
+    def _attn_g(self, name):
+        """gradient buffer of a class-attention weight (padded: a zeroed arena buffer, copied back by _attn_unpad)"""
+        if name not in self.attn_pad:
+            return self.grad(name)
+        if name not in self.attn_gpad:
+            self.attn_gpad[name] = self.gbuf(tuple(self.attn_pad[name][0].shape))
+        return self.attn_gpad[name]
+
+    def _attn_unpad(self):
+        """real part of every padded class-attention weight gradient back into the parameter's gradient; call AFTER the flush of
+        the heads' deferred weight-unfold jobs (they write the padded gradients) and before the 'heads' mark"""
+        for name, (_, rows, cols, lds, ldd) in self.attn_pad.items():
+            self.bwd.pad_copy_f32(self.attn_gpad[name], self.grad(name), rows, cols, ldd, lds, accumulate=True, label=name + '.unpad')
 
     def _contract_all_fwd(self, x4, M4):
         cfg, T, F, dt, cout = self.cfg, self.training, self.fwd, self.dt, self.cout
@@ -939,6 +979,9 @@ class GAEngine:
         groups = cfg['gram_groups']
         HW = Hc * Hc
         hd = E // nh
+        h['scale'] = hd ** -0.5
+        if self.shared_tok:       # padded head width (== the real one for the *_768 / *_1024 variants)
+            E, hd = self.Ea, self.hd_p
         g1 = h['g1']
         # --- Gram vector (fp32 accumulate; the reference's fp64 branch for train & B<128 is covered by the 1e-3 gate)
         alpha = 1.0 / (Hc * Hc * HW)
@@ -987,7 +1030,6 @@ class GAEngine:
         assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
         h['ao'] = self.act(pre + 'ao', (B, E))
         h['P'] = self.act(pre + 'P', (B, nh, N + 1), torch.float32)
-        h['scale'] = hd ** -0.5
         if self.shared_tok:
             # class-token row normalised on its own; norm1's affine part folded into the k | v and q operands
             g1, b1 = P[pre + 'norm1.weight'], P[pre + 'norm1.bias']
@@ -999,9 +1041,9 @@ class GAEngine:
             h['kvt'] = tk['kv'][:, k * E2:]                       # column slice, row stride tk['ld']
             h['kvc'] = self.act(pre + 'kvc', (B, E2))
             F.gemm(h['cn'], tk['W'][k * E2:], h['kvc'], B, E2, cout, dt, bias=tk['b'][k * E2:], label=pre + 'kvc')
-            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1)
+            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1, src=self._attn_w(pre + 'attn.q.weight'))
             bq = self.buf('w.' + pre + 'bq', (E,), torch.float32)
-            self.prep.bias_fold(P[pre + 'attn.q.weight'], None, None, b1, bq, E, cout)
+            self.prep.bias_fold(self._attn_w(pre + 'attn.q.weight'), None, None, b1, bq, E, cout)
             h['q'] = self.act(pre + 'q', (B, E))
             F.gemm(h['cn'], Wq, h['q'], B, E, cout, dt, bias=bq, label=pre + 'q')
             F.class_attn_fwd2(h['q'], h['kvc'], h['kvt'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, tok_ld=tk['ld'],
@@ -1027,7 +1069,7 @@ class GAEngine:
             h['q'] = self.act(pre + 'q', (B, E))
             F.gemm(h['un'], Wq, h['q'], B, E, cout, dt, lda=(N + 1) * cout, label=pre + 'q')
             F.class_attn_fwd(h['q'], h['kv'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
-        Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'])
+        Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'], src=self._attn_w(pre + 'attn.proj.weight'))
         bpr = self.buf('w.' + pre + 'bproj', (cout,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'attn.proj.bias'], P[pre + 'gamma_1'], None, bpr, cout, E)
         dp = self.dp_scale.get(pre)
@@ -1052,6 +1094,8 @@ class GAEngine:
         HW = M4 // B
         N = HW
         hd = E // nh
+        if self.shared_tok:
+            E, hd = self.Ea, self.hd_p
         pre = f'ga.{k}.'
         dp = self.dp_scale.get(pre)
         # classifier: done for all heads at once in _build_backward
@@ -1072,8 +1116,8 @@ class GAEngine:
         # attention projection
         Gp, gbp = self.gbuf((cout, E)), self.gbuf((cout,))
         Bk.wgrad(dpz, h['ao'], Gp, B, cout, E, dt, dbias=gbp, label=pre + 'proj.wg')
-        Bk.weight_unfold(Gp, E, cout, E, gb=gbp, W=P[pre + 'attn.proj.weight'], b=P[pre + 'attn.proj.bias'],
-                         rs=P[pre + 'gamma_1'], dW=self.grad(pre + 'attn.proj.weight'), db=self.grad(pre + 'attn.proj.bias'),
+        Bk.weight_unfold(Gp, E, cout, E, gb=gbp, W=self._attn_w(pre + 'attn.proj.weight'), b=P[pre + 'attn.proj.bias'],
+                         rs=P[pre + 'gamma_1'], dW=self._attn_g(pre + 'attn.proj.weight'), db=self.grad(pre + 'attn.proj.bias'),
                          d_rs=self.grad(pre + 'gamma_1'), label=pre + 'proj.unf')
         dao = self.tmp('dao', (B, E))
         Bk.gemm(dpz, W[pre + 'attn.proj.weight.T'], dao, B, E, cout, dt, ldb=pad8(cout), label=pre + 'proj.dg')
@@ -1094,8 +1138,8 @@ class GAEngine:
             Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], B, E2, cout, dt, dbias=tk['gb'][k * E2:], label=pre + 'kvc.wg')
             Gq, gbq = self.gbuf((E, cout)), self.gbuf((E,))
             Bk.wgrad(dq, h['cn'], Gq, B, E, cout, dt, dbias=gbq, label=pre + 'q.wg')
-            Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=P[pre + 'attn.q.weight'], cs=g1, v=b1,
-                             dW=self.grad(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
+            Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=self._attn_w(pre + 'attn.q.weight'), cs=g1, v=b1,
+                             dW=self._attn_g(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
             # gradient wrt the normalised class-token row (the image-token rows: one GEMM over all heads after the loop)
             dcn = self.tmp('dcn', (B, cout))
             Bk.gemm(dkvc, tk['WT'][:, k * E2:], dcn, B, cout, E2, dt, ldb=tk['ld'], label=pre + 'kvc.dg')
@@ -1156,6 +1200,7 @@ class GAEngine:
         cout = self.cout
         K, NC = cfg['branches'], cfg['num_classes']
         self.dlogits = self.buf('dlogits', (K, B, NC))
+        self.attn_gpad = {}
         Bk.zero(self.arena, label='zero.arena')
         dx4 = self.tmp('dx4', (M4, cout))
         # classifiers of the five heads: one batched wgrad and one batched dgrad
@@ -1188,9 +1233,10 @@ class GAEngine:
                 Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], cout, dt, dbias=tk['gb'], label='ga.kv_all.wg')
             for k in range(K):
                 pre = f'ga.{k}.'
-                Bk.weight_unfold(tk['G'][k * E2:], cout, E2, cout, gb=tk['gb'][k * E2:], W=P[pre + 'attn.k.weight'],
-                                 cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self.grad(pre + 'attn.k.weight'),
+                Bk.weight_unfold(tk['G'][k * E2:], cout, E2, cout, gb=tk['gb'][k * E2:], W=self._attn_w(pre + 'attn.k.weight'),
+                                 cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self._attn_g(pre + 'attn.k.weight'),
                                  d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'kv.unf')
+
             # ... and dx4 += LayerNorm'(gradient wrt the shared normalised tokens, summed over the heads by the K = 5*2E GEMM)
             dxt = self.tmp('dxn_tok', (M4, cout))
             Bk.gemm(tk['dkv'], tk['WT'], dxt, M4, cout, tk['ld'], dt, label='ga.kv_all.dg')
@@ -1223,6 +1269,7 @@ class GAEngine:
         if self.async_wgrad:
             Bk.join_async()
         Bk.flush('heads.')
+        self._attn_unpad()
         Bk.mark('heads')      # every gradient of stages.4 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
         seeds = []
