@@ -201,6 +201,18 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(const T* __restrict__ src
     }
 }
 
+// two-level group padding of an fp32 matrix: rows in groups of RG -> RGp, columns in groups of CG -> CGp (zero-initialised padded side)
+__global__ __launch_bounds__(256) void pad_groups_kernel(const float* __restrict__ src, float* __restrict__ dst, long R, long C, int RG,
+                                                         int RGp, int CG, int CGp, int unpad, int accumulate) {
+    const long n = R * C, Cp = C / CG * CGp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / C, c = i - r * C;
+        const long ip = (r / RG * RGp + r % RG) * Cp + c / CG * CGp + c % CG;
+        if (unpad) dst[i] = accumulate ? dst[i] + src[ip] : src[ip];
+        else dst[ip] = accumulate ? dst[ip] + src[i] : src[i];
+    }
+}
+
 int check_desc(const ga_small_linear_desc* d, const char* what) {
     GA_REQUIRE(d && d->A && d->W && d->rows > 0 && d->groups > 0 && d->Ng > 0 && d->Kg > 0, "%s: null / empty descriptor", what);
     GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "%s: bad dtype", what);
@@ -289,6 +301,17 @@ extern "C" int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t col
         hipLaunchKernelGGL(pad_copy_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(src),
                            reinterpret_cast<float*>(dst), (long)rows, (long)cols, (long)lds, (long)ldd, accumulate);
     return ga_check_launch("ga_pad_copy");
+}
+
+extern "C" int ga_pad_groups_f32(const float* src, float* dst, int64_t R, int64_t C, int RG, int RGp, int CG, int CGp, int unpad,
+                                 int accumulate, ga_stream_t stream) {
+    GA_REQUIRE(src && dst && R > 0 && C > 0 && RG > 0 && CG > 0 && RGp >= RG && CGp >= CG && R % RG == 0 && C % CG == 0,
+               "ga_pad_groups_f32: bad args (R=%ld C=%ld RG=%d->%d CG=%d->%d)", (long)R, (long)C, RG, RGp, CG, CGp);
+    const long n = R * C;
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + 255) / 256));
+    hipLaunchKernelGGL(pad_groups_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, (long)R, (long)C,
+                       RG, RGp, CG, CGp, unpad, accumulate);
+    return ga_check_launch("ga_pad_groups_f32");
 }
 
 extern "C" int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate,

@@ -102,7 +102,7 @@ class GAEngine:
         self.arena = None
         self.arena_off = 0
         if training:
-            self.arena = torch.zeros(int(flat['total'] * 1.15) + (1 << 20), device=self.dev)
+            self.arena = torch.zeros(int(flat['total'] * 1.15) + (1 << 20) + self._arena_extra(), device=self.dev)
         self._nbt = [t for n, t in self.Bf.items() if n.endswith('num_batches_tracked')]
         self.prep = Plan(name='prep', defer_small=True)
         self.fwd = Plan(name='fwd')
@@ -111,7 +111,11 @@ class GAEngine:
         self.bn_pool = torch.zeros(1 << 16, device=self.dev)
         self.bn_pool_off = 0
         self.bott_prefix = 'stages.4.'   # the SE-Bottleneck's parameter prefix (GA-CSWin with stage5='bottleneck': 'stage5.')
+        # zero-padded copies of parameters of the odd-width variants: name -> (padded buffer, how to copy); gradients: name -> arena buffer
+        self.ppad, self.pgrad = {}, {}
+        self.pad_gmlp = os.environ.get('GAEXT_PAD_GMLP', '1') != '0'    # odd-width grouped one-token layers on padded MFMA layouts
         self._build()
+        assert not self.pgrad or getattr(self, '_unpadded', False), 'padded parameter gradients were never copied back'
 
     # ------------------------------------------------------------------------------------------
     # buffers
@@ -342,7 +346,6 @@ class GAEngine:
         self.hd_p = pad8(hd_)
         self.Ea = nh_ * self.hd_p
         self.shared_tok = E_ % nh_ == 0 and self.Ea <= 512
-        self.attn_pad = {}
         if self.shared_tok and self.Ea != E_:
             for k in range(K):
                 pre = f'ga.{k}.attn.'
@@ -355,7 +358,7 @@ class GAEngine:
                 for name, shape, rows, cols, lds, ldd in spec:
                     buf = self.buf('pad.' + pre + name, shape, torch.float32, zero=True)
                     self.prep.pad_copy_f32(self.P[pre + name], buf, rows, cols, lds, ldd, label='prep.pad.' + pre + name)
-                    self.attn_pad[pre + name] = (buf, rows, cols, lds, ldd)
+                    self.ppad[pre + name] = (buf, 'copy', (rows, cols, lds, ldd))
         if self.shared_tok:
             self.tok = dict(xn=self.act('ga.tok.xn', (M4, cout)), rstd=self.act('ga.tok.rstd', (M4,), torch.float32))
             F.layernorm_fwd(x4, None, None, self.tok['xn'], None, self.tok['rstd'], M4, cout, 1e-5, dt, label='ga.tok.ln')
@@ -372,7 +375,7 @@ class GAEngine:
                 pre = f'ga.{k}.'
                 pk, pv = P[pre + 'attn.k.weight'], P[pre + 'attn.v.weight']
                 assert pv.data_ptr() == pk.data_ptr() + pk.numel() * 4, 'k/v weights must be adjacent in the flat buffer'
-                pk = self._attn_w(pre + 'attn.k.weight')
+                pk = self._pw(pre + 'attn.k.weight')
                 self.prep.weight_prep(pk, 1, E2, cout, 1, 1, dt, out=tk['W'][k * E2:], ldo=cout,
                                       outT=tk['WT'][:, k * E2:] if T else None, ldt=K * E2 if T else 0,
                                       cs=P[pre + 'norm1.weight'], t_cols=E2, label='prep.' + pre + 'kv')
@@ -401,23 +404,49 @@ class GAEngine:
         F.gemm(fa['x'], fa['W'], self.logits, B, NC, cout, dt, batch=K, strideA=B * cout, strideB=NC * cout, strideC=B * NC,
                bias=fa['b'], strideBias=NC, c_f32=True, label='fc.all')
 
-    def _attn_w(self, name):
-        """master copy of a class-attention weight: the zero-padded one where the head width is padded"""
-        return self.attn_pad[name][0] if name in self.attn_pad else self.P[name]
+    def _arena_extra(self):
+        """floats of gradient scratch beyond 1.15 x the parameters: the padded gradient copies of the odd-width variants"""
+        cfg = self.cfg
+        d = cfg.get('dims')
+        if not d or len(d) < 5 or any(k not in cfg for k in ('gram_dim', 'gram_groups', 'mlp_groups', 'dim_embed', 'num_heads', 'branches')):
+            return 0
+        cout, g, groups = d[4], cfg['gram_dim'], cfg['gram_groups']
+        if cout % (8 * groups) == 0 and cout % (8 * cfg['mlp_groups']) == 0 and (cfg['dim_embed'] // max(cfg['num_heads'], 1)) % 8 == 0:
+            return 0
+        cp = cout + 8 * max(groups, cfg['mlp_groups'])
+        return cfg['branches'] * (cp * (g * (g + 1) // 2 // groups + 8) + 8 * cp * cp // cfg['mlp_groups'] + 4 * cp * 512) + (1 << 20)
 
-    def _attn_g(self, name):
-        """gradient buffer of a class-attention weight (padded: a zeroed arena buffer, copied back by _attn_unpad)"""
-        if name not in self.attn_pad:
+    def _pw(self, name):
+        """master copy of a parameter: the zero-padded one where the layer runs on a padded layout"""
+        return self.ppad[name][0] if name in self.ppad else self.P[name]
+
+    def _pg(self, name):
+        """gradient buffer of a parameter (padded: a zeroed arena buffer, copied back by _unpad_all)"""
+        if name not in self.ppad:
             return self.grad(name)
-        if name not in self.attn_gpad:
-            self.attn_gpad[name] = self.gbuf(tuple(self.attn_pad[name][0].shape))
-        return self.attn_gpad[name]
+        if name not in self.pgrad:
+            self.pgrad[name] = self.gbuf(tuple(self.ppad[name][0].shape))
+        return self.pgrad[name]
 
-    def _attn_unpad(self):
-        """real part of every padded class-attention weight gradient back into the parameter's gradient; call AFTER the flush of
-        the heads' deferred weight-unfold jobs (they write the padded gradients) and before the 'heads' mark"""
-        for name, (_, rows, cols, lds, ldd) in self.attn_pad.items():
-            self.bwd.pad_copy_f32(self.attn_gpad[name], self.grad(name), rows, cols, ldd, lds, accumulate=True, label=name + '.unpad')
+    def _pad_groups(self, name, R, Cdim, RG, RGp, CG, CGp):
+        """register (once) the two-level group-padded copy of parameter `name` ([R][C] -> [R/RG*RGp][C/CG*CGp], ga_pad_groups_f32)"""
+        if name not in self.ppad:
+            buf = self.buf('pad.' + name, (R // RG * RGp, Cdim // CG * CGp), torch.float32, zero=True)
+            self.prep.pad_groups_f32(self.P[name], buf, R, Cdim, RG, RGp, CG, CGp, label='prep.pad.' + name)
+            self.ppad[name] = (buf, 'groups', (R, Cdim, RG, RGp, CG, CGp))
+        return self.ppad[name][0]
+
+    def _unpad_all(self):
+        """real part of every padded parameter gradient back into the parameter's gradient; call AFTER the flush of the heads'
+        deferred weight-unfold jobs (they write the padded gradients) and before the 'heads' mark"""
+        self._unpadded = True
+        for name, g in self.pgrad.items():
+            _, kind, a = self.ppad[name]
+            if kind == 'copy':
+                rows, cols, lds, ldd = a
+                self.bwd.pad_copy_f32(g, self.grad(name), rows, cols, ldd, lds, accumulate=True, label=name + '.unpad')
+            else:
+                self.bwd.pad_groups_f32(g, self.grad(name), *a, unpad=True, accumulate=True, label=name + '.unpad')
 
     def _contract_all_fwd(self, x4, M4):
         cfg, T, F, dt, cout = self.cfg, self.training, self.fwd, self.dt, self.cout
@@ -832,15 +861,41 @@ class GAEngine:
         """out = R + rowscale * gamma * fc2(shuffle(drop(act(fc1(t)))));  pre = '<block>.mlp.';  act 'gelu' (GA) or 'relu'
         (MAP, map.py:467) with an optional dropout mask [rows, 4C] on the hidden layer (in the SHUFFLED channel order)"""
         F, dt, P, T = self.fwd, self.dt, self.P, self.training
-        gamma = P[gamma_name] if gamma_name else None
+        gamma = self._pw(gamma_name) if gamma_name else None
         Hd = 4 * C
         gc_ = Hd // mg
         Nv = gc_ // mg          # rows per virtual group (fc1 input group is constant inside one)
         cin = C // mg
         n_idx = torch.arange(Hd)
         perm = ((n_idx % gc_) * mg + n_idx // gc_).to(torch.int32).to(self.dev)
+        if (Nv % 8 or cin % 8) and self.pad_gmlp and C % mg == 0:
+            # odd widths (688 / 4 = 172 channels per group) on the MFMA kernels: the layer runs as a GroupConvMlp of mg groups of
+            # cin_p = pad8(cin) channels on zero-padded copies of its five parameters (fc1 rows in groups of 4 cin -> 4 cin_p and
+            # columns cin -> cin_p; fc2 rows and columns in groups of cin -> cin_p; ga_pad_groups_f32) and group-padded copies of
+            # its input / residual; padded hidden and output channels are exact zeros (zero weights, zero biases), the real part
+            # of the output is compacted back and the real part of every padded gradient copied back after the backward pass
+            cin_p = pad8(cin)
+            Cp = mg * cin_p
+            self._pad_groups(pre + 'fc1.weight', Hd, cin, 4 * cin, 4 * cin_p, cin, cin_p)
+            self._pad_groups(pre + 'fc1.bias', 1, Hd, 1, 1, 4 * cin, 4 * cin_p)
+            self._pad_groups(pre + 'fc2.weight', C, gc_, cin, cin_p, cin, cin_p)
+            self._pad_groups(pre + 'fc2.bias', 1, C, 1, 1, cin, cin_p)
+            if gamma_name:
+                self._pad_groups(gamma_name, 1, C, 1, 1, cin, cin_p)
+            # (persistent zero-initialised buffers: the pad columns are never written)
+            tp = self.buf(pre + 't.pad', (rows, Cp), zero=True)
+            F.pad_copy(t, tp, rows * mg, cin, cin, cin_p, dt, label=pre + 't.pad')
+            Rp = None
+            if R is not None:
+                Rp = self.buf(pre + 'R.pad', (rows, Cp), zero=True)
+                F.pad_copy(R, Rp, rows * mg, cin, cin, cin_p, dt, label=pre + 'R.pad')
+            outp = self.tmp('gmlp.out.pad', (rows, Cp))
+            st = self._gmlp_fwd(pre, tp, rows, Cp, mg, outp, Rp, rowscale, rps, gamma_name=gamma_name, act=act, drop_mask=drop_mask)
+            F.pad_copy(outp, out, rows * mg, cin, cin_p, cin, dt, label=pre + 'out.unpad')
+            st['pad'] = dict(tp=tp, Cp=Cp, cin=cin, cin_p=cin_p)
+            return st
         if Nv % 8 or cin % 8:
-            # odd widths (688 / 4 = 172 channels per group): one-token layers on the alignment-free kernels, fp32 master weights,
+            # the same layers on the alignment-free kernels (GAEXT_PAD_GMLP=0), fp32 master weights,
             # the channel_shuffle as a column map of fc2's input (hidden kept in the ORIGINAL channel order, pre-activation saved)
             assert act == 'gelu' and drop_mask is None and rows <= 4096, (pre, C, mg, rows)
             st = dict(naive=True, Hd=Hd, hpre=self.act(pre + 'hpre', (rows, Hd)), am=self.act(pre + 'am', (rows, Hd)),
@@ -857,9 +912,9 @@ class GAEngine:
             st['d2b'] = F.small_linear_desc(st['am'], P[pre + 'fc2.weight'], out, rows, mg, cin, gc_, dt, lda=Hd, a_gstride=gc_, ldy=C, **kw)
             return st
         assert gc_ % mg == 0, (pre, C, mg)
-        Wm1 = self._w_plain(pre + 'fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm)
+        Wm1 = self._w_plain(pre + 'fc1.weight', Nv, cin, 1, 1, groups=mg * mg, row_perm=perm, src=self._pw(pre + 'fc1.weight'))
         bm1 = self.buf('w.' + pre + 'bm1', (Hd,), torch.float32)
-        self.prep.bias_fold(None, P[pre + 'fc1.bias'], None, None, bm1, Hd, cin, row_perm=perm)
+        self.prep.bias_fold(None, self._pw(pre + 'fc1.bias'), None, None, bm1, Hd, cin, row_perm=perm)
         st = dict(perm=perm, Hd=Hd, gc=gc_, Nv=Nv, cin=cin)
         st['am'] = self.act(pre + 'am', (rows, Hd))                      # gelu(hidden), shuffled order
         st['gm'] = self.act(pre + 'gm', (rows, Hd)) if T else None       # gelu'(hidden)
@@ -876,9 +931,9 @@ class GAEngine:
                    label=pre + 'fc1')
             if two:
                 F.relu_drop(raw, drop_mask, st['am'], st['gm'], rows * Hd, dt, label=pre + 'relu')
-        Wm2 = self._w_plain(pre + 'fc2.weight', cin, gc_, 1, 1, groups=mg, rs=gamma)
+        Wm2 = self._w_plain(pre + 'fc2.weight', cin, gc_, 1, 1, groups=mg, rs=gamma, src=self._pw(pre + 'fc2.weight'))
         bm2 = self.buf('w.' + pre + 'bm2', (C,), torch.float32)
-        self.prep.bias_fold(None, P[pre + 'fc2.bias'], gamma, None, bm2, C, gc_)
+        self.prep.bias_fold(None, self._pw(pre + 'fc2.bias'), gamma, None, bm2, C, gc_)
         F.gemm(st['am'], Wm2, out, rows, cin, gc_, dt, lda=Hd, batch=mg, strideA=gc_, strideB=cin * pad8(gc_),
                ldb=pad8(gc_), ldc=C, strideC=cin, bias=bm2, strideBias=cin, rowscale=rowscale,
                rows_per_scale=rps, R=R, ldr=C, strideR=cin, label=pre + 'fc2')
@@ -887,7 +942,17 @@ class GAEngine:
     def _gmlp_bwd(self, pre, st, dmz, t, rows, C, mg, dtk, gamma_name=None):
         """dmz: gradient wrt the MLP branch output (DropPath scale already applied) -> dtk = gradient wrt the input t"""
         Bk, dt, P, W = self.bwd, self.dt, self.P, self.W
-        gamma = P[gamma_name] if gamma_name else None
+        gamma = self._pw(gamma_name) if gamma_name else None
+        if 'pad' in st:       # the padded layer (see _gmlp_fwd): group-padded gradient in, real part of the input gradient out
+            pd = st.pop('pad')
+            cin, cin_p, Cp = pd['cin'], pd['cin_p'], pd['Cp']
+            dmzp = self.buf(pre + 'dmz.pad', (rows, Cp), zero=True)
+            Bk.pad_copy(dmz, dmzp, rows * mg, cin, cin, cin_p, dt, label=pre + 'dmz.pad')
+            dtkp = self.tmp('gmlp.dt.pad', (rows, Cp))
+            self._gmlp_bwd(pre, st, dmzp, pd['tp'], rows, Cp, mg, dtkp, gamma_name=gamma_name)
+            Bk.pad_copy(dtkp, dtk, rows * mg, cin, cin_p, cin, dt, label=pre + 'dt.unpad')
+            st['pad'] = pd
+            return
         if st.get('naive'):
             Hd = st['Hd']
             dam, dh = self.tmp('dam', (rows, Hd)), self.tmp('dhm', (rows, Hd))
@@ -902,9 +967,9 @@ class GAEngine:
         Gm2, gbm2 = self.gbuf((C, gc_)), self.gbuf((C,))
         Bk.wgrad(dmz, st['am'], Gm2, rows, cin, gc_, dt, ldy=C, ldx=Hd, ldw=gc_, batch=mg, strideY=cin, strideX=gc_,
                  strideW=cin * gc_, dbias=gbm2, strideDbias=cin, label=pre + 'fc2.wg')
-        Bk.weight_unfold(Gm2, gc_, C, gc_, gb=gbm2, W=P[pre + 'fc2.weight'], b=P[pre + 'fc2.bias'],
-                         rs=gamma, dW=self.grad(pre + 'fc2.weight'), db=self.grad(pre + 'fc2.bias'),
-                         d_rs=self.grad(gamma_name) if gamma_name else None, label=pre + 'fc2.unf')
+        Bk.weight_unfold(Gm2, gc_, C, gc_, gb=gbm2, W=self._pw(pre + 'fc2.weight'), b=self._pw(pre + 'fc2.bias'),
+                         rs=gamma, dW=self._pg(pre + 'fc2.weight'), db=self._pg(pre + 'fc2.bias'),
+                         d_rs=self._pg(gamma_name) if gamma_name else None, label=pre + 'fc2.unf')
         dhm = self.tmp('dhm', (rows, Hd))
         gbm1 = self.gbuf((Hd,))
         Bk.gemm(dmz, W[pre + 'fc2.weight.T'], dhm, rows, gc_, cin, dt, lda=C, batch=mg, strideA=cin,
@@ -914,8 +979,8 @@ class GAEngine:
         Gm1 = self.gbuf((Hd, cin))
         Bk.wgrad(dhm, t, Gm1, rows, Nv, cin, dt, ldy=Hd, ldx=C, ldw=cin, batch=mg * mg, strideY=Nv, strideX=cin,
                  x_batch_mod=mg, strideW=Nv * cin, label=pre + 'fc1.wg')
-        Bk.weight_unfold(Gm1, cin, Hd, cin, gb=gbm1, W=P[pre + 'fc1.weight'], b=P[pre + 'fc1.bias'],
-                         row_perm=st['perm'], dW=self.grad(pre + 'fc1.weight'), db=self.grad(pre + 'fc1.bias'),
+        Bk.weight_unfold(Gm1, cin, Hd, cin, gb=gbm1, W=self._pw(pre + 'fc1.weight'), b=self._pw(pre + 'fc1.bias'),
+                         row_perm=st['perm'], dW=self._pg(pre + 'fc1.weight'), db=self._pg(pre + 'fc1.bias'),
                          label=pre + 'fc1.unf')
         Wm1T = W[pre + 'fc1.weight.T']            # [mg*mg][cin][pad8(Nv)]
         for gi in range(mg):
@@ -1009,7 +1074,7 @@ class GAEngine:
                                                  a_gstride=Kp, ldy=cout, bias=P[pre + '0.bias'])
             cgp = pad8(cg)
             ep = self.tmp('emb_pad', (B, groups * cgp))
-            Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp, need_T=False)
+            Wemb = self._w_plain(pre + '0.weight', cg, Kg, 1, 1, groups=groups, ldo=Kp, need_T=self.pad_gmlp)
             F.gemm(h['vec'], Wemb, ep, B, cg, Kp, dt, lda=groups * Kp, batch=groups, strideA=Kp, strideB=cg * Kp,
                    ldc=groups * cgp, strideC=cgp, bias=P[pre + '0.bias'], strideBias=cg, label=pre + 'conv')
             F.pad_copy(ep, h['e'], B * groups, cg, cgp, cg, dt, label=pre + 'compact')
@@ -1041,9 +1106,9 @@ class GAEngine:
             h['kvt'] = tk['kv'][:, k * E2:]                       # column slice, row stride tk['ld']
             h['kvc'] = self.act(pre + 'kvc', (B, E2))
             F.gemm(h['cn'], tk['W'][k * E2:], h['kvc'], B, E2, cout, dt, bias=tk['b'][k * E2:], label=pre + 'kvc')
-            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1, src=self._attn_w(pre + 'attn.q.weight'))
+            Wq = self._w_plain(pre + 'attn.q.weight', E, cout, 1, 1, cs=g1, src=self._pw(pre + 'attn.q.weight'))
             bq = self.buf('w.' + pre + 'bq', (E,), torch.float32)
-            self.prep.bias_fold(self._attn_w(pre + 'attn.q.weight'), None, None, b1, bq, E, cout)
+            self.prep.bias_fold(self._pw(pre + 'attn.q.weight'), None, None, b1, bq, E, cout)
             h['q'] = self.act(pre + 'q', (B, E))
             F.gemm(h['cn'], Wq, h['q'], B, E, cout, dt, bias=bq, label=pre + 'q')
             F.class_attn_fwd2(h['q'], h['kvc'], h['kvt'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, tok_ld=tk['ld'],
@@ -1069,7 +1134,7 @@ class GAEngine:
             h['q'] = self.act(pre + 'q', (B, E))
             F.gemm(h['un'], Wq, h['q'], B, E, cout, dt, lda=(N + 1) * cout, label=pre + 'q')
             F.class_attn_fwd(h['q'], h['kv'], h['ao'], h['P'], B, N + 1, nh, hd, h['scale'], dt, label=pre + 'attn')
-        Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'], src=self._attn_w(pre + 'attn.proj.weight'))
+        Wpr = self._w_plain(pre + 'attn.proj.weight', cout, E, 1, 1, rs=P[pre + 'gamma_1'], src=self._pw(pre + 'attn.proj.weight'))
         bpr = self.buf('w.' + pre + 'bproj', (cout,), torch.float32)
         self.prep.bias_fold(None, P[pre + 'attn.proj.bias'], P[pre + 'gamma_1'], None, bpr, cout, E)
         dp = self.dp_scale.get(pre)
@@ -1116,8 +1181,8 @@ class GAEngine:
         # attention projection
         Gp, gbp = self.gbuf((cout, E)), self.gbuf((cout,))
         Bk.wgrad(dpz, h['ao'], Gp, B, cout, E, dt, dbias=gbp, label=pre + 'proj.wg')
-        Bk.weight_unfold(Gp, E, cout, E, gb=gbp, W=self._attn_w(pre + 'attn.proj.weight'), b=P[pre + 'attn.proj.bias'],
-                         rs=P[pre + 'gamma_1'], dW=self._attn_g(pre + 'attn.proj.weight'), db=self.grad(pre + 'attn.proj.bias'),
+        Bk.weight_unfold(Gp, E, cout, E, gb=gbp, W=self._pw(pre + 'attn.proj.weight'), b=P[pre + 'attn.proj.bias'],
+                         rs=P[pre + 'gamma_1'], dW=self._pg(pre + 'attn.proj.weight'), db=self.grad(pre + 'attn.proj.bias'),
                          d_rs=self.grad(pre + 'gamma_1'), label=pre + 'proj.unf')
         dao = self.tmp('dao', (B, E))
         Bk.gemm(dpz, W[pre + 'attn.proj.weight.T'], dao, B, E, cout, dt, ldb=pad8(cout), label=pre + 'proj.dg')
@@ -1138,8 +1203,8 @@ class GAEngine:
             Bk.wgrad(dkvc, h['cn'], tk['G'][k * E2:], B, E2, cout, dt, dbias=tk['gb'][k * E2:], label=pre + 'kvc.wg')
             Gq, gbq = self.gbuf((E, cout)), self.gbuf((E,))
             Bk.wgrad(dq, h['cn'], Gq, B, E, cout, dt, dbias=gbq, label=pre + 'q.wg')
-            Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=self._attn_w(pre + 'attn.q.weight'), cs=g1, v=b1,
-                             dW=self._attn_g(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
+            Bk.weight_unfold(Gq, cout, E, cout, gb=gbq, W=self._pw(pre + 'attn.q.weight'), cs=g1, v=b1,
+                             dW=self._pg(pre + 'attn.q.weight'), d_cs=dg1, d_v=db1, label=pre + 'q.unf')
             # gradient wrt the normalised class-token row (the image-token rows: one GEMM over all heads after the loop)
             dcn = self.tmp('dcn', (B, cout))
             Bk.gemm(dkvc, tk['WT'][:, k * E2:], dcn, B, cout, E2, dt, ldb=tk['ld'], label=pre + 'kvc.dg')
@@ -1168,7 +1233,21 @@ class GAEngine:
         self._bn_bwd(pre + '1.', h['bn_e'], dcls1, None, h['e'], de, B, cout)
         gW = self.grad(pre + '0.weight')
         dvec = self.buf(f'gram.{k}.dvec', (B, groups * Kp), zero=True)   # pad columns stay zero
-        if h['emb_small'] is not None:
+        if h['emb_small'] is not None and self.pad_gmlp:
+            # odd group width (86 / 122 output channels per group): the gradient in a group-padded copy [B][groups][pad8(cg)] (pad
+            # columns zero) -> both products on the MFMA kernels; the weight gradient lands in a padded scratch [groups][pad8(cg)][Kg]
+            # whose real rows are added to the parameter's gradient
+            cgp = pad8(cg)
+            dep = self.buf(pre + 'de.pad', (B, groups * cgp), zero=True)
+            Bk.pad_copy(de, dep, B * groups, cg, cg, cgp, dt, label=pre + 'de.pad')
+            Gp, gbp = self.gbuf((groups * cgp, Kg)), self.gbuf((groups * cgp,))
+            Bk.wgrad(dep, h['vec'], Gp, B, cgp, Kg, dt, ldy=groups * cgp, ldx=groups * Kp, ldw=Kg, batch=groups, strideY=cgp,
+                     strideX=Kp, strideW=cgp * Kg, dbias=gbp, strideDbias=cgp, label=pre + 'wg')
+            Bk.pad_copy_f32(Gp, gW, groups, cg * Kg, cgp * Kg, cg * Kg, accumulate=True, label=pre + 'wg.unpad')
+            Bk.pad_copy_f32(gbp, self.grad(pre + '0.bias'), groups, cg, cgp, cg, accumulate=True, label=pre + 'db.unpad')
+            Bk.gemm(dep, W[pre + '0.weight.T'], dvec, B, Kg, cgp, dt, lda=groups * cgp, batch=groups, strideA=cgp,
+                    strideB=Kg * cgp, ldb=cgp, ldc=groups * Kp, strideC=Kp, label=pre + 'dg')
+        elif h['emb_small'] is not None:
             Bk.small_linear_bwd(h['emb_small'], de, dA=dvec, dW=gW, dbias=self.grad(pre + '0.bias'), label=pre + 'bwd')
         else:
             Bk.wgrad(de, h['vec'], gW, B, cg, Kg, dt, ldy=cout, ldx=groups * Kp, ldw=Kg, batch=groups, strideY=cg, strideX=Kp,
@@ -1200,7 +1279,6 @@ class GAEngine:
         cout = self.cout
         K, NC = cfg['branches'], cfg['num_classes']
         self.dlogits = self.buf('dlogits', (K, B, NC))
-        self.attn_gpad = {}
         Bk.zero(self.arena, label='zero.arena')
         dx4 = self.tmp('dx4', (M4, cout))
         # classifiers of the five heads: one batched wgrad and one batched dgrad
@@ -1233,8 +1311,8 @@ class GAEngine:
                 Bk.wgrad(tk['dkv'], tk['xn'], tk['G'], M4, tk['ld'], cout, dt, dbias=tk['gb'], label='ga.kv_all.wg')
             for k in range(K):
                 pre = f'ga.{k}.'
-                Bk.weight_unfold(tk['G'][k * E2:], cout, E2, cout, gb=tk['gb'][k * E2:], W=self._attn_w(pre + 'attn.k.weight'),
-                                 cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self._attn_g(pre + 'attn.k.weight'),
+                Bk.weight_unfold(tk['G'][k * E2:], cout, E2, cout, gb=tk['gb'][k * E2:], W=self._pw(pre + 'attn.k.weight'),
+                                 cs=P[pre + 'norm1.weight'], v=P[pre + 'norm1.bias'], dW=self._pg(pre + 'attn.k.weight'),
                                  d_cs=self.grad(pre + 'norm1.weight'), d_v=self.grad(pre + 'norm1.bias'), label=pre + 'kv.unf')
 
             # ... and dx4 += LayerNorm'(gradient wrt the shared normalised tokens, summed over the heads by the K = 5*2E GEMM)
@@ -1269,7 +1347,7 @@ class GAEngine:
         if self.async_wgrad:
             Bk.join_async()
         Bk.flush('heads.')
-        self._attn_unpad()
+        self._unpad_all()
         Bk.mark('heads')      # every gradient of stages.4 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
         seeds = []

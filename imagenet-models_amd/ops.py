@@ -417,6 +417,10 @@ class Plan:
     def pad_copy_f32(self, src, dst, rows, cols, lds, ldd, accumulate=False, label=None):
         self._add('ga_pad_copy_f32', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate)), label, keep=(src, dst))
 
+    def pad_groups_f32(self, src, dst, R, Cdim, RG, RGp, CG, CGp, unpad=False, accumulate=False, label=None):
+        self._add('ga_pad_groups_f32', (_ptr(src), _ptr(dst), R, Cdim, RG, RGp, CG, CGp, int(unpad), int(accumulate)), label,
+                  keep=(src, dst))
+
     def pad_copy(self, src, dst, rows, cols, lds, ldd, dtype, accumulate=False, label=None):
         self._add('ga_pad_copy', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate), dtype), label, keep=(src, dst))
 

@@ -540,6 +540,12 @@ int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY, void* dA,
                         float* dcol_scale, ga_stream_t stream);
 int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream);
 int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, ga_stream_t stream);
+/* two-level group padding of an fp32 parameter matrix [R][C] <-> [R/RG*RGp][C/CG*CGp] (rows in groups of RG padded to RGp, columns
+ * in groups of CG padded to CGp; the padded side is zero-initialised by the caller): unpad = 0 writes the padded matrix, unpad = 1
+ * reads it back ((+)= with accumulate).  The grouped one-token layers of the odd-width variants (GroupConvMlp of ga_convnext_*_688 /
+ * base_976, ga_convnext.py:190-222: 172 / 244 channels per group) run on the MFMA kernels over such copies. */
+int ga_pad_groups_f32(const float* src, float* dst, int64_t R, int64_t C, int RG, int RGp, int CG, int CGp, int unpad, int accumulate,
+                      ga_stream_t stream);
 /* the same element-wise strided copy for activations in `dtype` (group compaction: [rows*groups][88] -> [rows*groups][86]) */
 int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, int dtype,
                 ga_stream_t stream);

@@ -73,3 +73,23 @@ def test_colstats_and_pad_copy():
     back = torch.ones(172, 9 * 172, device='cuda')
     p.pad_copy_f32(dst, back, 172, 9 * 172, 9 * 176, 9 * 172, accumulate=True)
     assert torch.equal(back.cpu(), src + 1)
+
+
+@pytest.mark.parametrize('R,C,RG,RGp,CG,CGp', [(2752, 172, 688, 704, 172, 176), (688, 688, 172, 176, 172, 176), (1, 688, 1, 1, 172, 176),
+                                                (6, 10, 3, 5, 5, 5)])
+def test_pad_groups_round_trip(R, C, RG, RGp, CG, CGp):
+    """ga_pad_groups_f32: rows in groups of RG -> RGp, columns in groups of CG -> CGp (the GroupConvMlp parameters of the odd-width
+    variants, ga_convnext.py:190-222): exact copy of the real part, zeros elsewhere, and the way back with accumulation"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + C)
+    src = torch.randn(R, C, generator=g)
+    Rp, Cp = R // RG * RGp, C // CG * CGp
+    dst = torch.zeros(Rp, Cp, device='cuda')
+    p = ops.Plan(eager=True)
+    p.pad_groups_f32(src.cuda(), dst, R, C, RG, RGp, CG, CGp)
+    want = torch.zeros(R // RG, RGp, C // CG, CGp)
+    want[:, :RG, :, :CG] = src.view(R // RG, RG, C // CG, CG)
+    assert torch.equal(dst.cpu(), want.view(Rp, Cp))
+    back = torch.ones(R, C, device='cuda')
+    p.pad_groups_f32(dst, back, R, C, RG, RGp, CG, CGp, unpad=True, accumulate=True)
+    assert torch.equal(back.cpu(), src + 1)
