@@ -453,7 +453,7 @@ class CSWinEngine(GAEngine):
         if self.async_wgrad:
             Bk.join_async()
         Bk.flush('heads.')
-        self._attn_unpad()
+        self._unpad_all()
         Bk.mark('heads')      # every gradient of stage5 / gram_* / ga / fc is final here
         # aggregate backward -> gradient seeds of the stage outputs / taps
         seeds = []

@@ -20,6 +20,7 @@ python3 bench.py --model ga_CSWin_64_12211_tiny_224 --no-cpu-baseline --no-measu
 python3 bench.py --model map_convnext_tiny --no-cpu-baseline --no-measured-peaks --kernel-table $O/ktable_map.json > $O/bench_map.log 2>&1 || exit 1
 python3 bench.py --model map_vit_base_patch16_384 --batch 128 --steps 30 --warmup 8 --no-cpu-baseline --no-measured-peaks --kernel-table $O/ktable_mapvit.json > $O/bench_mapvit.log 2>&1 || exit 1
 python3 bench.py --model map_pit_s --no-cpu-baseline --no-measured-peaks --kernel-table $O/ktable_mappit.json > $O/bench_mappit.log 2>&1 || exit 1
+python3 bench.py --model ga_convnext_tiny_688 --no-cpu-baseline --no-measured-peaks --kernel-table $O/ktable_688.json > $O/bench_688.log 2>&1 || exit 1
 python3 bench.py --model convnext_tiny --no-cpu-baseline --no-measured-peaks --kernel-table $O/ktable_cnx.json > $O/bench_cnx.log 2>&1 || exit 1
 echo tables done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcF -o f -- python3 bench.py --steps 2 --warmup 1 $B > $O/pmcF.log 2>&1 || exit 1
