@@ -1192,10 +1192,16 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
     // A-operand kinds: plain rows, or the 2 x 2 / stride-2 patches of an NHWC map (GA_A_PATCH2, the downsample convs): a patch row
     // is TWO runs of 2C contiguous elements (taps (0,0)(0,1) and (1,0)(1,1)), so the lane offsets point at the patch origin and
     // the second half of the K stages adds one image row (W * C elements) through the scalar offset -- no gather code in the loop
+    // GA_A_NEIGH2 (data gradient of the 3 x 3 / stride-2 convs, plain epilogue only): row m = pixel (y, x) of the a_H x a_W map, its
+    // K = 4C elements the pixels (y, x) (y, x+1) (y+1, x) (y+1, x+1) -- the same two runs of 2C elements one image row apart, but
+    // a neighbour beyond the right / lower edge is ZERO: two bits per staged row (has a right / a lower neighbour) against the
+    // quarter of K the stage lies in turn the lane's offset out of range
     const bool patch2 = d.a_kind == GA_A_PATCH2;
-    const unsigned p2_row = patch2 ? (unsigned)(d.a_W * d.a_C - 2 * d.a_C) * 2u : 0u;   // bytes added from stage nk/2 on
-    const u32x4_s rsA = make_rsrc(Ab, patch2 ? extent(4L * d.M, d.a_C, d.a_C, 2) : extent(d.M, d.lda, d.K, 2)),
+    const bool neigh2 = EPI == EPI_PLAIN && d.a_kind == GA_A_NEIGH2;
+    const unsigned p2_row = (patch2 || neigh2) ? (unsigned)(d.a_W * d.a_C - 2 * d.a_C) * 2u : 0u;   // bytes added from stage nk/2 on
+    const u32x4_s rsA = make_rsrc(Ab, patch2 ? extent(4L * d.M, d.a_C, d.a_C, 2) : neigh2 ? extent(d.M, d.a_C, d.a_C, 2) : extent(d.M, d.lda, d.K, 2)),
                   rsB = make_rsrc(Bb, extent(d.N, d.ldb, d.K, 2));
+    unsigned n2_have = 0;                                          // NEIGH2: bits 2i, 2i+1 = row of piece i has a right / lower neighbour
     const int ktail = d.K & 31;                                    // > 0: the last stage is ragged
     unsigned aoff[4], boff[2];
     int ivt = blockIdx.x, ikt = 0;                                 // issue-side cursor: output tile, stage inside it
@@ -1210,6 +1216,11 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
                     const unsigned OW = (unsigned)d.a_W >> 1, OH = (unsigned)d.a_H >> 1;
                     const unsigned ox = (unsigned)m % OW, t = (unsigned)m / OW, oy = t % OH, b = t / OH;
                     aoff[i] = m < d.M ? (unsigned)((((long)b * d.a_H + 2 * oy) * d.a_W + 2 * ox) * d.a_C + dchunk) * 2u : kOob;
+                } else if (neigh2) {
+                    const unsigned x = (unsigned)m % (unsigned)d.a_W, y = ((unsigned)m / (unsigned)d.a_W) % (unsigned)d.a_H;
+                    aoff[i] = m < d.M ? (unsigned)(m * d.a_C + dchunk) * 2u : kOob;
+                    const unsigned have = (x + 1 < (unsigned)d.a_W ? 1u : 0u) | (y + 1 < (unsigned)d.a_H ? 2u : 0u);
+                    n2_have = (n2_have & ~(3u << (2 * i))) | (have << (2 * i));
                 } else {
                     aoff[i] = m < d.M ? (unsigned)(m * d.lda + dchunk) * 2u : kOob;
                 }
@@ -1233,8 +1244,16 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
         const unsigned soff = (unsigned)ikt * 64u;
         const unsigned soffA = soff + (2 * ikt >= nk ? p2_row : 0u);
         const unsigned dst = lds0 + slot * kR3Slot;
-        if (part == 0) blds16x2(rsA, kdead ? kOob : aoff[0], kdead ? kOob : aoff[1], soffA, dst + (wave * 4) * 1024);
-        if (part == 1) blds16x2(rsA, kdead ? kOob : aoff[2], kdead ? kOob : aoff[3], soffA, dst + (wave * 4 + 2) * 1024);
+        unsigned a0 = aoff[part == 0 ? 0 : 2], a1 = aoff[part == 0 ? 1 : 3];
+        if (neigh2 && part < 2) {
+            // quarter of K = tap (dy, dx): bit 0 needs a right neighbour, bit 1 a lower one (nk % 4 == 0: C % 32 == 0)
+            const unsigned need = ((4 * ikt >= nk && 4 * ikt < 2 * nk) || 4 * ikt >= 3 * nk ? 1u : 0u) | (2 * ikt >= nk ? 2u : 0u);
+            const unsigned miss = need & ~(n2_have >> (4 * part));
+            if (miss & 3u) a0 = kOob;
+            if ((need & ~(n2_have >> (4 * part + 2))) & 3u) a1 = kOob;
+        }
+        if (part == 0) blds16x2(rsA, kdead ? kOob : a0, kdead ? kOob : a1, soffA, dst + (wave * 4) * 1024);
+        if (part == 1) blds16x2(rsA, kdead ? kOob : a0, kdead ? kOob : a1, soffA, dst + (wave * 4 + 2) * 1024);
         if (part == 2) {
             blds16x2(rsB, kdead ? kOob : boff[0], kdead ? kOob : boff[1], soff, dst + 16384 + (wave * 2) * 1024);
             if (++ikt == nk) {
@@ -2020,9 +2039,11 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     const int r3 = GA_KNOB("NT_R3", -1);
     const bool forced = r3 >= 0;
     const int mask = forced ? r3 : 15;
-    const bool patch2 = d->a_kind == GA_A_PATCH2;       // 2 x 2 / stride-2 patches (downsample convs): plain epilogue only
+    const bool neigh2 = d->a_kind == GA_A_NEIGH2;       // 2 x 2 neighbourhoods (data gradient of the 3 x 3 / stride-2 convs): plain epilogue only
+    const bool patch2 = d->a_kind == GA_A_PATCH2 || neigh2;   // 2 x 2 / stride-2 patches (downsample convs): plain epilogue only
     if (patch2 && (epi != EPI_PLAIN || d->a_C % 16 != 0 || d->K != 4 * d->a_C || 4L * d->M * d->a_C >= (1L << 30) || d->a_batch_mod || d->batch != 1))
         return false;
+    if (neigh2 && (d->a_C % 32 != 0 || (long)d->M % ((long)d->a_H * d->a_W) != 0 || !GA_KNOB("NT_R3_NEIGH2", 1))) return false;
     if (!mask || d->dtype != GA_BF16 || (d->a_kind != GA_A_PLAIN && !patch2) || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
     if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || (!patch2 && d->lda % 8 != 0) || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
     if ((!patch2 && (long)d->M * d->lda >= (1L << 30)) || (long)d->N * d->ldb >= (1L << 30)) return false;   // 32-bit byte offsets
@@ -2072,7 +2093,8 @@ bool want_pp(const ga_gemm_desc* d, int epi) {
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
 int classify_epilogue(const ga_gemm_desc* d, bool allow_patch2 = false) {
-    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && d->a_kind == GA_A_PATCH2)) || d->a_act != GA_ACT_NONE || d->alpha != 1.0f ||
+    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && (d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2))) || d->a_act != GA_ACT_NONE ||
+        d->alpha != 1.0f ||
         (d->c_kind != GA_C_PLAIN && !(allow_patch2 && d->c_kind == GA_C_UNPATCH2)) || d->c_f32 ||
         d->relu_after)
         return EPI_GENERIC;
@@ -2211,7 +2233,8 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
     } while (0)
     if (d->a_kind == GA_A_CONV3 && ga_conv3_c64_try(d, s)) return ga_check_launch("ga_gemm");     // 64 -> 64 channels: direct convolution
     const int epi = classify_epilogue(d);
-    if ((d->a_kind == GA_A_PATCH2 || d->c_kind == GA_C_UNPATCH2) && classify_epilogue(d, true) == EPI_PLAIN && want_r3(d, EPI_PLAIN)) {
+    if ((d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2 || d->c_kind == GA_C_UNPATCH2) && classify_epilogue(d, true) == EPI_PLAIN &&
+        want_r3(d, EPI_PLAIN)) {
         launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map / its data gradient
         return ga_check_launch("ga_gemm");
     }

@@ -192,6 +192,35 @@ def test_conv3x3_stride2_fwd_dgrad_wgrad(dt, shape):
     assert_close(dbias, gy_c.sum(0), tol(dt, 2), 'conv3s2 dbias')
 
 
+@pytest.mark.parametrize('shape', [(2, 28, 28, 32, 64), (1, 14, 14, 64, 128), (3, 56, 56, 64, 64), (8, 112, 112, 64, 64), (5, 14, 30, 96, 32)])
+def test_conv3x3_stride2_dgrad_on_the_ring_form(shape, knobs):
+    """data gradient of the 3 x 3 / stride-2 convs (ga_cswin.py:256,470) with the 2 x 2 neighbourhood rows (GA_A_NEIGH2) fetched by the
+    3-slot ring form: two runs of 2C elements one map row apart, neighbours beyond the right / lower edge as zeros -- against
+    F.conv2d's gradient and bit-for-bit against the register-staged gather form"""
+    ops = _imp()
+    B, H, W, Ci, Co = shape
+    OH, OW = H // 2, W // 2
+    dt = torch.bfloat16
+    g = gen(15)
+    w_c = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(dt).float()
+    gy_c, gy_g = rnd((B * OH * OW, Co), dt, g)
+    xr = torch.zeros(B, Ci, H, W, requires_grad=True)
+    F.conv2d(xr, w_c, None, stride=2, padding=1).backward(gy_c.reshape(B, OH, OW, Co).permute(0, 3, 1, 2))
+    ga = ops.ga_dtype(dt)
+    p = ops.Plan(eager=True)
+    Bt = torch.empty(4 * Ci, 4 * Co, dtype=dt, device='cuda')
+    p.conv3s2_dgrad_prep(w_c.cuda(), Bt, Co, Ci, 4 * Co, ga)
+    outs = []
+    for ring in (1, 0):
+        knobs(NT_R3=15 if ring else 0)
+        dx = torch.full((B * H * W, Ci), 7.0, dtype=dt, device='cuda')
+        p.gemm(gy_g, Bt, dx, B * OH * OW, 4 * Ci, 4 * Co, ga, a_kind=ops.A_NEIGH2, a_dims=(OH, OW, Co), c_kind=ops.C_UNPATCH2,
+               c_dims=(H, W, Ci))
+        assert_close(dx, xr.grad.permute(0, 2, 3, 1).reshape(-1, Ci), tol(dt), f'conv3s2 dgrad ring={ring}')
+        outs.append(dx.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_stem_first_conv_from_nchw(dt):
     """stage1_conv_embed.0 (3 -> E, 3x3 s2, no bias, ga_cswin.py:464): NCHW fp32 input packed to NHWC8, then the gather GEMM"""
