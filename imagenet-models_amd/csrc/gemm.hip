@@ -1158,7 +1158,9 @@ __device__ int g_r3_ticket[4096];
 // stores, 4 no GELU, 8 no operand loads, 16 no DMA, 32 wait-free K loop.  Compile-time on purpose: a run-time switch kept every
 // variant's registers live at once, hipcc spilled the destination registers of in-flight asm loads (guide 5.7 item 1) and a
 // garbage store offset inside the then 2 GiB buffer window faulted.
-template <int EPI, int DBG = 0>
+// AK = 1: the instantiation that also fetches the gather kinds GA_A_NEIGH2 / GA_A_CONV3S2 (their edge bookkeeping costs the plain
+// instantiation 25 spilled SGPRs when it is compiled in)
+template <int EPI, int DBG = 0, int AK = 0>
 __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm_desc d, const int stagger) {
     constexpr int dbg = DBG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1197,15 +1199,24 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
     // a neighbour beyond the right / lower edge is ZERO: two bits per staged row (has a right / a lower neighbour) against the
     // quarter of K the stage lies in turn the lane's offset out of range
     const bool patch2 = d.a_kind == GA_A_PATCH2;
-    const bool neigh2 = EPI == EPI_PLAIN && d.a_kind == GA_A_NEIGH2;
+    const bool neigh2 = AK == 1 && EPI == EPI_PLAIN && d.a_kind == GA_A_NEIGH2;
+    // GA_A_CONV3S2 (the 3 x 3 / stride-2 convs themselves, even maps, plain epilogue only): row m = output pixel, its K = 9C elements
+    // three runs of 3C (taps kx = 0, 1, 2 of one tap row are neighbouring pixels) one map row apart, starting one pixel up and left
+    // of the centre (2 oy, 2 ox).  The lane offset is the CENTRE pixel (always inside the map: the range check sees the lane offset
+    // only), the buffer base is moved W + 1 pixels down, and the scalar offset of a stage counts from the upper-left tap:
+    // linear k + ky (W - 3) C.  Taps left of column 0 / above row 0 turn the lane offset out of range (two bits per staged row).
+    const bool conv3s2 = AK == 1 && EPI == EPI_PLAIN && d.a_kind == GA_A_CONV3S2;
     const unsigned p2_row = (patch2 || neigh2) ? (unsigned)(d.a_W * d.a_C - 2 * d.a_C) * 2u : 0u;   // bytes added from stage nk/2 on
-    const u32x4_s rsA = make_rsrc(Ab, patch2 ? extent(4L * d.M, d.a_C, d.a_C, 2) : neigh2 ? extent(d.M, d.a_C, d.a_C, 2) : extent(d.M, d.lda, d.K, 2)),
+    const unsigned c3_row = conv3s2 ? (unsigned)((d.a_W - 3) * d.a_C) * 2u : 0u;                    // bytes added per tap row
+    const unsigned c3_shift = conv3s2 ? (unsigned)((d.a_W + 1) * d.a_C) * 2u : 0u;
+    const unsigned a_bytes = (patch2 || conv3s2) ? extent(4L * d.M, d.a_C, d.a_C, 2) : neigh2 ? extent(d.M, d.a_C, d.a_C, 2) : extent(d.M, d.lda, d.K, 2);
+    const u32x4_s rsA = make_rsrc(reinterpret_cast<const unsigned char*>(Ab) - c3_shift, a_bytes + c3_shift),
                   rsB = make_rsrc(Bb, extent(d.N, d.ldb, d.K, 2));
-    unsigned n2_have = 0;                                          // NEIGH2: bits 2i, 2i+1 = row of piece i has a right / lower neighbour
+    unsigned n2_have = 0;      // NEIGH2: bits 2i, 2i+1 = row of piece i has a right / lower neighbour; CONV3S2: a left / upper one
     const int ktail = d.K & 31;                                    // > 0: the last stage is ragged
     unsigned aoff[4], boff[2];
     int ivt = blockIdx.x, ikt = 0;                                 // issue-side cursor: output tile, stage inside it
-    auto dma_rows = [&]() {
+    auto dma_rows = [&]() __attribute__((always_inline)) {
         if (ivt < nwg) {
             const int bid = xcd_remap(ivt, nwg);
             const int tm_ = bid / tiles_n, tn_ = bid - tm_ * tiles_n;
@@ -1216,6 +1227,12 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
                     const unsigned OW = (unsigned)d.a_W >> 1, OH = (unsigned)d.a_H >> 1;
                     const unsigned ox = (unsigned)m % OW, t = (unsigned)m / OW, oy = t % OH, b = t / OH;
                     aoff[i] = m < d.M ? (unsigned)((((long)b * d.a_H + 2 * oy) * d.a_W + 2 * ox) * d.a_C + dchunk) * 2u : kOob;
+                } else if (conv3s2) {
+                    const unsigned OW = (unsigned)d.a_W >> 1, OH = (unsigned)d.a_H >> 1;
+                    const unsigned ox = (unsigned)m % OW, t = (unsigned)m / OW, oy = t % OH, b = t / OH;
+                    aoff[i] = m < d.M ? (unsigned)((((long)b * d.a_H + 2 * oy) * d.a_W + 2 * ox) * d.a_C + dchunk) * 2u : kOob;
+                    const unsigned have = (ox > 0 ? 1u : 0u) | (oy > 0 ? 2u : 0u);
+                    n2_have = (n2_have & ~(3u << (2 * i))) | (have << (2 * i));
                 } else if (neigh2) {
                     const unsigned x = (unsigned)m % (unsigned)d.a_W, y = ((unsigned)m / (unsigned)d.a_W) % (unsigned)d.a_H;
                     aoff[i] = m < d.M ? (unsigned)(m * d.a_C + dchunk) * 2u : kOob;
@@ -1239,12 +1256,22 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
     // a stage = EXACTLY 6 vector-memory operations per wave, issued as three pairs (part 0, 1, 2) that the K loop spreads between
     // its MFMA groups: a burst of 6 at the stage top cost ~600 clocks of issue against the 512 the stage's 32 MFMAs take
     // (no-epilogue timing variant: 990 TFLOP/s with the burst against 1440 without any DMA)
-    auto dma_part = [&](int slot, int part) {
+    auto dma_part = [&](int slot, int part) __attribute__((always_inline)) {
         const bool kdead = ktail && ikt == nk - 1 && dchunk >= ktail;
         const unsigned soff = (unsigned)ikt * 64u;
-        const unsigned soffA = soff + (2 * ikt >= nk ? p2_row : 0u);
+        unsigned soffA = soff + (2 * ikt >= nk ? p2_row : 0u);
         const unsigned dst = lds0 + slot * kR3Slot;
         unsigned a0 = aoff[part == 0 ? 0 : 2], a1 = aoff[part == 0 ? 1 : 3];
+        if (conv3s2 && part < 2) {
+            // stage -> tap (ky, kx): nk = 9 C / 32 stages, nk / 9 per tap (C % 32 == 0)
+            const int third = nk / 3, spt = nk / 9;
+            const int ky = (ikt >= third ? 1 : 0) + (ikt >= 2 * third ? 1 : 0);
+            const int r = ikt - ky * third;
+            const unsigned need = (r < spt ? 1u : 0u) | (ky == 0 ? 2u : 0u);       // kx == 0 needs a left, ky == 0 an upper neighbour
+            soffA = soff + (unsigned)ky * c3_row;
+            if ((need & ~(n2_have >> (4 * part))) & 3u) a0 = kOob;
+            if ((need & ~(n2_have >> (4 * part + 2))) & 3u) a1 = kOob;
+        }
         if (neigh2 && part < 2) {
             // quarter of K = tap (dy, dx): bit 0 needs a right neighbour, bit 1 a lower one (nk % 4 == 0: C % 32 == 0)
             const unsigned need = ((4 * ikt >= nk && 4 * ikt < 2 * nk) || 4 * ikt >= 3 * nk ? 1u : 0u) | (2 * ikt >= nk ? 2u : 0u);
@@ -1263,7 +1290,7 @@ __global__ __launch_bounds__(kR3Threads, 2) void gemm_nt_r3_kernel(const ga_gemm
             }
         }
     };
-    auto dma_issue = [&](int slot) {
+    auto dma_issue = [&](int slot) __attribute__((always_inline)) {
         dma_part(slot, 0);
         dma_part(slot, 1);
         dma_part(slot, 2);
@@ -1997,9 +2024,9 @@ void launch_nt_pp(const ga_gemm_desc* d, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, kPPSmem, s, *d, dbg);
 }
 
-template <int EPI, int DBG = 0>
+template <int EPI, int DBG = 0, int AK = 0>
 void launch_nt_r3_(const ga_gemm_desc* d, hipStream_t s) {
-    auto kern = gemm_nt_r3_kernel<EPI, DBG>;
+    auto kern = gemm_nt_r3_kernel<EPI, DBG, AK>;
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kR3Smem) == hipSuccess;
     if (!ok) {
         ga_set_error("ga_gemm: cannot reserve %d bytes of LDS", kR3Smem);
@@ -2040,10 +2067,15 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     const bool forced = r3 >= 0;
     const int mask = forced ? r3 : 15;
     const bool neigh2 = d->a_kind == GA_A_NEIGH2;       // 2 x 2 neighbourhoods (data gradient of the 3 x 3 / stride-2 convs): plain epilogue only
-    const bool patch2 = d->a_kind == GA_A_PATCH2 || neigh2;   // 2 x 2 / stride-2 patches (downsample convs): plain epilogue only
-    if (patch2 && (epi != EPI_PLAIN || d->a_C % 16 != 0 || d->K != 4 * d->a_C || 4L * d->M * d->a_C >= (1L << 30) || d->a_batch_mod || d->batch != 1))
+    const bool conv3s2 = d->a_kind == GA_A_CONV3S2;     // the 3 x 3 / stride-2 convs on even maps: plain epilogue only
+    const bool patch2 = d->a_kind == GA_A_PATCH2 || neigh2 || conv3s2;   // 2 x 2 / stride-2 patches (downsample convs): plain epilogue only
+    if (patch2 && (epi != EPI_PLAIN || d->a_C % 16 != 0 || d->K != (conv3s2 ? 9 : 4) * d->a_C || 4L * d->M * d->a_C >= (1L << 30) ||
+                   d->a_batch_mod || d->batch != 1))
         return false;
     if (neigh2 && (d->a_C % 32 != 0 || (long)d->M % ((long)d->a_H * d->a_W) != 0 || !GA_KNOB("NT_R3_NEIGH2", 1))) return false;
+    if (conv3s2 && (d->a_C % 32 != 0 || d->a_H % 2 != 0 || d->a_W % 2 != 0 || d->a_W < 4 ||
+                    (long)d->M % ((long)(d->a_H / 2) * (d->a_W / 2)) != 0 || !GA_KNOB("NT_R3_CONV3S2", 1)))
+        return false;
     if (!mask || d->dtype != GA_BF16 || (d->a_kind != GA_A_PLAIN && !patch2) || epi == EPI_GENERIC || !((mask >> epi) & 1)) return false;
     if (d->N % 8 != 0 || d->K % 8 != 0 || d->K < 64 || (!patch2 && d->lda % 8 != 0) || d->ldb % 8 != 0 || d->ldc % 8 != 0) return false;
     if ((!patch2 && (long)d->M * d->lda >= (1L << 30)) || (long)d->N * d->ldb >= (1L << 30)) return false;   // 32-bit byte offsets
@@ -2093,7 +2125,8 @@ bool want_pp(const ga_gemm_desc* d, int epi) {
 
 // pick the compile-time epilogue when the launch matches one of the hot shapes of the training step
 int classify_epilogue(const ga_gemm_desc* d, bool allow_patch2 = false) {
-    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && (d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2))) || d->a_act != GA_ACT_NONE ||
+    if ((d->a_kind != GA_A_PLAIN && !(allow_patch2 && (d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2 || d->a_kind == GA_A_CONV3S2))) ||
+        d->a_act != GA_ACT_NONE ||
         d->alpha != 1.0f ||
         (d->c_kind != GA_C_PLAIN && !(allow_patch2 && d->c_kind == GA_C_UNPATCH2)) || d->c_f32 ||
         d->relu_after)
@@ -2233,9 +2266,11 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
     } while (0)
     if (d->a_kind == GA_A_CONV3 && ga_conv3_c64_try(d, s)) return ga_check_launch("ga_gemm");     // 64 -> 64 channels: direct convolution
     const int epi = classify_epilogue(d);
-    if ((d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2 || d->c_kind == GA_C_UNPATCH2) && classify_epilogue(d, true) == EPI_PLAIN &&
+    if ((d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2 || d->a_kind == GA_A_CONV3S2 || d->c_kind == GA_C_UNPATCH2) &&
+        classify_epilogue(d, true) == EPI_PLAIN &&
         want_r3(d, EPI_PLAIN)) {
-        launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map / its data gradient
+        if (d->a_kind == GA_A_NEIGH2 || d->a_kind == GA_A_CONV3S2) launch_nt_r3_<EPI_PLAIN, 0, 1>(d, s);
+        else launch_nt_r3<EPI_PLAIN>(d, s);          // downsample conv (2 x 2 / stride 2) straight from the NHWC map / its data gradient
         return ga_check_launch("ga_gemm");
     }
     if (want_r3(d, epi)) {

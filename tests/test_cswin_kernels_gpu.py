@@ -221,6 +221,35 @@ def test_conv3x3_stride2_dgrad_on_the_ring_form(shape, knobs):
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
 
 
+@pytest.mark.parametrize('shape', [(2, 28, 28, 32, 64), (1, 14, 14, 64, 128), (3, 56, 56, 64, 64), (8, 112, 112, 64, 64), (5, 14, 30, 96, 40),
+                                   (2, 4, 4, 32, 16)])
+def test_conv3x3_stride2_forward_on_the_ring_form(shape, knobs):
+    """the 3 x 3 / stride-2 convs (ga_cswin.py:256,470; GA_A_CONV3S2) with their 9C-element rows fetched by the 3-slot ring form as
+    three runs of 3C elements (buffer base moved W + 1 pixels down, lane offset at the centre tap, taps left of / above the map
+    out of range) -- against F.conv2d and the register-staged gather form"""
+    ops = _imp()
+    B, H, W, Ci, Co = shape
+    OH, OW = H // 2, W // 2
+    dt = torch.bfloat16
+    g = gen(16)
+    x_c, x_g = rnd((B, H, W, Ci), dt, g)
+    w_c = (torch.randn(Co, Ci, 3, 3, generator=g) / math.sqrt(9 * Ci)).to(dt).float()
+    bias = torch.randn(Co, generator=g)
+    y = F.conv2d(x_c.permute(0, 3, 1, 2), w_c, bias, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ga = ops.ga_dtype(dt)
+    p = ops.Plan(eager=True)
+    Wf = torch.empty(Co, 9 * Ci, dtype=dt, device='cuda')
+    p.convw_pack(w_c.cuda(), Wf, Co, Ci, 9, Ci, 9 * Ci, ga)
+    outs = []
+    for ring in (1, 0):
+        knobs(NT_R3=15 if ring else 0)
+        out = torch.full((B * OH * OW, Co), 7.0, dtype=dt, device='cuda')
+        p.gemm(x_g, Wf, out, B * OH * OW, Co, 9 * Ci, ga, a_kind=ops.A_CONV3S2, a_dims=(H, W, Ci), bias=bias.cuda())
+        assert_close(out, y, tol(dt), f'conv3s2 fwd ring={ring}')
+        outs.append(out.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_stem_first_conv_from_nchw(dt):
     """stage1_conv_embed.0 (3 -> E, 3x3 s2, no bias, ga_cswin.py:464): NCHW fp32 input packed to NHWC8, then the gather GEMM"""
