@@ -209,5 +209,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // conv3.hip: the direct 3 x 3 / 64-channel form of ga_gemm's GA_A_CONV3 product; returns 1 if it took the launch
 int ga_conv3_c64_try(const ga_gemm_desc* d, hipStream_t s);
+// ... and of the GA_A_CONV3S2 product of the 3 -> 64-channel first convolution on the NHWC8 image
+int ga_conv0_c8_try(const ga_gemm_desc* d, hipStream_t s);
 size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d);
 int ga_conv3_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s);

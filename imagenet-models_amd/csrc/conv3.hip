@@ -344,7 +344,118 @@ __global__ __launch_bounds__(256) void conv3_wgrad_reduce(const float* __restric
     atomicAdd(dW + (long)n * ldw + k, alpha * a);
 }
 
+// ------------------------------------------------------------------------------------------------
+// First convolution of GA-CSWin's deep stem (ga_cswin.py:464: Conv2d(3, 64, 3, 2, 1), no bias) on the NHWC8 copy of the image
+// (3 channels + 5 zeros = 16 bytes per pixel): 3.2 M output pixels x 64 channels from K = 27 -- HBM-bound (205 MB in, 411 MB out
+// at batch 256), the gather GEMM ran it at 60 TFLOP/s (0.49 ms; its byte floor is 0.13 ms).
+//   No LDS, no barrier: a k step is one tap ROW (3 taps x 8 channels + 8 zeros = 32), so the B fragment of output pixel
+//   (oy, ox0 + (lane & 15)) is ONE 16-byte pixel per lane -- (2 oy + ky - 1, 2 ox + (lane >> 4) - 1), lanes 48-63 and pixels
+//   outside the image an out-of-range buffer offset = zeros -- and the 12 weight fragments (3 tap rows x 4 channel tiles) stay in
+//   registers for the whole kernel.  D: lane = 4 consecutive channels 16 j + 4 (lane >> 4) + r of pixel lane & 15; lane pairs
+//   (lane ^ 16) swap 8-byte halves so that every lane ends with two whole 16-byte chunks -> 16-byte NHWC stores.
+//   wave = NG groups of 16 pixels of one output row per iteration (3 NG loads in flight).
+// ------------------------------------------------------------------------------------------------
+constexpr int C0_NG = 4;
+
+__global__ __launch_bounds__(256) void conv0_c8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wmat, long ldb,
+                                                       bf16_t* __restrict__ y, int nimg, int H, int W, unsigned in_bytes, unsigned out_bytes) {
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 15, g = lane >> 4;
+    const int OH = H >> 1, OW = W >> 1;
+    const int gpr = (OW + 15) / 16;                                 // 16-pixel groups per output row
+    const long ngroups = (long)nimg * OH * gpr;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x), 0, in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y, 0, out_bytes, 0x00020000);
+    // weights: fragment (ky, j) = row 16 j + p of the [64][72] matrix, its 8 elements of tap (ky, kx = g); g == 3: zeros
+    bf16x8_t wf[3][4];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            c3_u4 v = {0u, 0u, 0u, 0u};
+            if (g < 3) v = *reinterpret_cast<const c3_u4*>(wmat + (long)(16 * j + p) * ldb + (3 * ky + g) * 8);
+            wf[ky][j] = *reinterpret_cast<const bf16x8_t*>(&v);
+        }
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long q0 = wave0 * C0_NG; q0 < ngroups; q0 += nwaves * C0_NG) {
+        c3_u4 xin[C0_NG][3];
+        unsigned obase[C0_NG];
+#pragma unroll
+        for (int u = 0; u < C0_NG; ++u) {
+            const long q = q0 + u;
+            const bool live = q < ngroups;
+            const long row = live ? q / gpr : 0;                    // (img, oy)
+            const int gx = live ? (int)(q - row * gpr) : 0;
+            const int oy = (int)(row % OH);
+            const long img = row / OH;
+            const int ox = gx * 16 + p;
+            const int ix = 2 * ox + g - 1;
+            const bool okx = live && g < 3 && ox < OW && (unsigned)ix < (unsigned)W;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy + ky - 1;
+                const bool ok = okx && (unsigned)iy < (unsigned)H;
+                const unsigned off = ok ? (unsigned)(((img * H + iy) * W + ix) * 16) : 0x80000000u;
+                xin[u][ky] = __builtin_bit_cast(c3_u4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            }
+            obase[u] = (live && ox < OW) ? (unsigned)(((img * OH + oy) * OW + ox) * 128) : 0x80000000u;
+        }
+#pragma unroll
+        for (int u = 0; u < C0_NG; ++u) {
+            f32x4_t acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(&xin[u][ky]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ky][j], b, acc[j], 0, 0, 0);
+            }
+            // lane pair (g even, g odd): the even lane assembles the chunk of tile j = 2 t, the odd lane that of tile 2 t + 1
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const unsigned e0 = pack2bf(acc[2 * t][0], acc[2 * t][1]), e1 = pack2bf(acc[2 * t][2], acc[2 * t][3]);
+                const unsigned o0 = pack2bf(acc[2 * t + 1][0], acc[2 * t + 1][1]), o1 = pack2bf(acc[2 * t + 1][2], acc[2 * t + 1][3]);
+                const bool odd = g & 1;
+                // what I send: the half the partner assembles (even lane sends its tile-(2t+1) half, odd lane its tile-2t half)
+                const unsigned s0 = odd ? e0 : o0, s1 = odd ? e1 : o1;
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                c3_u4 ov;
+                if (!odd) { ov[0] = e0; ov[1] = e1; ov[2] = r0; ov[3] = r1; }      // channels 16 (2t) + 8 (g >> 1) .. + 7
+                else { ov[0] = r0; ov[1] = r1; ov[2] = o0; ov[3] = o1; }            // channels 16 (2t + 1) + 8 (g >> 1) .. + 7
+                const unsigned c = 2 * (2 * t + (odd ? 1 : 0)) + (g >> 1);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, ry, obase[u] + c * 16u, 0, 0);
+                asm volatile("s_nop 1" ::"v"(ov) : "memory");
+            }
+        }
+    }
+}
+
 }  // namespace
+
+// ga_gemm's GA_A_CONV3S2 product for the 3 -> 64-channel first convolution on the NHWC8 image: returns 1 if it took the launch
+int ga_conv0_c8_try(const ga_gemm_desc* d, hipStream_t s) {
+    if (!GA_KNOB("CONV0_DIRECT", 1)) return 0;
+    if (d->dtype != GA_BF16 || d->a_kind != GA_A_CONV3S2 || d->a_C != 8 || d->N != 64 || d->K != 72 || d->batch != 1) return 0;
+    if (d->c_kind != GA_C_PLAIN || d->c_f32 || d->ldc != 64 || d->bias || d->R || d->H || d->C2 || d->rowscale || d->colsum || d->colsumsq ||
+        d->act != GA_ACT_NONE || d->a_act != GA_ACT_NONE || d->relu_after || d->alpha != 1.0f)
+        return 0;
+    if (d->a_H % 2 != 0 || d->a_W % 2 != 0 || d->ldb % 8 != 0 || ((reinterpret_cast<uintptr_t>(d->A) | reinterpret_cast<uintptr_t>(d->B) |
+                                                                   reinterpret_cast<uintptr_t>(d->C)) & 15))
+        return 0;
+    const long ohw = (long)(d->a_H / 2) * (d->a_W / 2);
+    if (d->M % ohw != 0) return 0;
+    const long nimg = d->M / ohw;
+    const long in_bytes = nimg * d->a_H * d->a_W * 16, out_bytes = d->M * 128;
+    if (in_bytes >= (1L << 31) || out_bytes >= (1L << 31)) return 0;
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ngroups = nimg * (d->a_H / 2) * ((d->a_W / 2 + 15) / 16);
+    const int grid = (int)std::max<long>(1, std::min<long>((ngroups + 4 * C0_NG - 1) / (4 * C0_NG), (long)cus * 8));
+    hipLaunchKernelGGL(conv0_c8_kernel, dim3(grid), dim3(256), 0, s, (const bf16_t*)d->A, (const bf16_t*)d->B, (long)d->ldb, (bf16_t*)d->C,
+                       (int)nimg, d->a_H, d->a_W, (unsigned)in_bytes, (unsigned)out_bytes);
+    return 1;
+}
 
 // ga_gemm's GA_A_CONV3 product, plain epilogue, bf16, 64 input channels, N = 64, maps of 8 x 16 tiles: returns 1 if it took the launch
 int ga_conv3_c64_try(const ga_gemm_desc* d, hipStream_t s) {

@@ -2095,6 +2095,7 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     //   8-wave ping-pong body on very wide / very long / very tall launches (N 2208: x0.91, K 3072: x0.83, 8192^3: x0.88,
     //   M 73,856 of the ViT trunk: x0.91 .. 0.97) and behind the 128-column forms at N < 384 with a mid-length K (x0.95)
     if ((long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch < num_cus() / 2) return false;      // too few tiles to fill the chip
+    if (neigh2 || conv3s2) return true;      // the alternative is the register-staged gather (110-240 TFLOP/s on these launches)
     const bool pp = want_pp(d, epi);
     if (d->M >= 65536 && pp) return false;
     if (epi != EPI_PLAIN) return true;
@@ -2265,6 +2266,7 @@ extern "C" int ga_gemm(const ga_gemm_desc* d, ga_stream_t stream) {
         else launch_nt<float, TNW, NWM>(d, s);         \
     } while (0)
     if (d->a_kind == GA_A_CONV3 && ga_conv3_c64_try(d, s)) return ga_check_launch("ga_gemm");     // 64 -> 64 channels: direct convolution
+    if (d->a_kind == GA_A_CONV3S2 && d->a_C == 8 && ga_conv0_c8_try(d, s)) return ga_check_launch("ga_gemm");   // 3 (8) -> 64: first conv of the deep stem
     const int epi = classify_epilogue(d);
     if ((d->a_kind == GA_A_PATCH2 || d->a_kind == GA_A_NEIGH2 || d->a_kind == GA_A_CONV3S2 || d->c_kind == GA_C_UNPATCH2) &&
         classify_epilogue(d, true) == EPI_PLAIN &&

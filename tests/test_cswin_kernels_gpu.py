@@ -250,6 +250,35 @@ def test_conv3x3_stride2_forward_on_the_ring_form(shape, knobs):
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
 
 
+@pytest.mark.parametrize('geom', [(2, 32, 32), (1, 20, 36), (3, 224, 224), (1, 2, 2)])
+def test_stem_first_conv_direct_form_64_channels(geom, knobs):
+    """stage1_conv_embed.0 at its real width (3 -> 64, 3x3 s2, no bias, ga_cswin.py:464): the direct kernel (one NHWC8 pixel per lane
+    and tap row, weights in registers) against F.conv2d and against the gather GEMM"""
+    ops = _imp()
+    B, H, W = geom
+    Co = 64
+    dt = torch.bfloat16
+    g = gen(17)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(Co, 3, 3, 3, generator=g) / math.sqrt(27)
+    ga = ops.ga_dtype(dt)
+    p = ops.Plan(eager=True)
+    x8 = torch.empty(B * H * W, 8, dtype=dt, device='cuda')
+    p.nchw3_to_nhwc8(x.cuda(), x8, B, H, W, ga)
+    Wf = torch.empty(Co, 72, dtype=dt, device='cuda')
+    p.convw_pack(w.cuda(), Wf, Co, 3, 9, 8, 72, ga)
+    OH, OW = H // 2, W // 2
+    ref = F.conv2d(x.to(dt).float(), w.to(dt).float(), None, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    outs = []
+    for direct in (1, 0):
+        knobs(CONV0_DIRECT=direct)
+        out = torch.full((B * OH * OW, Co), 7.0, dtype=dt, device='cuda')
+        p.gemm(x8, Wf, out, B * OH * OW, Co, 72, ga, a_kind=ops.A_CONV3S2, a_dims=(H, W, 8))
+        assert_close(out, ref, tol(dt), f'stem conv0 direct={direct}')
+        outs.append(out.float().cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * max(outs[1].abs().max().item(), 1e-3)
+
+
 @pytest.mark.parametrize('dt', DT)
 def test_stem_first_conv_from_nchw(dt):
     """stage1_conv_embed.0 (3 -> E, 3x3 s2, no bias, ga_cswin.py:464): NCHW fp32 input packed to NHWC8, then the gather GEMM"""
