@@ -2094,8 +2094,10 @@ bool want_r3(const ga_gemm_desc* d, int epi) {
     //   plain: ahead for K <= 512 (x1.13 .. 1.18) and for the K = 768 .. 2208 launches of the heads (x1.03 .. 1.10); behind the
     //   8-wave ping-pong body on very wide / very long / very tall launches (N 2208: x0.91, K 3072: x0.83, 8192^3: x0.88,
     //   M 73,856 of the ViT trunk: x0.91 .. 0.97) and behind the 128-column forms at N < 384 with a mid-length K (x0.95)
+    // gather kinds: the alternative is the register-staged gather (110-240 TFLOP/s on these launches, 0.105 ms for the 100 tiles
+    // of merge3's half-batch forward against 0.03 here)
+    if (neigh2 || conv3s2) return (long)cdiv(d->M, 256) * cdiv(d->N, 128) >= 16;
     if ((long)cdiv(d->M, 256) * cdiv(d->N, 128) * d->batch < num_cus() / 2) return false;      // too few tiles to fill the chip
-    if (neigh2 || conv3s2) return true;      // the alternative is the register-staged gather (110-240 TFLOP/s on these launches)
     const bool pp = want_pp(d, epi);
     if (d->M >= 65536 && pp) return false;
     if (epi != EPI_PLAIN) return true;
