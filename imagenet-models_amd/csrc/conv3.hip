@@ -431,7 +431,166 @@ __global__ __launch_bounds__(256) void conv0_c8_kernel(const bf16_t* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ConvNeXt stem (ga_convnext.py:431-434 / timm ConvNeXt stem: Conv2d(3, C, 4, 4) + LayerNorm over the channels) in one pass from
+// the fp32 NCHW image: 4 x 4 / stride-4 patches (K = 48 = (c, ky, kx)) x C = 16 NT output channels, + bias -> `pre` (bf16, kept for
+// the LayerNorm backward) -> LayerNorm of the ROUNDED values (what the two-launch path normalises) -> y, mean, rstd.
+//   HBM-bound: 154 MB in, 2 x 154 MB out at batch 256; the gather GEMM + LayerNorm launches took 0.18 + 0.08 ms (K = 48 at 40 TFLOP/s,
+//   and the LayerNorm re-read `pre`).  Same structure as the kernel above: no LDS, a lane's pixel operand of a k step is two float4
+//   (rows ky, ky + 1 of one channel, 4 kx each) packed to 8 bf16, the 2 NT weight fragments stay in registers; a pixel's C channels
+//   end up on the four lanes l, l + 16, l + 32, l + 48 (4 consecutive channels per tile each), so the LayerNorm sums are two
+//   `__shfl_xor`; lane pairs swap 8-byte halves for 16-byte stores.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void stem4_ln_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wmat, long ldw,
+                                                       const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, bf16_t* __restrict__ pre, bf16_t* __restrict__ y,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int nimg, int H, int W,
+                                                       float eps) {
+    constexpr int C = 16 * NT;
+    const int lane = threadIdx.x & 63;
+    const int p = lane & 15, g = lane >> 4;
+    const int OH = H >> 2, OW = W >> 2;
+    const long M = (long)nimg * OH * OW;
+    const long ngroups = (M + 15) / 16;
+    // weight fragment (s, j): row 16 j + p, elements 32 s + 8 g .. + 7 (zeros beyond k = 48)
+    bf16x8_t wf[2][NT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            c3_u4 v = {0u, 0u, 0u, 0u};
+            if (32 * s2 + 8 * g < 48) v = *reinterpret_cast<const c3_u4*>(wmat + (long)(16 * j + p) * ldw + 32 * s2 + 8 * g);
+            wf[s2][j] = *reinterpret_cast<const bf16x8_t*>(&v);
+        }
+    float bi[NT][4], ga[NT][4], be[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * j + 4 * g + r;
+            bi[j][r] = bias ? bias[c] : 0.f;
+            ga[j][r] = gamma[c];
+            be[j][r] = beta[c];
+        }
+    const long wave0 = (long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long)gridDim.x * 4;
+    for (long q = wave0; q < ngroups; q += nwaves) {
+        const long m = q * 16 + p;
+        const bool live = m < M;
+        const long mm = live ? m : M - 1;
+        const int ox = (int)(mm % OW);
+        const long t = mm / OW;
+        const int oy = (int)(t % OH);
+        const long b = t / OH;
+        bf16x8_t xb[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int k0 = 32 * s2 + 8 * g;
+            c3_u4 v = {0u, 0u, 0u, 0u};
+            if (k0 < 48) {
+                const int c = k0 >> 4, ky = (k0 >> 2) & 3;
+                const float* src = x + ((b * 3 + c) * H + 4 * oy + ky) * (long)W + 4 * ox;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 a2 = *reinterpret_cast<const float4*>(src + W);
+                v[0] = pack2bf(a.x, a.y);
+                v[1] = pack2bf(a.z, a.w);
+                v[2] = pack2bf(a2.x, a2.y);
+                v[3] = pack2bf(a2.z, a2.w);
+            }
+            xb[s2] = *reinterpret_cast<const bf16x8_t*>(&v);
+        }
+        f32x4_t acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][j], xb[0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][j], xb[1], acc[j], 0, 0, 0);
+        }
+        // + bias, round to bf16 (`pre`), LayerNorm statistics of the rounded values over the pixel's C channels (4 lanes)
+        unsigned pk[NT][2];
+        float vr[NT][4];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            pk[j][0] = pack2bf(acc[j][0] + bi[j][0], acc[j][1] + bi[j][1]);
+            pk[j][1] = pack2bf(acc[j][2] + bi[j][2], acc[j][3] + bi[j][3]);
+            vr[j][0] = __uint_as_float(pk[j][0] << 16);
+            vr[j][1] = __uint_as_float(pk[j][0] & 0xffff0000u);
+            vr[j][2] = __uint_as_float(pk[j][1] << 16);
+            vr[j][3] = __uint_as_float(pk[j][1] & 0xffff0000u);
+            sum += (vr[j][0] + vr[j][1]) + (vr[j][2] + vr[j][3]);
+        }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum * (1.f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dlt = vr[j][r] - mu;
+                sq = fmaf(dlt, dlt, sq);
+            }
+        sq += __shfl_xor(sq, 16);
+        sq += __shfl_xor(sq, 32);
+        const float rs = rsqrtf(sq * (1.f / C) + eps);
+        unsigned yk[NT][2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf((vr[j][r] - mu) * rs, ga[j][r], be[j][r]);
+            yk[j][0] = pack2bf(o[0], o[1]);
+            yk[j][1] = pack2bf(o[2], o[3]);
+        }
+        if (live && g == 0) {
+            mean[m] = mu;
+            rstd[m] = rs;
+        }
+        // lane pair (g even, g odd): the even lane assembles the 16-byte chunk of tile 2 t, the odd lane that of tile 2 t + 1
+        const bool odd = g & 1;
+#pragma unroll
+        for (int t2 = 0; t2 < NT / 2; ++t2) {
+            const unsigned c = 2 * (2 * t2 + (odd ? 1 : 0)) + (g >> 1);
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const unsigned e0 = which ? yk[2 * t2][0] : pk[2 * t2][0], e1 = which ? yk[2 * t2][1] : pk[2 * t2][1];
+                const unsigned o0 = which ? yk[2 * t2 + 1][0] : pk[2 * t2 + 1][0], o1 = which ? yk[2 * t2 + 1][1] : pk[2 * t2 + 1][1];
+                const unsigned s0 = odd ? e0 : o0, s1 = odd ? e1 : o1;
+                const unsigned r0 = (unsigned)__shfl_xor((int)s0, 16), r1 = (unsigned)__shfl_xor((int)s1, 16);
+                c3_u4 ov;
+                if (!odd) { ov[0] = e0; ov[1] = e1; ov[2] = r0; ov[3] = r1; }
+                else { ov[0] = r0; ov[1] = r1; ov[2] = o0; ov[3] = o1; }
+                if (live) *reinterpret_cast<c3_u4*>((which ? y : pre) + m * C + c * 8) = ov;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ga_stem4_ln_fwd(const float* x, const void* W, int64_t ldw, const float* bias, const float* gamma, const float* beta,
+                               void* pre, void* y, float* mean, float* rstd, int B, int H, int W_, int C, float eps,
+                               ga_stream_t stream) {
+    GA_REQUIRE(x && W && gamma && beta && pre && y && mean && rstd && B > 0 && H > 0 && W_ > 0, "ga_stem4_ln_fwd: null / empty argument");
+    GA_REQUIRE(H % 4 == 0 && W_ % 4 == 0 && (C == 96 || C == 128) && ldw >= 48 && ldw % 8 == 0,
+               "ga_stem4_ln_fwd: needs H, W multiples of 4, C = 96 or 128, ldw >= 48 and a multiple of 8 (H=%d W=%d C=%d ldw=%ld)", H, W_, C,
+               (long)ldw);
+    GA_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(pre) |
+                 reinterpret_cast<uintptr_t>(y)) & 15) == 0, "ga_stem4_ln_fwd: operands must be 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ngroups = ((long)B * (H / 4) * (W_ / 4) + 15) / 16;
+    const int grid = (int)std::max<long>(1, std::min<long>((ngroups + 3) / 4, (long)cus * 8));
+    if (C == 96)
+        hipLaunchKernelGGL(stem4_ln_kernel<6>, dim3(grid), dim3(256), 0, s, x, (const bf16_t*)W, (long)ldw, bias, gamma, beta, (bf16_t*)pre,
+                           (bf16_t*)y, mean, rstd, B, H, W_, eps);
+    else
+        hipLaunchKernelGGL(stem4_ln_kernel<8>, dim3(grid), dim3(256), 0, s, x, (const bf16_t*)W, (long)ldw, bias, gamma, beta, (bf16_t*)pre,
+                           (bf16_t*)y, mean, rstd, B, H, W_, eps);
+    return ga_check_launch("ga_stem4_ln_fwd");
+}
 
 // ga_gemm's GA_A_CONV3S2 product for the 3 -> 64-channel first convolution on the NHWC8 image: returns 1 if it took the launch
 int ga_conv0_c8_try(const ga_gemm_desc* d, hipStream_t s) {

@@ -269,14 +269,21 @@ class GAEngine:
         Wst = self._w_plain(sc + 'weight', d[0], 3, 4, 4, stem=True, need_T=False)
         stem_pre = self.act('stem.pre', (M0, d[0]))
         self.x_placeholder = torch.zeros(8, device=self.dev)  # patched by set_input
-        F.gemm(self.x_placeholder, Wst, stem_pre, M0, d[0], 48, dt, a_kind=A_STEM4_NCHW, a_dims=(self.img, self.img, 3),
-               bias=self.P[sc + 'bias'], label='stem.conv')
-        self.input_descs.append(self._last_desc(F))
         mean = self.act('stem.mean', (M0,), torch.float32)
         rstd = self.act('stem.rstd', (M0,), torch.float32)
         x = self.buf('stem.out', (M0, d[0]))
-        F.layernorm_fwd(stem_pre, self.P[sl + 'weight'], self.P[sl + 'bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
-                        label='stem.ln')
+        self.stem_call = None
+        if dt == GA_BF16 and d[0] in (96, 128) and self.img % 4 == 0 and os.environ.get('GAEXT_STEM_FUSED', '1') != '0':
+            # conv + bias + LayerNorm in one pass over the image (ga_stem4_ln_fwd): the input pointer is argument 0 of this call
+            self.stem_call = len(F.calls)
+            F.stem4_ln_fwd(self.x_placeholder, Wst, Wst.shape[1], self.P[sc + 'bias'], self.P[sl + 'weight'], self.P[sl + 'bias'],
+                           stem_pre, x, mean, rstd, B, self.img, self.img, d[0], 1e-6, label='stem.conv+ln')
+        else:
+            F.gemm(self.x_placeholder, Wst, stem_pre, M0, d[0], 48, dt, a_kind=A_STEM4_NCHW, a_dims=(self.img, self.img, 3),
+                   bias=self.P[sc + 'bias'], label='stem.conv')
+            self.input_descs.append(self._last_desc(F))
+            F.layernorm_fwd(stem_pre, self.P[sl + 'weight'], self.P[sl + 'bias'], x, mean, rstd, M0, d[0], 1e-6, dt,
+                            label='stem.ln')
         # ---------------- stages 0..3 ----------------
         # one pass per chain (batch part): with GAEXT_FWD_SPLIT > 1 the chains run on side streams; every pass names
         # the same full-batch buffers and records its own rows only
@@ -1416,7 +1423,7 @@ class GAEngine:
         with self._wlane():
             Bk.wgrad(dpre, self.x_placeholder, self.grad(sc + 'weight'), M0, d[0], 48, dt, x_kind=A_STEM4_NCHW,
                      x_dims=(self.img, self.img, 3), dbias=self.grad(sc + 'bias'), label='stem.wg')
-        self.input_descs.append(self._last_desc(Bk))
+        self.input_bwd_desc = self._last_desc(Bk)
 
     # ------------------------------------------------------------------------------------------
     # run
@@ -1444,10 +1451,13 @@ class GAEngine:
             x = x.contiguous()   # channels_last callers (GA/train.py:729-730): the stem gather reads NCHW
         self.x_ref = x
         ptr = x.data_ptr()
-        fd = self.input_descs[0]
-        fd.A = ptr
-        if len(self.input_descs) > 1:
-            self.input_descs[1].X = ptr
+        if getattr(self, 'stem_call', None) is not None:
+            fn, args, label = self.fwd.calls[self.stem_call]
+            self.fwd.calls[self.stem_call] = (fn, (ptr,) + tuple(args[1:]), label)
+        else:
+            self.input_descs[0].A = ptr
+        if getattr(self, 'input_bwd_desc', None) is not None:
+            self.input_bwd_desc.X = ptr
 
     def forward(self, x):
         self.set_input(x)

@@ -417,6 +417,11 @@ class Plan:
     def pad_copy_f32(self, src, dst, rows, cols, lds, ldd, accumulate=False, label=None):
         self._add('ga_pad_copy_f32', (_ptr(src), _ptr(dst), rows, cols, lds, ldd, int(accumulate)), label, keep=(src, dst))
 
+    def stem4_ln_fwd(self, x, W, ldw, bias, gamma, beta, pre, y, mean, rstd, B, H, W_, Cdim, eps, label=None):
+        """ConvNeXt stem conv (4 x 4 / 4 from the fp32 NCHW image) + bias + LayerNorm in one bf16 launch"""
+        self._add('ga_stem4_ln_fwd', (_ptr(x), _ptr(W), ldw, _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(pre), _ptr(y), _ptr(mean), _ptr(rstd),
+                                      B, H, W_, Cdim, eps), label, keep=(x, W, bias, gamma, beta, pre, y, mean, rstd))
+
     def pad_groups_f32(self, src, dst, R, Cdim, RG, RGp, CG, CGp, unpad=False, accumulate=False, label=None):
         self._add('ga_pad_groups_f32', (_ptr(src), _ptr(dst), R, Cdim, RG, RGp, CG, CGp, int(unpad), int(accumulate)), label,
                   keep=(src, dst))

@@ -540,6 +540,12 @@ int ga_small_linear_bwd(const ga_small_linear_desc* d, const void* dY, void* dA,
                         float* dcol_scale, ga_stream_t stream);
 int ga_colstats(const void* x, int64_t ld, int rows, int C, float* sum, float* sumsq, int dtype, ga_stream_t stream);
 int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, int64_t lds, int64_t ldd, int accumulate, ga_stream_t stream);
+/* ConvNeXt stem in one pass (timm ConvNeXt stem / ga_convnext.py:431-434: Conv2d(3, C, 4, 4) + LayerNorm over the channels), bf16:
+ *   x fp32 NCHW [B][3][H][W];  W bf16 [C][ldw], k = (c, ky, kx) as ga_weight_prep(stem = 1) writes it;  bias / gamma / beta fp32 [C];
+ *   pre [B*H/4*W/4][C] = conv + bias (kept for ga_layernorm_bwd), y = LayerNorm(pre) * gamma + beta, mean / rstd per pixel.
+ *   Equals ga_gemm(GA_A_STEM4_NCHW, bias) followed by ga_layernorm_fwd on the rounded `pre`.  C = 96 or 128. */
+int ga_stem4_ln_fwd(const float* x, const void* W, int64_t ldw, const float* bias, const float* gamma, const float* beta, void* pre,
+                    void* y, float* mean, float* rstd, int B, int H, int W_, int C, float eps, ga_stream_t stream);
 /* two-level group padding of an fp32 parameter matrix [R][C] <-> [R/RG*RGp][C/CG*CGp] (rows in groups of RG padded to RGp, columns
  * in groups of CG padded to CGp; the padded side is zero-initialised by the caller): unpad = 0 writes the padded matrix, unpad = 1
  * reads it back ((+)= with accumulate).  The grouped one-token layers of the odd-width variants (GroupConvMlp of ga_convnext_*_688 /

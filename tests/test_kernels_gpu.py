@@ -269,6 +269,40 @@ def test_gemm_stem(dt):
     assert_close(dW, ww.grad.reshape(N, 48), tol(dt, 2), 'stem wgrad')
 
 
+@pytest.mark.parametrize('geom', [(2, 16, 24, 96), (3, 224, 224, 96), (1, 4, 4, 128), (5, 36, 20, 128)])
+def test_stem_conv_layernorm_one_pass(geom):
+    """ga_stem4_ln_fwd (ConvNeXt stem, ga_convnext.py:431-434: Conv2d(3, C, 4, 4) + LayerNorm2d) against the two launches it replaces
+    (stem gather GEMM + ga_layernorm_fwd: `pre` bit-identical, y / mean / rstd to rounding) and against torch"""
+    ops = _imp()
+    dt = torch.bfloat16
+    g = gen(21)
+    Bn, H, W, N = geom
+    x = torch.randn(Bn, 3, H, W, generator=g)
+    w, _ = rnd((N, 3, 4, 4), dt, g, 0.2)
+    bias, gam, bet = torch.randn(N, generator=g) * 0.1, torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    M = Bn * (H // 4) * (W // 4)
+    P = ops.Plan(eager=True)
+    Wf = torch.empty(N, 48, dtype=dt, device='cuda')
+    P.weight_prep(w.cuda(), 1, N, 3, 4, 4, ops.GA_BF16, out=Wf, ldo=48, stem=True)
+    X, Bi, Ga, Be = x.cuda(), bias.cuda(), gam.cuda(), bet.cuda()
+    pre2, y2 = torch.empty(M, N, dtype=dt, device='cuda'), torch.empty(M, N, dtype=dt, device='cuda')
+    m2, r2 = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    P.gemm(X, Wf, pre2, M, N, 48, ops.GA_BF16, a_kind=ops.A_STEM4_NCHW, a_dims=(H, W, 3), bias=Bi)
+    P.layernorm_fwd(pre2, Ga, Be, y2, m2, r2, M, N, 1e-6, ops.GA_BF16)
+    pre1, y1 = torch.full((M, N), 7.0, dtype=dt, device='cuda'), torch.full((M, N), 7.0, dtype=dt, device='cuda')
+    m1, r1 = torch.zeros(M, device='cuda'), torch.zeros(M, device='cuda')
+    P.stem4_ln_fwd(X, Wf, 48, Bi, Ga, Be, pre1, y1, m1, r1, Bn, H, W, N, 1e-6)
+    ref = F.conv2d(x.to(dt).float(), w, bias, stride=4).permute(0, 2, 3, 1).reshape(M, N)
+    assert_close(pre1, ref, tol(dt), 'stem pre vs torch')
+    assert_close(pre1, pre2.float().cpu(), 1e-2, 'stem pre vs the gather GEMM')
+    pr = pre1.float().cpu()
+    yref = F.layer_norm(pr, (N,), gam, bet, 1e-6)
+    assert_close(y1, yref, 2e-2, 'stem y vs torch on the rounded pre')
+    assert_close(y1, y2.float().cpu(), 2e-2, 'stem y vs ga_layernorm_fwd')
+    assert_close(m1, pr.mean(1), 1e-4, 'mean')
+    assert_close(r1, 1.0 / torch.sqrt(pr.var(1, unbiased=False) + 1e-6), 1e-4, 'rstd')
+
+
 @pytest.mark.parametrize('form', ['dma256', 'dma128', 't256', 'pp', 'r3'])
 @pytest.mark.parametrize('shape', [(70000, 384, 96), (66000, 192, 200), (65600, 768, 384), (70000, 96, 384), (66000, 512, 328),
                                    (33000, 1536, 768), (40100, 264, 520), (12500, 3072, 768), (50200, 384, 1536)])
