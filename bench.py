@@ -76,7 +76,7 @@ def parse():
 
 
 def kernel_family(label):
-    for key, fam in (('.wg', 'gemm_tn(wgrad)'), ('wgrad', 'gemm_tn(wgrad)'), ('gram.', 'gemm/gram'),
+    for key, fam in (('stem.conv+ln', 'stem_conv_ln'), ('.pad', 'pad_copy'), ('unpad', 'pad_copy'), ('.wg', 'gemm_tn(wgrad)'), ('wgrad', 'gemm_tn(wgrad)'), ('gram.', 'gemm/gram'),
                      ('.dww', 'dwconv7_wgrad'), ('.dwd', 'dwconv7'), ('.dw', 'dwconv7'),
                      ('attnb', 'stripe_attn_bwd' if 'stage' in label or 'gram_layer' in label else 'class_attn_bwd'), ('.attn', 'stripe_attn_fwd' if 'stage' in label or 'gram_layer' in label else 'class_attn'),
                      ('.lnb', 'layernorm_bwd'), ('ln0b', 'layernorm_bwd'), ('ln1b', 'layernorm_bwd'), ('ln2b', 'layernorm_bwd'),
