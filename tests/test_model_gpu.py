@@ -612,3 +612,37 @@ def test_lanes_do_not_change_the_training_trajectory(monkeypatch):
     # AdamW moves a parameter whose gradient is rounding noise (biases feeding a train-mode BatchNorm) by +-lr per step
     # whatever the noise, so two runs differ by ~2e-3 in L2 even on one stream: the losses above are the sharp check
     assert float((p_on - p_off).double().norm() / p_off.double().norm()) < 5e-3
+
+
+@pytest.mark.parametrize('name', ['ga_convnext_base_976', 'ga_convnext_tiny_688'])
+def test_odd_width_padded_layers_equal_the_alignment_free_path(name, monkeypatch):
+    """the grouped one-token layers of the odd-width variants (GroupConvMlp, gram_embedding backward; ga_convnext.py:190-222,418-420)
+    on zero-padded MFMA layouts (engine default) against the same model on the alignment-free small.hip kernels (GAEXT_PAD_GMLP=0):
+    two independent code paths of this library, one train step at B = 2 in fp32 math mode -- logits, loss and EVERY gradient
+    (base_976 has no reference train fixture: this is the check of its 244 / 122-channel groups and 30-wide attention heads)"""
+    import imagenet_models_amd as A
+    O = _oracle()
+    _, cfg = load_golden('b976_eval.npz' if '976' in name else 't688_train_b4.npz')
+    sd = O.fill_state(cfg)
+    x = O.gen_input(2, seed=3).cuda()
+    target = torch.tensor([3, 11]).cuda()
+    res = []
+    for pad in ('1', '0'):
+        monkeypatch.setenv('GAEXT_PAD_GMLP', pad)
+        m = A.create_model(name, math_mode='fp32')
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.zero_grad()
+        outs = m(x)
+        loss = A.ga_loss(outs, target, -0.8)
+        loss.backward()
+        res.append((torch.stack(outs).detach().cpu(), float(loss), {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters()}))
+        del m
+    (o1, l1, g1), (o0, l0, g0) = res
+    assert rel(o1, o0) < 1e-4 and abs(l1 - l0) <= 1e-5 * abs(l0), (rel(o1, o0), l1, l0)
+    # the parity metric of every gradient test (oracle.grad_errors: analytically-zero gradients -- biases in front of a train-mode
+    # BatchNorm -- hold round-off noise only and are measured absolutely against 0.1 x the largest gradient)
+    errs = O.grad_errors(g1, g0)
+    worst = sorted(((e, n) for n, e in errs.items()), reverse=True)[:5]
+    print(f'[{name}] padded vs alignment-free: logits {rel(o1, o0):.1e} loss {abs(l1 - l0) / abs(l0):.1e} worst grads {worst}')
+    assert worst[0][0] < 2e-3, worst
