@@ -208,6 +208,17 @@ __device__ __forceinline__ void c3_dma4(c3_u4 rs, unsigned dst, unsigned v0, uns
                  : "memory");
 }
 
+__device__ __forceinline__ void c3_dma2(c3_u4 rs, unsigned dst, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+                 "buffer_load_dwordx4 %[c0], %[rs], 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %[c1], %[rs], 0 offen offset:1024 lds\n\t"
+                 "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep)
+                 : [c0] "v"(v0), [c1] "v"(v1), [rs] "s"(rs), [d] "s"(dst)
+                 : "memory");
+}
+
 __global__ __launch_bounds__(256, 1) void conv3_c64_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                  float* __restrict__ part, int nimg, int H, int W, unsigned bytes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -321,6 +332,143 @@ __global__ __launch_bounds__(256, 1) void conv3_c64_wgrad_kernel(const bf16_t* _
     }
     c3_wait_vm<0>();
     // partial of this workgroup: lane holds D[co = 16 jt + 4 (lane >> 4) + r][ci = 16 wv + (lane & 15)] of every tap
+    float* pp = part + (long)blockIdx.x * (64 * 576);
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[(16 * jt + 4 * fk + r) * 576 + tap * 64 + 16 * wv + fr] = acc[tap][jt][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same weight gradient for the 3 x 3 / STRIDE-2 convolution of the deep stem (ga_cswin.py:470: Conv2d(64, 64, 3, 2, 1), 112 -> 56):
+// dW[co][tap * 64 + ci] += sum over output pixels of dY[p][co] * X[2 p + tap - 1][ci].  Tiles of 8 x 8 output pixels; the X halo
+// tile is 17 x 17 input pixels at a pitch of 20 (a k step = 32 output pixels = 4 tile rows advances the input pixel index by
+// 8 x 20 = 160: the swizzle term (P >> 1) & 7 stays, and consecutive output pixels sit two input pixels apart, so the four rows of
+// a transposing read land in four different swizzle classes).  Everything else -- roles of the waves, accumulators, partials --
+// as above.  The gather form of gemm_tn ran this launch at 137 TFLOP/s (0.43 ms on the tail of the backward).
+// ------------------------------------------------------------------------------------------------
+constexpr int T2 = 8, H2 = 2 * T2 + 1, XW2 = 20;             // output tile edge, halo edge, halo row pitch (pixels)
+constexpr int XBUF2 = 48 * 1024, DBUF2 = 8 * 1024;           // 17 x 20 x 128 B = 42.5 KiB in 12 pieces per wave; 64 x 128 B
+constexpr int WG_LDS2 = 2 * XBUF2 + 2 * DBUF2;               // 112 KiB
+
+__global__ __launch_bounds__(256, 1) void conv3s2_c64_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                   float* __restrict__ part, int nimg, int H, int W, unsigned xbytes,
+                                                                   unsigned ybytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int OH = H >> 1, OW = W >> 1;
+    const int tiles_x = OW / T2, tiles_y = OH / T2;
+    const int tpi = tiles_x * tiles_y;
+    const long ntiles = (long)nimg * tpi;
+    const c3_u4 rx = c3_rsrc(x, xbytes), rd = c3_rsrc(dy, ybytes);
+
+    // DMA: X piece i (12 per wave) covers chunks u = (12 wv + i) * 64 + lane of the padded halo image: pixel P = u / 8 = hy * 20 + hx;
+    // dY piece i (2 per wave): chunks u = (2 wv + i) * 64 + lane, pixel p = u / 8 = row * 8 + column of the 8 x 8 tile
+    int xy[12], xx_[12], xc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int u = (wv * 12 + i) * 64 + lane;
+        const int P = u >> 3, hy = P / XW2, hx = P - hy * XW2;
+        xy[i] = (hy < H2 && hx < H2) ? hy : -1000000;
+        xx_[i] = hx;
+        xc[i] = (u & 7) ^ ((P >> 1) & 7);
+    }
+    int dpy[2], dpx[2], dc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = (wv * 2 + i) * 64 + lane;
+        const int p = u >> 3;
+        dpy[i] = p >> 3;
+        dpx[i] = p & 7;
+        dc[i] = (u & 7) ^ ((p >> 1) & 7);
+    }
+    auto issue = [&](long t, int buf) __attribute__((always_inline)) {
+        const bool live = t < ntiles;
+        const int img = live ? (int)(t / tpi) : 0;
+        const int rem = live ? (int)(t - (long)img * tpi) : 0;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        unsigned v[12], q[2];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int yy = 2 * ty * T2 + xy[i] - 1, xx = 2 * tx * T2 + xx_[i] - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            const unsigned off = (unsigned)((((long)img * H + yy) * W + xx) * 128 + xc[i] * 16);
+            v[i] = (ok ? off : 0x80000000u) - 1024u * (i & 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned off = (unsigned)((((long)img * OH + ty * T2 + dpy[i]) * OW + tx * T2 + dpx[i]) * 128 + dc[i] * 16);
+            q[i] = (live ? off : 0x80000000u) - 1024u * i;
+        }
+        const unsigned xb = lds0 + buf * XBUF2 + wv * 12288;
+        c3_dma4(rx, xb, v[0], v[1], v[2], v[3]);
+        c3_dma4(rx, xb + 4096, v[4], v[5], v[6], v[7]);
+        c3_dma4(rx, xb + 8192, v[8], v[9], v[10], v[11]);
+        c3_dma2(rd, lds0 + 2 * XBUF2 + buf * DBUF2 + wv * 2048, q[0], q[1]);
+    };
+
+    // fragment addresses (ds_read_b64_tr_b16: a 16-lane group reads 4 rows x 16 columns, 8 bytes per lane, and hands lane i column i)
+    const int g = lane >> 4, rlo = (lane & 15) >> 2, csub = (lane & 3) >> 1, bsub = 8 * (lane & 1);
+    unsigned da[4][2];                              // dY fragment of output-channel tile jt, half hf, at k step 0 (+ 4096 per k step)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int p = 8 * g + rlo + 4 * hf;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) da[jt][hf] = p * 128 + (((2 * jt + csub) ^ ((p >> 1) & 7)) << 4) + bsub;
+    }
+    unsigned xa[9][2];                              // X fragment (this wave's 16 input channels) of tap, half, at k step 0 (+ 160 x 128 per k step)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int kk = 8 * g + rlo + 4 * hf;    // output pixel of the k step: row kk >> 3, column kk & 7
+            const int P = (2 * (kk >> 3) + tap / 3) * XW2 + 2 * (kk & 7) + tap % 3;
+            xa[tap][hf] = P * 128 + (((2 * wv + csub) ^ ((P >> 1) & 7)) << 4) + bsub;
+        }
+
+    f32x4_t acc[9][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[tap][jt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    long t = blockIdx.x;
+    issue(t, 0);
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        c3_wait_vm<0>();                            // this wave's pieces of tile t (nothing else is in flight: no stores in the loop)
+        __builtin_amdgcn_s_barrier();               // everyone's pieces have landed; everyone is done with the other buffers
+        issue(t + gridDim.x, buf ^ 1);
+        const unsigned char* xi = smem + buf * XBUF2;
+        const unsigned char* di = smem + 2 * XBUF2 + buf * DBUF2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            c3_s4 df[4][2], xf[9][2];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    df[jt][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(di + da[jt][hf] + ks * 4096));
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                    xf[tap][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(xi + xa[tap][hf] + ks * (8 * XW2 * 128)));
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(&xf[tap][0]);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+                    acc[tap][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(&df[jt][0]), b, acc[tap][jt], 0, 0, 0);
+            }
+        }
+    }
+    c3_wait_vm<0>();
     float* pp = part + (long)blockIdx.x * (64 * 576);
     const int fr = lane & 15, fk = lane >> 4;
 #pragma unroll
@@ -654,7 +802,39 @@ static int conv3_wgrad_wgs(const ga_wgrad_desc* d) {
     const long ntiles = (long)d->M / (TH * TW);
     return (int)std::min<long>(ntiles, cus);
 }
-size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d) { return (size_t)conv3_wgrad_wgs(d) * 64 * 576 * sizeof(float); }
+// ... and for the stride-2 convolution (GA_A_CONV3S2: x_H x x_W is the INPUT map, M the output pixels)
+static int conv3s2_wgrad_wgs(const ga_wgrad_desc* d) {
+    if (!GA_KNOB("CONV3_DIRECT", 1)) return 0;
+    if (d->dtype != GA_BF16 || d->x_kind != GA_A_CONV3S2 || d->x_C != 64 || d->N != 64 || d->K != 576 || d->batch != 1 || d->dbias ||
+        d->x_act != GA_ACT_NONE || d->ldy != 64 || !d->accumulate)
+        return 0;
+    if (d->x_H % (2 * T2) != 0 || d->x_W % (2 * T2) != 0) return 0;
+    const long ohw = (long)(d->x_H / 2) * (d->x_W / 2);
+    if ((long)d->M % ohw != 0 || (long)d->M * 4 * 128 >= (1L << 31)) return 0;
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ntiles = (long)d->M / (T2 * T2);
+    return (int)std::min<long>(ntiles, cus);
+}
+size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d) {
+    const int wgs = d->x_kind == GA_A_CONV3S2 ? conv3s2_wgrad_wgs(d) : conv3_wgrad_wgs(d);
+    return (size_t)wgs * 64 * 576 * sizeof(float);
+}
+
+int ga_conv3s2_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s) {
+    const int wgs = conv3s2_wgrad_wgs(d);
+    if (!wgs || !d->workspace || (size_t)d->ws_bytes < (size_t)wgs * 64 * 576 * sizeof(float)) return 0;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3s2_c64_wgrad_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS2) == hipSuccess;
+    if (!attr_ok) return 0;
+    const long ohw = (long)(d->x_H / 2) * (d->x_W / 2);
+    const long nimg = d->M / ohw;
+    float* part = reinterpret_cast<float*>(d->workspace);
+    hipLaunchKernelGGL(conv3s2_c64_wgrad_kernel, dim3(wgs), dim3(256), WG_LDS2, s, (const bf16_t*)d->Y, (const bf16_t*)d->X, part, (int)nimg,
+                       d->x_H, d->x_W, (unsigned)(nimg * d->x_H * d->x_W * 128), (unsigned)((long)d->M * 128));
+    hipLaunchKernelGGL(conv3_wgrad_reduce, dim3(cdiv(64 * 576, 256), cdiv(wgs, 16)), dim3(256), 0, s, part, wgs, d->alpha, d->dW, (long)d->ldw);
+    return 1;
+}
 
 int ga_conv3_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s) {
     const int wgs = conv3_wgrad_wgs(d);

@@ -250,6 +250,34 @@ def test_conv3x3_stride2_forward_on_the_ring_form(shape, knobs):
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
 
 
+@pytest.mark.parametrize('geom', [(2, 32, 32), (1, 16, 48), (3, 112, 112), (40, 112, 112)])     # (the last: more tiles than workgroups)
+def test_conv3x3_stride2_wgrad_direct_form_64_channels(geom, knobs):
+    """weight gradient of the stem's Conv2d(64, 64, 3, 2, 1) (ga_cswin.py:470) on the direct kernel (8 x 8 output tiles, 17 x 17 halo,
+    transposing LDS reads; csrc/conv3.hip) against F.conv2d's gradient and against the gather form of gemm_tn; accumulates into dW"""
+    ops = _imp()
+    B, H, W = geom
+    Ci = Co = 64
+    OH, OW = H // 2, W // 2
+    dt = torch.bfloat16
+    g = gen(18)
+    x_c, x_g = rnd((B, H, W, Ci), dt, g)
+    gy_c, gy_g = rnd((B * OH * OW, Co), dt, g)
+    wr = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+    F.conv2d(x_c.permute(0, 3, 1, 2), wr, None, stride=2, padding=1).backward(gy_c.reshape(B, OH, OW, Co).permute(0, 3, 1, 2))
+    ga = ops.ga_dtype(dt)
+    outs = []
+    for direct in (1, 0):
+        knobs(CONV3_DIRECT=direct)
+        p = ops.Plan(eager=True)
+        G = torch.full((Co, 9 * Ci), 0.5, device='cuda')            # the launch ADDS its result
+        p.wgrad(gy_g, x_g, G, B * OH * OW, Co, 9 * Ci, ga, x_kind=ops.A_CONV3S2, x_dims=(H, W, Ci))
+        dW = torch.zeros(Co, Ci, 3, 3, device='cuda')
+        p.convw_unpack_grad(G - 0.5, dW, Co, Ci, 9, Ci, 9 * Ci)
+        assert_close(dW, wr.grad, tol(dt, 2), f'conv3s2 wgrad direct={direct}')
+        outs.append(dW.cpu())
+    assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
+
+
 @pytest.mark.parametrize('geom', [(2, 32, 32), (1, 20, 36), (3, 224, 224), (1, 2, 2)])
 def test_stem_first_conv_direct_form_64_channels(geom, knobs):
     """stage1_conv_embed.0 at its real width (3 -> 64, 3x3 s2, no bias, ga_cswin.py:464): the direct kernel (one NHWC8 pixel per lane
