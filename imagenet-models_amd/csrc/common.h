@@ -214,3 +214,4 @@ int ga_conv0_c8_try(const ga_gemm_desc* d, hipStream_t s);
 size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d);
 int ga_conv3_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s);
 int ga_conv3s2_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s);
+int ga_conv0_c8_wgrad_try(const ga_wgrad_desc* d, hipStream_t s);

@@ -479,6 +479,131 @@ __global__ __launch_bounds__(256, 1) void conv3s2_c64_wgrad_kernel(const bf16_t*
             for (int r = 0; r < 4; ++r) pp[(16 * jt + 4 * fk + r) * 576 + tap * 64 + 16 * wv + fr] = acc[tap][jt][r];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the FIRST convolution of the deep stem (ga_cswin.py:464: Conv2d(3, 64, 3, 2, 1)) on the NHWC8 image copy:
+// dW[co][tap * 8 + ch] += sum over output pixels of dY[p][co] * X8[2 p + tap - 1][ch] -- 3.2 M pixels, a 64 x 72 result, 411 + 205 MB
+// of operands: HBM-bound (0.13 ms); the gather form of gemm_tn took 0.35-0.37 ms on the very tail of the backward.
+//   Tiles of 8 x 16 output pixels (dY [128 pixels][128 B], swizzled as above; X8 halo 17 x 33 input pixels of 16 bytes at a pitch of
+//   36), double-buffered by LDS-DMA, 52 KiB per workgroup -> three workgroups per CU.  wave w owns output channels 16 w .. + 15; the
+//   B operand of (tap row ky, column pair cp) is a transposing read of 4 output pixels x [2 adjacent input pixels x 8 channels]
+//   (32 contiguous bytes): columns 0-7 = tap kx = 2 cp, columns 8-15 = tap 2 cp + 1 (cp = 1: kx = 3 does not exist, those columns
+//   are dropped) -> 6 MFMAs per k step (32 output pixels) and wave.  One fp32 partial [64][72] per workgroup + reduce.
+// ------------------------------------------------------------------------------------------------
+constexpr int XW0 = 36;                                      // halo row pitch (pixels)
+constexpr int XBUF0 = 16 * 1024, DBUF0 = 16 * 1024;          // 17 x 36 x 16 B = 9.6 KiB in 4 pieces per wave (the rest out of range); 128 x 128 B
+constexpr int WG_LDS0 = 2 * XBUF0 + 2 * DBUF0;               // 64 KiB
+
+__global__ __launch_bounds__(256, 2) void conv0_c8_wgrad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                                float* __restrict__ part, int nimg, int H, int W, unsigned xbytes,
+                                                                unsigned ybytes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int OH = H >> 1, OW = W >> 1;
+    const int tiles_x = OW / TW, tiles_y = OH / TH;
+    const int tpi = tiles_x * tiles_y;
+    const long ntiles = (long)nimg * tpi;
+    const c3_u4 rx = c3_rsrc(x, xbytes), rd = c3_rsrc(dy, ybytes);
+    // DMA: X piece i (4 per wave): chunk u = (4 wv + i) * 64 + lane = halo pixel P = hy * 36 + hx (one 16-byte pixel per chunk);
+    // dY piece i (4 per wave): chunks u = (4 wv + i) * 64 + lane, pixel p = u / 8 of the 8 x 16 tile
+    int xy[4], xx_[4], dpy[4], dpx[4], dc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int P = (wv * 4 + i) * 64 + lane, hy = P / XW0, hx = P - hy * XW0;
+        xy[i] = (hy < 2 * TH + 1 && hx < 2 * TW + 1) ? hy : -1000000;
+        xx_[i] = hx;
+        const int u = (wv * 4 + i) * 64 + lane, p = u >> 3;
+        dpy[i] = p >> 4;
+        dpx[i] = p & 15;
+        dc[i] = (u & 7) ^ ((p >> 1) & 7);
+    }
+    auto issue = [&](long t, int buf) __attribute__((always_inline)) {
+        const bool live = t < ntiles;
+        const int img = live ? (int)(t / tpi) : 0;
+        const int rem = live ? (int)(t - (long)img * tpi) : 0;
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        unsigned v[4], q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = 2 * ty * TH + xy[i] - 1, xx = 2 * tx * TW + xx_[i] - 1;
+            const bool ok = live && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            v[i] = (ok ? (unsigned)((((long)img * H + yy) * W + xx) * 16) : 0x80000000u) - 1024u * i;
+            const unsigned off = (unsigned)((((long)img * OH + ty * TH + dpy[i]) * OW + tx * TW + dpx[i]) * 128 + dc[i] * 16);
+            q[i] = (live ? off : 0x80000000u) - 1024u * i;
+        }
+        c3_dma4(rx, lds0 + buf * XBUF0 + wv * 4096, v[0], v[1], v[2], v[3]);
+        c3_dma4(rd, lds0 + 2 * XBUF0 + buf * DBUF0 + wv * 4096, q[0], q[1], q[2], q[3]);
+    };
+    const int g = lane >> 4, rlo = (lane & 15) >> 2, csub = (lane & 3) >> 1, bsub = 8 * (lane & 1);
+    unsigned da[2], xa[6][2];                       // dY fragment of this wave's channel tile; X fragment of (ky, cp); per half, at k step 0
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        const int p = 8 * g + rlo + 4 * hf;         // output pixel of the k step: row p >> 4, column p & 15
+        da[hf] = p * 128 + (((2 * wv + csub) ^ ((p >> 1) & 7)) << 4) + bsub;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const int ky = nt >> 1, cp = nt & 1;
+            const int P = (2 * (p >> 4) + ky) * XW0 + 2 * (p & 15) + 2 * cp;
+            xa[nt][hf] = P * 16 + (lane & 3) * 8;
+        }
+    }
+    f32x4_t acc[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) acc[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    long t = blockIdx.x;
+    issue(t, 0);
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        c3_wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        issue(t + gridDim.x, buf ^ 1);
+        const unsigned char* xi = smem + buf * XBUF0;
+        const unsigned char* di = smem + 2 * XBUF0 + buf * DBUF0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {            // 32 output pixels = 2 tile rows = 4 input rows
+            c3_s4 df[2], xf[6][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                df[hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(di + da[hf] + ks * 4096));
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+                    xf[nt][hf] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) c3_s4*)(xi + xa[nt][hf] + ks * (4 * XW0 * 16)));
+            }
+            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(&df[0]);
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8_t*>(&xf[nt][0]), acc[nt], 0, 0, 0);
+        }
+    }
+    c3_wait_vm<0>();
+    // lane holds D[co = 16 wv + 4 (lane >> 4) + r][column lane & 15 of (ky, cp)]: column = (pixel e = c >> 3, channel c & 7), tap kx = 2 cp + e
+    float* pp = part + (long)blockIdx.x * (64 * 72);
+    const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int ky = nt >> 1, kx = 2 * (nt & 1) + (fr >> 3);
+        if (kx < 3) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pp[(16 * wv + 4 * fk + r) * 72 + (3 * ky + kx) * 8 + (fr & 7)] = acc[nt][r];
+        }
+    }
+}
+
+// dW[n][k] += alpha * sum_s part[s][n][k] for the [64][72] partials of the kernel above
+__global__ __launch_bounds__(256) void conv0_wgrad_reduce(const float* __restrict__ part, int nparts, float alpha, float* __restrict__ dW,
+                                                          long ldw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // over 64 * 72
+    if (i >= 64 * 72) return;
+    const int s0 = blockIdx.y * 16, s1 = min(nparts, s0 + 16);
+    float a = 0.f;
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) a += part[(long)s * (64 * 72) + i];
+    const int n = i / 72, k = i - n * 72;
+    atomicAdd(dW + (long)n * ldw + k, alpha * a);
+}
+
 // dW[n][k] += alpha * sum_s part[s][n][k]: blockIdx.y sums 16 partials and adds its share with one atomic per element
 __global__ __launch_bounds__(256) void conv3_wgrad_reduce(const float* __restrict__ part, int nparts, float alpha, float* __restrict__ dW,
                                                           long ldw) {
@@ -816,9 +941,39 @@ static int conv3s2_wgrad_wgs(const ga_wgrad_desc* d) {
     const long ntiles = (long)d->M / (T2 * T2);
     return (int)std::min<long>(ntiles, cus);
 }
+// ... and for the first convolution (GA_A_CONV3S2 on the 8-channel image copy)
+static int conv0_wgrad_wgs(const ga_wgrad_desc* d) {
+    if (!GA_KNOB("CONV0_DIRECT", 1)) return 0;
+    if (d->dtype != GA_BF16 || d->x_kind != GA_A_CONV3S2 || d->x_C != 8 || d->N != 64 || d->K != 72 || d->batch != 1 || d->dbias ||
+        d->x_act != GA_ACT_NONE || d->ldy != 64 || !d->accumulate)
+        return 0;
+    if (d->x_H % (2 * TH) != 0 || d->x_W % (2 * TW) != 0) return 0;
+    const long ohw = (long)(d->x_H / 2) * (d->x_W / 2);
+    if ((long)d->M % ohw != 0 || (long)d->M * 128 >= (1L << 31)) return 0;
+    int cus = 256;
+    ga_device_info(&cus, nullptr, nullptr);
+    const long ntiles = (long)d->M / (TH * TW);
+    return (int)std::min<long>(ntiles, 2L * cus);
+}
 size_t ga_conv3_c64_wgrad_workspace(const ga_wgrad_desc* d) {
+    if (d->x_kind == GA_A_CONV3S2 && d->x_C == 8) return (size_t)conv0_wgrad_wgs(d) * 64 * 72 * sizeof(float);
     const int wgs = d->x_kind == GA_A_CONV3S2 ? conv3s2_wgrad_wgs(d) : conv3_wgrad_wgs(d);
     return (size_t)wgs * 64 * 576 * sizeof(float);
+}
+
+int ga_conv0_c8_wgrad_try(const ga_wgrad_desc* d, hipStream_t s) {
+    const int wgs = conv0_wgrad_wgs(d);
+    if (!wgs || !d->workspace || (size_t)d->ws_bytes < (size_t)wgs * 64 * 72 * sizeof(float)) return 0;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(conv0_c8_wgrad_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS0) == hipSuccess;
+    if (!attr_ok) return 0;
+    const long ohw = (long)(d->x_H / 2) * (d->x_W / 2);
+    const long nimg = d->M / ohw;
+    float* part = reinterpret_cast<float*>(d->workspace);
+    hipLaunchKernelGGL(conv0_c8_wgrad_kernel, dim3(wgs), dim3(256), WG_LDS0, s, (const bf16_t*)d->Y, (const bf16_t*)d->X, part, (int)nimg,
+                       d->x_H, d->x_W, (unsigned)(nimg * d->x_H * d->x_W * 16), (unsigned)((long)d->M * 128));
+    hipLaunchKernelGGL(conv0_wgrad_reduce, dim3(cdiv(64 * 72, 256), cdiv(wgs, 16)), dim3(256), 0, s, part, wgs, d->alpha, d->dW, (long)d->ldw);
+    return 1;
 }
 
 int ga_conv3s2_c64_wgrad_try(const ga_wgrad_desc* d, hipStream_t s) {

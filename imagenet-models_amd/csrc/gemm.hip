@@ -2365,6 +2365,7 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (d->x_kind == GA_A_CONV3 && ga_conv3_c64_wgrad_try(d, s)) return ga_check_launch("ga_wgrad");   // 64 -> 64 channels: direct form
     if (d->x_kind == GA_A_CONV3S2 && d->x_C == 64 && ga_conv3s2_c64_wgrad_try(d, s)) return ga_check_launch("ga_wgrad");   // ... stride 2
+    if (d->x_kind == GA_A_CONV3S2 && d->x_C == 8 && ga_conv0_c8_wgrad_try(d, s)) return ga_check_launch("ga_wgrad");        // 3 (8) -> 64, stride 2
     if (tn2_eligible(d)) {
         static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn2_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, kTn2Smem) == hipSuccess;
@@ -2393,7 +2394,7 @@ extern "C" int ga_wgrad(const ga_wgrad_desc* d, ga_stream_t stream) {
 
 extern "C" size_t ga_wgrad_workspace(const ga_wgrad_desc* d) {
     if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return 0;
-    if (d->x_kind == GA_A_CONV3 || (d->x_kind == GA_A_CONV3S2 && d->x_C == 64)) return ga_conv3_c64_wgrad_workspace(d);
+    if (d->x_kind == GA_A_CONV3 || (d->x_kind == GA_A_CONV3S2 && (d->x_C == 64 || d->x_C == 8))) return ga_conv3_c64_wgrad_workspace(d);
     if (!tn2_eligible(d)) return 0;
     int split;
     return tn2_plan(d, &split);

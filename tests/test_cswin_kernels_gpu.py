@@ -278,7 +278,7 @@ def test_conv3x3_stride2_wgrad_direct_form_64_channels(geom, knobs):
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * outs[1].abs().max().item()
 
 
-@pytest.mark.parametrize('geom', [(2, 32, 32), (1, 20, 36), (3, 224, 224), (1, 2, 2)])
+@pytest.mark.parametrize('geom', [(2, 32, 32), (1, 20, 36), (3, 224, 224), (1, 2, 2), (1, 16, 96), (20, 224, 224)])
 def test_stem_first_conv_direct_form_64_channels(geom, knobs):
     """stage1_conv_embed.0 at its real width (3 -> 64, 3x3 s2, no bias, ga_cswin.py:464): the direct kernel (one NHWC8 pixel per lane
     and tap row, weights in registers) against F.conv2d and against the gather GEMM"""
@@ -305,6 +305,20 @@ def test_stem_first_conv_direct_form_64_channels(geom, knobs):
         assert_close(out, ref, tol(dt), f'stem conv0 direct={direct}')
         outs.append(out.float().cpu())
     assert (outs[0] - outs[1]).abs().max().item() <= 2e-2 * max(outs[1].abs().max().item(), 1e-3)
+    # its weight gradient: the direct kernel needs maps of 16 x 32-pixel input tiles (other maps stay on the gather form of gemm_tn)
+    gy_c, gy_g = rnd((B * OH * OW, Co), dt, g)
+    wr = w.to(dt).float().clone().requires_grad_(True)
+    F.conv2d(x.to(dt).float(), wr, None, stride=2, padding=1).backward(gy_c.reshape(B, OH, OW, Co).permute(0, 3, 1, 2))
+    gs = []
+    for direct in (1, 0):
+        knobs(CONV0_DIRECT=direct)
+        G = torch.full((Co, 72), 0.25, device='cuda')               # the launch ADDS its result
+        p.wgrad(gy_g, x8, G, B * OH * OW, Co, 72, ga, x_kind=ops.A_CONV3S2, x_dims=(H, W, 8))
+        dW = torch.zeros(Co, 3, 3, 3, device='cuda')
+        p.convw_unpack_grad(G - 0.25, dW, Co, 3, 9, 8, 72)
+        assert_close(dW, wr.grad, tol(dt, 2), f'stem conv0 wgrad direct={direct}')
+        gs.append(dW.cpu())
+    assert (gs[0] - gs[1]).abs().max().item() <= 2e-2 * max(gs[1].abs().max().item(), 1e-3)
 
 
 @pytest.mark.parametrize('dt', DT)

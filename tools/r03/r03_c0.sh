@@ -7,6 +7,6 @@ tail -2 gpurun_out/r03/t_c0.log
 timeout -k 10 900 python -m pytest tests/test_cswin_model_gpu.py -m gpu -x -q > gpurun_out/r03/t_c0b.log 2>&1 || { tail -30 gpurun_out/r03/t_c0b.log; exit 1; }
 tail -2 gpurun_out/r03/t_c0b.log
 for v in 1 0 1; do
-GAEXT_CONV3_DIRECT=$v python bench.py --model ga_CSWin_64_12211_tiny_224 --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r03/kt_c3w_$v.json > gpurun_out/r03/c3w_$v.log 2>&1 || { tail -20 gpurun_out/r03/c3w_$v.log; exit 1; }
-echo "conv3_direct=$v $(tail -1 gpurun_out/r03/c3w_$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"
+GAEXT_CONV0_DIRECT=$v python bench.py --model ga_CSWin_64_12211_tiny_224 --no-cpu-baseline --no-measured-peaks --kernel-table gpurun_out/r03/kt_c0w_$v.json > gpurun_out/r03/c0w_$v.log 2>&1 || { tail -20 gpurun_out/r03/c0w_$v.log; exit 1; }
+echo "conv0_direct=$v $(tail -1 gpurun_out/r03/c0w_$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")"
 done
