@@ -189,6 +189,7 @@ _SIGS = {
     'ga_pad_copy_f32': ([vp, vp, i64, i64, i64, i64, i32, vp], i32),
     'ga_pad_copy': ([vp, vp, i64, i64, i64, i64, i32, i32, vp], i32),
     'ga_stem4_ln_fwd': ([vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp], i32),
+    'ga_blockdiag_f32': ([vp, vp, i64, i32, i32, i32, i64, i32, i32, vp], i32),
     'ga_pad_groups_f32': ([vp, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp], i32),
     'ga_attn_fwd': ([C.POINTER(AttnDesc), vp], i32),
     'ga_attn_bwd_workspace': ([C.POINTER(AttnDesc)], C.c_size_t),

@@ -213,6 +213,19 @@ __global__ __launch_bounds__(256) void pad_groups_kernel(const float* __restrict
     }
 }
 
+// compact [R][cg] <-> block-diagonal [R][ld] with the rows in groups of rg, ng groups per diagonal (R may stack several matrices):
+// row r's cg values sit at columns ((r / rg) % ng) * cg ...
+__global__ __launch_bounds__(256) void blockdiag_kernel(const float* __restrict__ src, float* __restrict__ dst, long R, int rg, int ng, int cg,
+                                                        long ld, int to_diag, int accumulate) {
+    const long n = R * cg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cg, c = i - r * cg;
+        const long j = r * ld + ((r / rg) % ng) * cg + c;
+        if (to_diag) dst[j] = accumulate ? dst[j] + src[i] : src[i];
+        else dst[i] = accumulate ? dst[i] + src[j] : src[j];
+    }
+}
+
 int check_desc(const ga_small_linear_desc* d, const char* what) {
     GA_REQUIRE(d && d->A && d->W && d->rows > 0 && d->groups > 0 && d->Ng > 0 && d->Kg > 0, "%s: null / empty descriptor", what);
     GA_REQUIRE(d->dtype == GA_F32 || d->dtype == GA_BF16, "%s: bad dtype", what);
@@ -301,6 +314,16 @@ extern "C" int ga_pad_copy(const void* src, void* dst, int64_t rows, int64_t col
         hipLaunchKernelGGL(pad_copy_kernel<float>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float*>(src),
                            reinterpret_cast<float*>(dst), (long)rows, (long)cols, (long)lds, (long)ldd, accumulate);
     return ga_check_launch("ga_pad_copy");
+}
+
+extern "C" int ga_blockdiag_f32(const float* src, float* dst, int64_t R, int rg, int ng, int cg, int64_t ld, int to_diag, int accumulate,
+                                ga_stream_t stream) {
+    GA_REQUIRE(src && dst && R > 0 && rg > 0 && ng > 0 && cg > 0 && R % ((long)rg * ng) == 0 && ld >= (long)ng * cg, "ga_blockdiag_f32: bad args");
+    const long n = R * cg;
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + 255) / 256));
+    hipLaunchKernelGGL(blockdiag_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src, dst, (long)R, rg, ng, cg,
+                       (long)ld, to_diag, accumulate);
+    return ga_check_launch("ga_blockdiag_f32");
 }
 
 extern "C" int ga_pad_groups_f32(const float* src, float* dst, int64_t R, int64_t C, int RG, int RGp, int CG, int CGp, int unpad,

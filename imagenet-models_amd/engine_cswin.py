@@ -15,6 +15,8 @@ engine.GAEngine; the trunk is restated here from /root/reference/GA/ga_cswin.py:
 Saved for backward per CSWinBlock: xn1 (LN1 output without affine), rstd1, qkv, the attention output, xn2, rstd2,
 a = gelu(h), g = gelu'(h), the block output.
 """
+import os
+
 import torch
 
 from . import ops
@@ -385,7 +387,28 @@ class CSWinEngine(GAEngine):
         K, g_, gg = cfg['branches'], cfg['gram_dim'], cfg['gram_groups']
         gpo, cpi = g_ // gg, cout // gg
         assert g_ % gg == 0 and gpo % 8 == 0 and cpi % 8 == 0, 'grouped gram_contraction needs 8-aligned group widths'
-        gc = self.gcon = dict(ld=K * g_, gpo=gpo, cpi=cpi)
+        gc = self.gcon = dict(ld=K * g_, gpo=gpo, cpi=cpi, dense=False)
+        if dt == ops.GA_BF16 and os.environ.get('GAEXT_GC_DENSE', '1') != '0':
+            # the five grouped convs as ONE dense product over block-diagonal weights ([K g_] x cout, zeros off the diagonal blocks):
+            # 8 x the MACs of the grouped form, but one ring-form launch with N = 960 instead of 40 products with N = 24 whose 48-byte
+            # output rows are partial cache lines (0.196 -> 0.07 ms forward; the data gradient of all heads one launch as well)
+            gc['dense'] = True
+            gc['Wm'] = self.buf('pad.gram_contraction.bd', (K * g_, cout), torch.float32, zero=True)     # block-diagonal fp32 master
+            for k in range(K):
+                self.prep.blockdiag_f32(P[f'gram_contraction.{k}.0.weight'], gc['Wm'][k * g_:], g_, gpo, gg, cpi, cout,
+                                        label=f'prep.gram_contraction.{k}.bd')
+            gc['Wd'] = self.buf('w.gram_contraction.bd', (K * g_, cout))
+            gc['WdT'] = self.buf('wT.gram_contraction.bd', (cout, pad8(K * g_))) if T else None
+            self.prep.weight_prep(gc['Wm'], 1, K * g_, cout, 1, 1, dt, out=gc['Wd'], ldo=cout, outT=gc['WdT'],
+                                  ldt=pad8(K * g_) if T else 0, label='prep.gram_contraction.bd')
+            gc['b'] = self.buf('w.gram_contraction.ball', (K * g_,), torch.float32)
+            gc['s'], gc['q'] = self._bn_pool(K * g_), self._bn_pool(K * g_)
+            for k in range(K):
+                self.prep.bias_fold(None, P[f'gram_contraction.{k}.0.bias'], None, None, gc['b'][k * g_:], g_, cpi)
+            gc['out'] = self.act('gram_contraction.all.out', (M4, K * g_))
+            F.gemm(x4, gc['Wd'], gc['out'], M4, K * g_, cout, dt, bias=gc['b'], colsum=gc['s'] if T else None,
+                   colsumsq=gc['q'] if T else None, label='gram_contraction.all')
+            return
         gc['W'] = self.buf('w.gram_contraction.all', (K * g_, cpi))
         gc['WT'] = self.buf('wT.gram_contraction.all', (K, gg * cpi, pad8(gpo))) if T else None
         gc['b'] = self.buf('w.gram_contraction.ball', (K * g_,), torch.float32)
@@ -406,6 +429,18 @@ class CSWinEngine(GAEngine):
         gcn = self.gcon
         gpo, cpi = gcn['gpo'], gcn['cpi']
         Gc, gbc = self.gbuf((K * g_, cpi)), self.gbuf((K * g_,))
+        if gcn['dense']:
+            Gd = self.gbuf((K * g_, cout))
+            with self._wlane():
+                Bk.wgrad(gcn['dout'], x4, Gd, M4, K * g_, cout, dt, dbias=gbc, label='gram_contraction.all.wg')
+                Bk.blockdiag_f32(Gd, Gc, K * g_, gpo, gg, cpi, cout, to_diag=False, label='gram_contraction.all.wg.diag')
+            for k in range(K):
+                pre = f'gram_contraction.{k}.'
+                Bk.axpy_f32(self.grad(pre + '0.weight'), Gc[k * g_:], 1.0, g_ * cpi)
+                Bk.axpy_f32(self.grad(pre + '0.bias'), gbc[k * g_:], 1.0, g_)
+            Bk.gemm(gcn['dout'], gcn['WdT'], dx4, M4, cout, K * g_, dt, ldb=pad8(K * g_), R=None if self.shared_tok else dx4, ldr=cout,
+                    label='gram_contraction.all.dg')
+            return
         with self._wlane():
             Bk.wgrad(gcn['dout'], x4, Gc, M4, gpo, cpi, dt, ldy=K * g_, ldx=cout, ldw=cpi, batch=K * gg, strideY=gpo, strideX=cpi,
                      x_batch_mod=gg, strideW=gpo * cpi, dbias=gbc, strideDbias=gpo, label='gram_contraction.all.wg')

@@ -422,6 +422,9 @@ class Plan:
         self._add('ga_stem4_ln_fwd', (_ptr(x), _ptr(W), ldw, _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(pre), _ptr(y), _ptr(mean), _ptr(rstd),
                                       B, H, W_, Cdim, eps), label, keep=(x, W, bias, gamma, beta, pre, y, mean, rstd))
 
+    def blockdiag_f32(self, src, dst, R, rg, ng, cg, ld, to_diag=True, accumulate=False, label=None):
+        self._add('ga_blockdiag_f32', (_ptr(src), _ptr(dst), R, rg, ng, cg, ld, int(to_diag), int(accumulate)), label, keep=(src, dst))
+
     def pad_groups_f32(self, src, dst, R, Cdim, RG, RGp, CG, CGp, unpad=False, accumulate=False, label=None):
         self._add('ga_pad_groups_f32', (_ptr(src), _ptr(dst), R, Cdim, RG, RGp, CG, CGp, int(unpad), int(accumulate)), label,
                   keep=(src, dst))

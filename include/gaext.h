@@ -546,6 +546,12 @@ int ga_pad_copy_f32(const float* src, float* dst, int64_t rows, int64_t cols, in
  *   Equals ga_gemm(GA_A_STEM4_NCHW, bias) followed by ga_layernorm_fwd on the rounded `pre`.  C = 96 or 128. */
 int ga_stem4_ln_fwd(const float* x, const void* W, int64_t ldw, const float* bias, const float* gamma, const float* beta, void* pre,
                     void* y, float* mean, float* rstd, int B, int H, int W_, int C, float eps, ga_stream_t stream);
+/* grouped 1x1 convolution as ONE dense GEMM: the weight [R][cg] of a conv with ng groups (rg output rows and cg input channels per
+ * group; R = a multiple of rg * ng: several such weights stacked) <-> its block-diagonal image [R][ld] (row r's values at columns
+ * ((r / rg) % ng) * cg ..., zeros elsewhere, zero-initialised by the caller).  to_diag = 1 writes the block-diagonal side, 0 reads it back ((+)= with accumulate).  GA-CSWin's grouped gram_contraction
+ * (ga_cswin.py:559-561: 8 groups of 64 -> 24 channels, five heads) runs as one 960 x 512 product instead of 40 products with N = 24. */
+int ga_blockdiag_f32(const float* src, float* dst, int64_t R, int rg, int ng, int cg, int64_t ld, int to_diag, int accumulate,
+                     ga_stream_t stream);
 /* two-level group padding of an fp32 parameter matrix [R][C] <-> [R/RG*RGp][C/CG*CGp] (rows in groups of RG padded to RGp, columns
  * in groups of CG padded to CGp; the padded side is zero-initialised by the caller): unpad = 0 writes the padded matrix, unpad = 1
  * reads it back ((+)= with accumulate).  The grouped one-token layers of the odd-width variants (GroupConvMlp of ga_convnext_*_688 /

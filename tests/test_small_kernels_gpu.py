@@ -93,3 +93,22 @@ def test_pad_groups_round_trip(R, C, RG, RGp, CG, CGp):
     back = torch.ones(R, C, device='cuda')
     p.pad_groups_f32(dst, back, R, C, RG, RGp, CG, CGp, unpad=True, accumulate=True)
     assert torch.equal(back.cpu(), src + 1)
+
+
+@pytest.mark.parametrize('R,rg,ng,cg,ld', [(192, 24, 8, 64, 512), (960, 24, 8, 64, 520), (12, 2, 3, 3, 9)])
+def test_blockdiag_round_trip(R, rg, ng, cg, ld):
+    """ga_blockdiag_f32: the weight of a grouped 1x1 convolution [R][cg] <-> its block-diagonal image [R][ld] (GA-CSWin's grouped
+    gram_contraction as one dense product, ga_cswin.py:559-561)"""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R + cg)
+    src = torch.randn(R, cg, generator=g)
+    dst = torch.zeros(R, ld, device='cuda')
+    p = ops.Plan(eager=True)
+    p.blockdiag_f32(src.cuda(), dst, R, rg, ng, cg, ld)
+    want = torch.zeros(R, ld)
+    for r in range(R):
+        want[r, ((r // rg) % ng) * cg:((r // rg) % ng) * cg + cg] = src[r]
+    assert torch.equal(dst.cpu(), want)
+    back = torch.ones(R, cg, device='cuda')
+    p.blockdiag_f32(dst, back, R, rg, ng, cg, ld, to_diag=False, accumulate=True)
+    assert torch.equal(back.cpu(), src + 1)
