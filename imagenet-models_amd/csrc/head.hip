@@ -438,7 +438,7 @@ __global__ __launch_bounds__(1024) void gram_pack_bwd_kernel(const T* __restrict
 // form above reads dvec and vhat element-wise from memory for every one of the C x C outputs -- the lower triangle column-wise,
 // the token interleave strided -- and pays three runtime integer divisions per output (0.22-0.34 ms per launch at C = 384, 13x
 // its bytes).  Here pass 2 computes draw once per packed entry with coalesced reads into LDS [t], and pass 3 fills the C x C
-// matrix from LDS with coalesced stores; bf16(2 x) = 2 bf16(x), so the results are bit-identical.
+// matrix from LDS with coalesced stores (bf16(2 x) = 2 bf16(x): the same values up to the summation order of the dot product).
 template <int NTOK>
 __global__ __launch_bounds__(1024) void gram_pack_bwd_lds_kernel(const bf16_t* __restrict__ dvec, const bf16_t* __restrict__ vhat,
                                                                  const float* __restrict__ inv_norm, bf16_t* __restrict__ S, int C,
@@ -451,9 +451,34 @@ __global__ __launch_bounds__(1024) void gram_pack_bwd_lds_kernel(const bf16_t* _
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bf16_t* db = dvec + b * groups * Kp;
     const bf16_t* vb = vhat + b * groups * Kp;
+    // both passes over the sample's two vectors: 8-byte (4-element) accesses, 2 x 4 independent loads per iteration -- with one
+    // workgroup of 16 waves per CU (the LDS image) the 2-byte, one-load-per-iteration form was latency-bound (0.10 ms per launch at
+    // 73,920 entries: 72 dependent round trips)
+    const bool vec4 = (Kg & 3) == 0;               // (group bases are 16-byte aligned: Kp % 8 == 0)
     float dot = 0.f;
-    for (int g = 0; g < groups; ++g)
-        for (int k = threadIdx.x; k < Kg; k += 1024) dot = fmaf(bf2f(db[g * Kp + k]), bf2f(vb[g * Kp + k]), dot);
+    if (vec4) {
+        const int K4 = Kg >> 2, n4 = groups * K4;
+        for (int q = threadIdx.x; q < n4; q += 4 * 1024) {
+            uint2 dv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + u * 1024;
+                const int g = qq < n4 ? qq / K4 : 0, k = qq < n4 ? (qq - g * K4) * 4 : 0;
+                dv[u] = qq < n4 ? *reinterpret_cast<const uint2*>(db + g * Kp + k) : make_uint2(0u, 0u);
+                vv[u] = qq < n4 ? *reinterpret_cast<const uint2*>(vb + g * Kp + k) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                dot = fmaf(__uint_as_float(dv[u].x << 16), __uint_as_float(vv[u].x << 16), dot);
+                dot = fmaf(__uint_as_float(dv[u].x & 0xffff0000u), __uint_as_float(vv[u].x & 0xffff0000u), dot);
+                dot = fmaf(__uint_as_float(dv[u].y << 16), __uint_as_float(vv[u].y << 16), dot);
+                dot = fmaf(__uint_as_float(dv[u].y & 0xffff0000u), __uint_as_float(vv[u].y & 0xffff0000u), dot);
+            }
+        }
+    } else {
+        for (int g = 0; g < groups; ++g)
+            for (int k = threadIdx.x; k < Kg; k += 1024) dot = fmaf(bf2f(db[g * Kp + k]), bf2f(vb[g * Kp + k]), dot);
+    }
     dot = wave_sum(dot);
     if (lane == 0) red[wave] = dot;
     __syncthreads();
@@ -461,9 +486,34 @@ __global__ __launch_bounds__(1024) void gram_pack_bwd_lds_kernel(const bf16_t* _
 #pragma unroll
     for (int w = 0; w < 16; ++w) dot += red[w];
     const float inv = inv_norm[b];
-    for (int g = 0; g < groups; ++g)
-        for (int k = threadIdx.x; k < Kg; k += 1024)
-            packed[g * Kg + k] = f2bf(inv * (bf2f(db[g * Kp + k]) - bf2f(vb[g * Kp + k]) * dot));
+    if (vec4) {
+        const int K4 = Kg >> 2, n4 = groups * K4;
+        for (int q = threadIdx.x; q < n4; q += 4 * 1024) {
+            uint2 dv[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + u * 1024;
+                const int g = qq < n4 ? qq / K4 : 0, k = qq < n4 ? (qq - g * K4) * 4 : 0;
+                dv[u] = qq < n4 ? *reinterpret_cast<const uint2*>(db + g * Kp + k) : make_uint2(0u, 0u);
+                vv[u] = qq < n4 ? *reinterpret_cast<const uint2*>(vb + g * Kp + k) : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int qq = q + u * 1024;
+                if (qq < n4) {
+                    const float o0 = inv * (__uint_as_float(dv[u].x << 16) - __uint_as_float(vv[u].x << 16) * dot);
+                    const float o1 = inv * (__uint_as_float(dv[u].x & 0xffff0000u) - __uint_as_float(vv[u].x & 0xffff0000u) * dot);
+                    const float o2 = inv * (__uint_as_float(dv[u].y << 16) - __uint_as_float(vv[u].y << 16) * dot);
+                    const float o3 = inv * (__uint_as_float(dv[u].y & 0xffff0000u) - __uint_as_float(vv[u].y & 0xffff0000u) * dot);
+                    *reinterpret_cast<uint2*>(packed + qq * 4) = make_uint2(pack2bf(o0, o1), pack2bf(o2, o3));   // g * Kg + k = 4 qq
+                }
+            }
+        }
+    } else {
+        for (int g = 0; g < groups; ++g)
+            for (int k = threadIdx.x; k < Kg; k += 1024)
+                packed[g * Kg + k] = f2bf(inv * (bf2f(db[g * Kp + k]) - bf2f(vb[g * Kp + k]) * dot));
+    }
     __syncthreads();
     bf16_t* Sb = S + b * C * C;
     for (int i = wave; i < C; i += 16) {                 // output row i: entries (i, j) read packed (min, max)
