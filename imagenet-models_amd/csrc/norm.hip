@@ -507,8 +507,13 @@ static int ln_bwd_t(const void* g, const void* x, const float* mean, const float
                     void* dx2 = nullptr, const float* scale2 = nullptr, int64_t rows_per_scale = 1) {
     const int G = pick_group(C, elt<T>::EPC);
     const int rpb = 256 / G;
-    // persistent when parameter gradients are reduced (bounds the number of atomics)
-    dim3 grid(grid_blocks(rows, rpb, dw ? 1024 : 4096)), block(256);
+    // persistent when parameter gradients are reduced: every workgroup ends with 2 C atomics onto the same 2 C addresses, so the
+    // workgroup count trades bytes in flight against contended atomics (tools/r03/r03_lnb.sh, B = 256 stage shapes, ms at
+    // 1024 / 512 / 256 workgroups: C = 96 0.114 / 0.145 / 0.241; C = 192 0.065 / 0.052 / 0.071; C = 384 0.046 / 0.037 / 0.042;
+    // C = 768 0.040 / 0.027 / 0.028)
+    const int wgs_knob = GA_KNOB("LN_BWD_WGS", 0);
+    const int wgs = wgs_knob > 0 ? std::max(64, wgs_knob) : (C <= 128 ? 1024 : 512);
+    dim3 grid(grid_blocks(rows, rpb, dw ? wgs : 4096)), block(256);
     const size_t lds = dw ? (size_t)2 * rpb * C * sizeof(float) : 0;
     const int nch3 = C / elt<T>::EPC <= G ? 1 : (C / elt<T>::EPC <= 3 * G ? 2 : (C / elt<T>::EPC <= 4 * G ? 0 : 8));
     LN_DISPATCH(G, (w != nullptr || dw != nullptr), nch3, ln_bwd_kernel, grid, block, lds, s, (const T*)g, (const T*)x, mean, rstd, w, (const T*)dres, (T*)dx,
