@@ -55,10 +55,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int j = 0; j < kMaxCh; ++j) {
             const int ci = lg + G * j;
+            // UNCONDITIONAL loads from a clamped chunk + selects: as `ci < nch ? w[...] : 1` hipcc emitted one exec-masked branch
+            // with a single dword load per element -- 2 E dependent round trips per workgroup before its first row (44 us for ANY
+            // tensor of the step against 8-29 us for the form without parameters: tools/r03/ln_bench.py)
+            const int cc = ci < nch ? ci : 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                wv[j][e] = ci < nch ? w[ci * E + e] : 1.f;
-                bv[j][e] = ci < nch ? b[ci * E + e] : 0.f;
+                const float wl = w[cc * E + e], bl = b[cc * E + e];
+                wv[j][e] = ci < nch ? wl : 1.f;
+                bv[j][e] = ci < nch ? bl : 0.f;
             }
         }
     }
@@ -158,7 +163,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ g, co
             for (int e = 0; e < E; ++e) {
                 aw[j][e] = ab[j][e] = 0.f;
                 const int ci = lg + G * j;
-                wv[j][e] = (w && ci < nch) ? w[ci * E + e] : 1.f;
+                // (unconditional load from a clamped chunk + select: see ln_fwd_kernel)
+                const float* wsafe = w ? w : rstd;                 // any readable fp32 address when there is no weight
+                const float wl = wsafe[(w && ci < nch) ? ci * E + e : 0];
+                wv[j][e] = (w && ci < nch) ? wl : 1.f;
             }
     }
     // U rows per thread and iteration: measured SLOWER backward with U = 2 / 4 (block norm of C = 96: 0.097 vs 0.079 ms, affine
