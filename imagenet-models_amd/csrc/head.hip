@@ -284,12 +284,16 @@ __global__ __launch_bounds__(256) void chan_scale_kernel(const T* __restrict__ x
         const long e = (long)i * 8;
         const int c = (int)(i % P) << 3;
         const long b = i / PB;
-        float v[8];
+        float v[8], gv[8], av[8];
         load8(x + e, v);
+        // (two 32-byte loads, not 16 conditional dword loads in series: the per-element `if (g)` form compiled to one exec-masked
+        //  branch + load per element)
+        if (g) load8(g + b * C + c, gv);
+        if (add) load8(add + b * C + c, av);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            if (g) v[j] *= g[b * C + c + j];
-            if (add) v[j] += add[b * C + c + j];
+            if (g) v[j] *= gv[j];
+            if (add) v[j] += av[j];
         }
         store8(y + e, v);
     }
