@@ -547,10 +547,17 @@ __global__ __launch_bounds__(128 * NWM, (NWM == 2 && !DMA && !PRE && EPI >= 0 &&
 
     // ---- fused epilogue, two 64-row halves staged through LDS as fp32 [64][BN+4]
     float bias[8], csum[8], csq[8];
+    {
+        // unconditional loads from a clamped index + selects: as `cond ? d.bias[...] : 0` this was one exec-masked branch with a
+        // single dword load per element, eight L2 round trips in series at the top of EVERY tile's epilogue
+        const float* bsrc = d.bias ? d.bias + (long)z * d.strideBias : reinterpret_cast<const float*>(Bb);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bias[j] = (d.bias && n_ok && n + j < d.N) ? d.bias[z * d.strideBias + n + j] : 0.f;
-        csum[j] = csq[j] = 0.f;
+        for (int j = 0; j < 8; ++j) {
+            const bool live = d.bias && n_ok && n + j < d.N;
+            const float bl = bsrc[live ? n + j : 0];
+            bias[j] = live ? bl : 0.f;
+            csum[j] = csq[j] = 0.f;
+        }
     }
     long c_off = 0;
     if (F_UNPATCH && n_ok) {
@@ -995,10 +1002,16 @@ __global__ __launch_bounds__(kPPThreads) void gemm_nt_pp_kernel(const ga_gemm_de
             const int n = tile_n * 256 + wc * 64 + q * 8;
             const bool n_ok = n < d.N;                          // N % 8 == 0: a piece is wholly in or out
             float bias[8], csum[8], csq[8];
+            {
+                // (unconditional loads from a clamped index + selects: see gemm_nt_kernel's epilogue)
+                const bool live = d.bias && n_ok;
+                const float* bsrc = d.bias ? d.bias + (long)z * d.strideBias : reinterpret_cast<const float*>(Bb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bias[j] = (d.bias && n_ok) ? d.bias[(long)z * d.strideBias + n + j] : 0.f;
-                csum[j] = csq[j] = 0.f;
+                for (int j = 0; j < 8; ++j) {
+                    const float bl = bsrc[live ? n + j : 0];
+                    bias[j] = live ? bl : 0.f;
+                    csum[j] = csq[j] = 0.f;
+                }
             }
             const bool do_csum = (EPI == EPI_PLAIN || EPI == EPI_DG2) && d.colsum != nullptr;
             // the epilogue operand (dgrad2: stored GELU'; fc2: shortcut) of row piece tm+1 is requested while piece tm is staged
