@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize('family', ['', 'map_vit_small_patch16_224', 'map_pit_s'])
+@pytest.mark.parametrize('family', ['', 'map_vit_small_patch16_224', 'map_pit_s', 'ga_convnext_tiny_688'])
 def test_bucketed_allreduce_matches_whole_buffer_reduction(family):
     """'' = the narrow GA-ConvNeXt of tests/ddp_check.py; the two MAP trunks are the engines whose backward marks round 2's
-    ADVICE found ahead of pending weight-gradient jobs (full-size registered models, B = 2 per rank)"""
+    ADVICE found ahead of pending weight-gradient jobs (full-size registered models, B = 2 per rank); tiny_688: the padded parameter
+    gradients of the odd-width heads are copied back BEFORE the 'heads' mark (engine._unpad_all)"""
     env = dict(os.environ, GA_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', GA_DDP_FAMILY=family)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', '29533', os.path.join(ROOT, 'tests', 'ddp_check.py')]
