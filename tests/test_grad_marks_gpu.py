@@ -18,6 +18,7 @@ FAMILIES = [
     ('map_vit_small_patch16_224', {}, 2),
     ('map_pit_s', {}, 2),
     ('convnext_tiny', {}, 2),
+    ('ga_convnext_tiny_688', {}, 2),      # padded parameter gradients of the odd-width heads: copied back before the 'heads' mark
 ]
 
 
